@@ -1,0 +1,338 @@
+"""ctypes front-end of oracle/quad_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It mirrors the reference's duck-typed ``quad`` API
+(environment/quadrotor_env.py:111-577) on top of the plain-C fp64 restatement so
+parity tests can drive oracle and HIP path with the same calls.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libquad_oracle.so")
+
+VARIANT_MAIN, VARIANT_OPT = 0, 1
+INT_RK45, INT_DP5, INT_RK4 = 0, 1, 2
+INTEGRATORS = {"rk45": INT_RK45, "dp5": INT_DP5, "rk4": INT_RK4}
+
+_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds).  Safe to call repeatedly."""
+    src = os.path.join(_HERE, "quad_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    return _SO
+
+
+class _Env(C.Structure):
+    _fields_ = [
+        ("t_step", C.c_double), ("n", C.c_int), ("T", C.c_int), ("training", C.c_int),
+        ("direct", C.c_int), ("clipped", C.c_int), ("variant", C.c_int), ("integrator", C.c_int),
+        ("bb_cond", C.c_double * 9), ("zero_control", C.c_double * 4),
+        ("previous_state", C.c_double * 13), ("state", C.c_double * 13),
+        ("quat_state", C.c_double * 14),
+        ("ang", C.c_double * 3), ("prev_ang", C.c_double * 3), ("ang_vel", C.c_double * 3),
+        ("V_q", C.c_double * 4), ("w", C.c_double * 4), ("step_effort", C.c_double * 4),
+        ("clipped_action", C.c_double * 4), ("action", C.c_double * 4), ("accel", C.c_double * 3),
+        ("prev_shaping", C.c_double), ("has_prev_shaping", C.c_int),
+        ("i", C.c_int), ("done", C.c_int), ("solved", C.c_int),
+        ("reward", C.c_double), ("abs_sum", C.c_double),
+        ("target_state", C.c_double), ("current_state", C.c_double),
+        ("nfev", C.c_int), ("nsub", C.c_int),
+    ]
+
+
+class _Pid(C.Structure):
+    _fields_ = [("p", C.c_double * 6), ("i", C.c_double * 6), ("d", C.c_double * 6),
+                ("ix", C.c_double * 6), ("x_old", C.c_double * 6),
+                ("ang_d_ant", C.c_double * 3), ("ts", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        assert _lib.qo_env_size() == C.sizeof(_Env), "oracle struct layout drifted"
+        _lib.qo_batch_rollout.restype = C.c_long
+    return _lib
+
+
+def _a(x, n=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if n is not None:
+        assert x.size == n, (x.shape, n)
+    return x
+
+
+def _p(x):
+    return x.ctypes.data_as(_dp)
+
+
+# ---- functional wrappers ------------------------------------------------------
+def euler_quat(ang):
+    q = np.zeros(4)
+    lib().qo_euler_quat(_p(_a(ang, 3)), _p(q))
+    return q
+
+
+def quat_euler(q):
+    ang = np.zeros(3)
+    lib().qo_quat_euler(_p(_a(q, 4)), _p(ang))
+    return ang
+
+
+def deriv_quat(w, q):
+    dq = np.zeros(4)
+    lib().qo_deriv_quat(_p(_a(w, 3)), _p(_a(q, 4)), _p(dq))
+    return dq
+
+
+def quat_rot_mat(q):
+    R = np.zeros(9)
+    lib().qo_quat_rot_mat(_p(_a(q, 4)), _p(R))
+    return R.reshape(3, 3)
+
+
+def f2F(a):
+    w, F, M = np.zeros(4), C.c_double(), np.zeros(3)
+    lib().qo_f2F(_p(_a(a, 4)), _p(w), C.byref(F), _p(M))
+    return w, F.value, M
+
+
+def f2w(f, m, clipped=True, variant=VARIANT_MAIN):
+    se, w, F, M = np.zeros(4), np.zeros(4), C.c_double(), np.zeros(3)
+    lib().qo_f2w(int(variant), int(bool(clipped)), C.c_double(float(f)), _p(_a(m, 3)), _p(se), _p(w),
+                 C.byref(F), _p(M))
+    return se, w, F.value, M
+
+
+def lqr_gains(clipped=True):
+    kt, katt = np.zeros(6), np.zeros(6)
+    lib().qo_lqr_gains(int(bool(clipped)), _p(kt), _p(katt))
+    return kt.reshape(3, 2), katt.reshape(3, 2)
+
+
+def mlp_forward(x, W1, b1, W2, b2, W3, b3, final_tanh):
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    W1, b1, W2, b2, W3, b3 = (_a(v) for v in (W1, b1, W2, b2, W3, b3))
+    h, in_dim = W1.shape
+    out_dim = W3.shape[0]
+    y = np.zeros((x.shape[0], out_dim))
+    for r in range(x.shape[0]):
+        xr = _a(x[r])
+        lib().qo_mlp_forward(_p(xr), in_dim, h, out_dim, _p(W1), _p(b1), _p(W2), _p(b2), _p(W3), _p(b3),
+                             int(bool(final_tanh)), _p(y[r]))
+    return y
+
+
+def gae(values, masks, rewards, ddof):
+    values, masks, rewards = _a(values), _a(masks), _a(rewards)
+    n = rewards.size
+    assert values.size == n + 1 and masks.size == n
+    ret, adv = np.zeros(n), np.zeros(n)
+    lib().qo_gae(_p(values), _p(masks), _p(rewards), n, int(ddof), _p(ret), _p(adv))
+    return ret, adv
+
+
+def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, ang, v_ang):
+    out = np.zeros(4)
+    ls = 0.0 if last_shaping is None else float(last_shaping)
+    lib().qo_visual_reward(int(total_steps), _p(_a(marker, 3)), _p(_a(pos, 3)), _p(_a(vel, 3)),
+                           _p(_a(control, 3)), C.c_double(ls), int(step), _p(_a(ang, 3)), _p(_a(v_ang, 3)),
+                           _p(out))
+    return out[0], out[1], bool(out[2]), int(out[3])
+
+
+def random_init_states(seed_or_rng, n_envs=1):
+    """Replay of quad.reset()'s random branch draw order (quadrotor_env.py:426,440-445,
+    robust_control.reset :97-101), one env after another on ONE legacy MT19937 stream
+    (the reference uses the global np.random).  Returns float64 [n_envs, 13]."""
+    rng = seed_or_rng if isinstance(seed_or_rng, np.random.RandomState) else np.random.RandomState(seed_or_rng)
+    out = np.zeros((n_envs, 13))
+    for k in range(n_envs):
+        rng.random_sample(4); rng.normal(0, 0.3, 1); rng.random_sample(4)
+        rng.normal(np.zeros(3), 0.1 * np.ones(3), [3])
+        ang = rng.rand(3) - 0.5
+        q = euler_quat(ang)
+        out[k, 0:5:2] = np.clip(rng.normal([0, 0, 0], 2), -2.5, 2.5)
+        out[k, 1:6:2] = np.clip(rng.normal([0, 0, 0], 2), -5.0, 5.0)
+        out[k, 6:10] = q
+        out[k, 10:13] = np.clip(rng.normal([0, 0, 0], 2), -15.0, 7.5)
+    return out
+
+
+def batch_rollout(states, steps, t_step=0.01, direct=1, variant=VARIANT_MAIN, integrator="rk45",
+                  controller=0, act=None):
+    """N independent envs advanced `steps` steps (after reset's single warm-up step).
+    controller: 0 constant action, 1 LQR, 2 PID.  Returns (final states [N,13], reward sums [N])."""
+    s = np.array(states, dtype=np.float64, order="C").reshape(-1, 13)
+    rs = np.zeros(s.shape[0])
+    act = _a(np.zeros(4) if act is None else act, 4)
+    lib().qo_batch_rollout(s.shape[0], int(steps), C.c_double(t_step), int(direct), int(variant),
+                           INTEGRATORS[integrator], int(controller), _p(act), _p(s), _p(rs))
+    return s, rs
+
+
+# ---- quad-compatible class ------------------------------------------------------
+class OracleQuad:
+    """Same call surface as reference ``quad`` (quadrotor_env.py:111-577).
+
+    variant="opt" follows quadrotor_env_opt.py (``training`` then plays PPO_TRAINING).
+    integrator: "rk45" = scipy-exact adaptive DP5(4) (reference behaviour),
+    "dp5" = one fixed DP5 step, "rk4" = classic RK4.
+    """
+
+    def __init__(self, t_step, n, training=True, euler=0, direct_control=1, T=1, clipped=True,
+                 variant="main", integrator="rk45"):
+        self._e = _Env()
+        self._variant = VARIANT_OPT if variant == "opt" else VARIANT_MAIN
+        lib().qo_init(C.byref(self._e), C.c_double(t_step), int(n), int(bool(training)), int(bool(direct_control)),
+                      int(T), int(bool(clipped)), self._variant, INTEGRATORS[integrator])
+        self.T = T
+        self.t_step = t_step
+        self.mass, self.gravity = 1.03, 9.82
+        self.J_mat = np.diag([16.83e-3, 16.83e-3, 28.34e-3])
+        self.state_size, self.action_size = 13, 4
+        self._rng = np.random.RandomState()
+
+    def seed(self, seed):
+        self._rng = np.random.RandomState(seed)
+
+    # attribute views
+    def _vec(self, name):
+        return np.array(getattr(self._e, name)[:])
+
+    state = property(lambda s: s._vec("state"))
+    previous_state = property(lambda s: s._vec("previous_state"))
+    quat_state = property(lambda s: s._vec("quat_state")[None, :])
+    ang = property(lambda s: s._vec("ang"))
+    prev_ang = property(lambda s: s._vec("prev_ang"))
+    ang_vel = property(lambda s: s._vec("ang_vel"))
+    w = property(lambda s: s._vec("w")[:, None])
+    step_effort = property(lambda s: s._vec("step_effort"))
+    clipped_action = property(lambda s: s._vec("clipped_action"))
+    zero_control = property(lambda s: s._vec("zero_control"))
+    bb_cond = property(lambda s: s._vec("bb_cond"))
+    accel = property(lambda s: s._vec("accel")[:, None])
+    i = property(lambda s: s._e.i)
+    n = property(lambda s: s._e.n)
+    done = property(lambda s: bool(s._e.done))
+    solved = property(lambda s: s._e.solved)
+    reward = property(lambda s: s._e.reward)
+    abs_sum = property(lambda s: s._e.abs_sum)
+    nfev = property(lambda s: s._e.nfev)
+    nsub = property(lambda s: s._e.nsub)
+    prev_shaping = property(lambda s: s._e.prev_shaping if s._e.has_prev_shaping else None)
+
+    def drone_eq(self, t, x, action):
+        out = np.zeros(13)
+        lib().qo_drone_eq(C.byref(self._e), _p(_a(x, 13)), _p(_a(action, 4)), _p(out))
+        return out
+
+    def set_w(self, w):
+        for k in range(4):
+            self._e.w[k] = float(np.asarray(w).ravel()[k])
+
+    def set_previous_state(self, x):
+        x = _a(x, 13)
+        for k in range(13):
+            self._e.previous_state[k] = x[k]
+
+    def reset(self, det_state=None):
+        if det_state is None:
+            if self._variant == VARIANT_OPT:  # no robust_parameters draws in the opt variant
+                rng = self._rng
+                ang = rng.rand(3) - 0.5
+                s = np.zeros(13)
+                s[0:5:2] = np.clip(rng.normal([0, 0, 0], 2), -2.5, 2.5)
+                s[1:6:2] = np.clip(rng.normal([0, 0, 0], 2), -5.0, 5.0)
+                s[6:10] = euler_quat(ang)
+                s[10:13] = np.clip(rng.normal([0, 0, 0], 2), -15.0, 7.5)
+            else:
+                s = random_init_states(self._rng, 1)[0]
+        else:
+            s = _a(det_state, 13)
+        states = np.zeros((self.T, 14))
+        actions = np.zeros((self.T, 4))
+        lib().qo_reset(C.byref(self._e), _p(s), _p(states), _p(actions))
+        return states, actions
+
+    def step(self, action):
+        lib().qo_step(C.byref(self._e), _p(_a(action, 4)))
+        return self.quat_state, self._e.reward, bool(self._e.done)
+
+
+class OraclePid:
+    """pid_control of environment/controller/pid_vel_control.py:29-110 (targets passed in)."""
+
+    def __init__(self, env, clipped=True):
+        self.env = env
+        self._c = _Pid()
+        lib().qo_pid_init(C.byref(self._c), int(bool(clipped)))
+
+    def control(self, xd, dxd, psd, dpsd):
+        a = np.zeros(4)
+        lib().qo_pid_action(C.byref(self._c), C.byref(self.env._e), _p(_a(xd, 3)), C.c_double(float(psd)), _p(a))
+        return a
+
+
+class OracleLqr:
+    """Control law of environment/controller/lqr_quad.py:128-154."""
+
+    def __init__(self, env, clipped=True):
+        self.env = env
+        self.kt, self.katt = lqr_gains(clipped)
+
+    def control(self):
+        a = np.zeros(4)
+        lib().qo_lqr_action(C.byref(self.env._e), _p(_a(self.kt)), _p(_a(self.katt)), _p(a))
+        return a
+
+
+class OracleWindow:
+    """dl_in_gen of environment/controller/dl_auxiliary.py:15-32."""
+
+    def __init__(self, T, state_size=13, action_size=4):
+        self.T = T
+        self.hist_size = (state_size - 3) + action_size + 1
+        self.reset()
+
+    def reset(self):
+        self.deep_learning_input = np.zeros(self.hist_size * self.T, dtype=np.float32)
+
+    def dl_input(self, states, actions):
+        fp = C.POINTER(C.c_float)
+        for s, a in zip(np.atleast_2d(states), np.atleast_2d(actions)):
+            lib().qo_dl_input(self.deep_learning_input.ctypes.data_as(fp), self.T, _p(_a(s, 14)), _p(_a(a, 4)))
+        return self.deep_learning_input
+
+
+def reward_case(variant, training, state, ang, action, prev_shaping, i, done, n=100, T=1):
+    """Drive done_condition()+reward_function() on a hand-set env (golden G7)."""
+    env = OracleQuad(0.01, n, training=training, direct_control=1, T=T,
+                     variant="opt" if variant else "main")
+    e = env._e
+    for k in range(13):
+        e.state[k] = float(state[k])
+    for k in range(3):
+        e.ang[k] = float(ang[k])
+    for k in range(4):
+        e.action[k] = float(action[k])
+    e.has_prev_shaping = 0 if prev_shaping is None or np.isnan(prev_shaping) else 1
+    e.prev_shaping = 0.0 if not e.has_prev_shaping else float(prev_shaping)
+    e.i = int(i)
+    e.done = int(bool(done))
+    e.solved = 0
+    lib().qo_done_condition(C.byref(e))
+    lib().qo_reward_function(C.byref(e))
+    return e.reward, bool(e.done), e.solved, e.prev_shaping

@@ -1,0 +1,259 @@
+"""CPU: the C oracle (oracle/quad_oracle.c) against golden vectors produced by the
+reference itself (oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from .conftest import golden, rel_err
+
+TOL = 1e-11  # fp64 restatement vs fp64 reference
+
+
+def test_g1_utils(oracle):
+    g = golden("g1_utils")
+    for k in range(len(g["ang"])):
+        assert rel_err(oracle.euler_quat(g["ang"][k]), g["q"][k]) < 1e-13
+        assert rel_err(oracle.quat_euler(g["q"][k]), g["ang_back"][k]) < 1e-12
+    for k in range(len(g["w"])):
+        assert rel_err(oracle.deriv_quat(g["w"][k], g["qn"][k]), g["dq"][k]) < 1e-13
+        assert rel_err(oracle.quat_rot_mat(g["qn"][k]), g["R"][k]) < 1e-13
+
+
+def test_g2_rhs(oracle):
+    g = golden("g2_rhs")
+    env_d = oracle.OracleQuad(0.01, 1000, direct_control=1)
+    env_o = oracle.OracleQuad(0.01, 1000, direct_control=1, variant="opt")
+    env_i = oracle.OracleQuad(0.01, 1000, direct_control=0)
+    for k in range(len(g["X"])):
+        assert rel_err(env_d.drone_eq(0, g["X"][k], g["A"][k]), g["dx_direct"][k], 1e-6) < TOL
+        assert rel_err(env_o.drone_eq(0, g["X"][k], g["A"][k]), g["dx_opt"][k], 1e-6) < TOL
+        env_i.set_w(g["w_indirect"][k])
+        assert rel_err(env_i.drone_eq(0, g["X"][k], g["u_indirect"][k]), g["dx_indirect"][k], 1e-6) < TOL
+
+
+def test_g3_mixing(oracle):
+    g = golden("g3_mixing")
+    for k in range(len(g["A"])):
+        w, F, M = oracle.f2F(g["A"][k])
+        assert rel_err(w, g["w_f2F"][k]) < 1e-13 and abs(F - g["F_f2F"][k]) < 1e-12
+        assert rel_err(M, g["M_f2F"][k], 1e-6) < 1e-10
+        for clipped, tag in ((True, "clipped"), (False, "unclipped")):
+            se, w, Fn, Mn = oracle.f2w(g["FM"][k, 0], g["FM"][k, 1:], clipped=clipped)
+            assert rel_err(se, g["se_" + tag][k]) < 1e-10
+            assert rel_err(w, g["w_" + tag][k], 1.0) < 1e-9
+            assert rel_err(np.append(Fn, Mn), g["FM_" + tag][k], 1e-3) < 1e-10
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("g4_step_direct", dict(direct_control=1)),
+    ("g4_step_indirect", dict(direct_control=0)),
+    ("g4_step_indirect_unclipped", dict(direct_control=0, clipped=False)),
+    ("g4_step_direct_eval", dict(direct_control=1, training=False)),
+    ("g13_step_opt_direct", dict(direct_control=1, variant="opt", training=False)),
+    ("g13_step_opt_indirect", dict(direct_control=0, variant="opt", training=False)),
+])
+def test_g4_reset_then_step(oracle, name, kw):
+    g = golden(name)
+    n = len(g["x0"])
+    for k in range(n):
+        env = oracle.OracleQuad(0.01, 1000, T=1, **kw)
+        env.reset(g["x0"][k])
+        # exact hover in indirect mode is rounding-degenerate: f0 is ~1e-15 and whether
+        # select_initial_step sees d1<=1e-15 depends on LAPACK's LU rounding inside f2w
+        # (np.linalg.solve, quadrotor_env.py:216) -- the sub-step count differs, the
+        # state does not (checked below to 1e-11).
+        degenerate = (not kw["direct_control"]) and k % 16 == 0
+        assert degenerate or env.nfev == g["nfev_reset"][k], (k, env.nfev, g["nfev_reset"][k])
+        for pre, do in (("r_", None), ("s_", g["action"][k])):
+            if do is not None:
+                env.step(do)
+                assert degenerate or env.nfev == g["nfev_step"][k]
+            assert rel_err(env.state, g[pre + "state"][k]) < TOL, (name, k, pre)
+            assert rel_err(env.quat_state.ravel(), g[pre + "quat_state"][k]) < TOL
+            assert rel_err(env.ang, g[pre + "ang"][k]) < 1e-10
+            assert rel_err(env.ang_vel, g[pre + "ang_vel"][k], 1e-1) < 1e-9
+            assert abs(env.reward - g[pre + "reward"][k]) < 1e-9, (name, k, pre, env.reward, g[pre + "reward"][k])
+            assert env.done == bool(g[pre + "done"][k]) and env.solved == int(g[pre + "solved"][k])
+            assert env.i == int(g[pre + "i"][k])
+            assert rel_err(env.step_effort, g[pre + "step_effort"][k]) < 1e-9
+            assert rel_err(env.clipped_action, g[pre + "clipped_action"][k]) < 1e-9
+            assert abs(env.abs_sum - g[pre + "abs_sum"][k]) < 1e-9
+            if not kw["direct_control"] or pre == "s_":
+                assert rel_err(env.w.ravel(), g[pre + "w"][k], 1.0) < 1e-9
+
+
+def test_g5_reset_seeded(oracle):
+    g = golden("g5_reset")
+    for direct in (1, 0):
+        for T in (1, 5):
+            for seed in range(16):
+                x0 = oracle.random_init_states(seed, 1)[0]
+                assert rel_err(x0, g[f"x0_d{direct}_T{T}"][seed]) < 1e-14
+                env = oracle.OracleQuad(0.01, 1000, direct_control=direct, T=T)
+                env.seed(seed)
+                s, a = env.reset()
+                assert s.shape == (T, 14) and a.shape == (T, 4)
+                assert rel_err(s, g[f"states_d{direct}_T{T}"][seed]) < TOL
+                assert np.array_equal(a, g[f"actions_d{direct}_T{T}"][seed])
+    env = oracle.OracleQuad(0.01, 1000, direct_control=1, T=1)
+    env.seed(7)
+    s1, _ = env.reset()
+    s2, _ = env.reset()
+    assert rel_err(np.array([s1, s2]), g["two_resets_seed7"]) < TOL
+    envo = oracle.OracleQuad(0.01, 1000, direct_control=1, T=1, variant="opt", training=False)
+    envo.seed(3)
+    so, _ = envo.reset()
+    assert rel_err(so, g["opt_seed3"]) < TOL
+
+
+def _cmp_traj(rows, g, tol_state, tol_rest=None):
+    ref = g["traj"]
+    rows = np.array(rows)
+    e_state = rel_err(rows[:, :13], ref[:, :13])
+    assert e_state < tol_state, e_state
+    assert rel_err(rows[:, 13:16], ref[:, 13:16]) < (tol_rest or tol_state * 10)
+    assert np.array_equal(rows[:, 24:26], ref[:, 24:26])  # done, solved
+    assert np.max(np.abs(rows[:, 23] - ref[:, 23])) < 1e-6  # reward
+    return e_state
+
+
+def _rec(env):
+    return np.concatenate([env.state, env.ang, env.ang_vel, env.step_effort,
+                           [env.reward, float(env.done), float(env.solved)]])
+
+
+def test_g6_pid_config1(oracle):
+    """BASELINE config 1: 1 env, PID, seed 1, 1000 steps (pid_vel_control.py:131-164)."""
+    g = golden("g6_pid_seed1")
+    env = oracle.OracleQuad(0.01, 1000, training=True, direct_control=0, T=5, clipped=True)
+    env.seed(1)
+    env.reset()
+    ctl = oracle.OraclePid(env)
+    action = np.array([9.82 * 1.03, 0, 0, 0])
+    rows = []
+    for k in range(1000):
+        env.step(action)
+        assert rel_err(action, g["actions"][k], 1e-2) < 1e-6, k
+        action = ctl.control([0, 0, 0], [0, 0, 0], 0, 0)
+        rows.append(_rec(env))
+    _cmp_traj(rows, g, 1e-8, 1e-6)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_g6_lqr(oracle, seed):
+    g = golden(f"g6_lqr_seed{seed}")
+    env = oracle.OracleQuad(0.01, 500, training=True, direct_control=0, T=1, clipped=True)
+    env.seed(seed)
+    env.reset()
+    ctl = oracle.OracleLqr(env)
+    rows = []
+    for k in range(500):
+        a = ctl.control()
+        assert rel_err(a, g["actions"][k], 1e-2) < 1e-6, k
+        env.step(a)
+        rows.append(_rec(env))
+    _cmp_traj(rows, g, 1e-8, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["g6_hover", "g6_hover_perturbed"])
+def test_g6_hover(oracle, name):
+    g = golden(name)
+    env = oracle.OracleQuad(0.01, 2000, training=False, direct_control=1, T=1)
+    env.reset(g["x0"])
+    rows, nfev = [], []
+    for k in range(1000):
+        env.step(np.zeros(4))
+        rows.append(_rec(env)); nfev.append(env.nfev)
+    assert np.array_equal(np.array(nfev), g["nfev"])
+    _cmp_traj(rows, g, 1e-9)
+
+
+def test_g7_reward_branches(oracle):
+    g = golden("g7_reward")["cases"]
+    hit = set()
+    for row in g:
+        variant, training = int(row[0]), bool(row[1])
+        st, ang, act = row[2:15], row[15:18], row[18:22]
+        prev, i, d0 = row[22], row[23], row[24]
+        r, done, solved, shaping = oracle.reward_case(variant, training, st, ang, act, prev, i, d0)
+        assert abs(r - row[25]) < 1e-10, row
+        assert done == bool(row[26]) and solved == int(row[27])
+        assert abs(shaping - row[28]) < 1e-10
+        hit.add((variant, done, solved))
+    assert len(hit) >= 5  # solved / timeout / broken / running branches of both variants
+
+
+def test_g8_window_and_g9_mlp(oracle):
+    for N in (16, 128):
+        g = golden(f"g9_mlp_N{N}")
+        for head, final_tanh, key in (("actor", True, "mean64"), ("critic", False, "value64")):
+            W = [g[f"{head}_{l}_{p}"] for l in (0, 2, 4) for p in ("weight", "bias")]
+            y = oracle.mlp_forward(g["obs"].astype(np.float64), *W, final_tanh)
+            assert rel_err(y, g[key], 1e-3) < 1e-12
+            assert rel_err(y, g[key.replace("64", "32")], 1.0) < 5e-6  # fp32 torch forward
+    g = golden("g6_ppo128_seed1")
+    env = oracle.OracleQuad(0.01, 500, training=False, direct_control=1, T=5)
+    env.seed(1)
+    s, a = env.reset()
+    win = oracle.OracleWindow(5)
+    win.dl_input(s, a)
+    w0 = win.dl_input(s, a).copy()
+    assert np.array_equal(w0, g["windows"][0].astype(np.float32))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_g6_ppo_actor_in_loop(oracle, seed):
+    """ppo_quad_eval.py:44-62 with the checked-in N=128 weights; the reference runs the
+    actor in fp32 torch, the oracle in fp64, so the match is to fp32 forward noise."""
+    g = golden(f"g6_ppo128_seed{seed}")
+    w = golden("g9_mlp_N128")
+    W = [w[f"actor_{l}_{p}"] for l in (0, 2, 4) for p in ("weight", "bias")]
+    env = oracle.OracleQuad(0.01, 500, training=False, direct_control=1, T=5)
+    env.seed(seed)
+    s, a = env.reset()
+    win = oracle.OracleWindow(5)
+    win.dl_input(s, a)
+    obs = win.dl_input(s, a)
+    rows = []
+    for k in range(500):
+        act = oracle.mlp_forward(obs.astype(np.float64), *W, True)[0]
+        assert np.max(np.abs(act - g["actions"][k])) < 5e-4, k
+        q, _, _ = env.step(act)
+        obs = win.dl_input(q, act[None, :])
+        rows.append(_rec(env))
+    rows = np.array(rows)
+    assert rel_err(rows[:, :13], g["traj"][:, :13]) < 5e-4
+
+
+def test_g10_gae(oracle):
+    g = golden("g10_gae")
+    for n in (12, 1000):
+        ret, adv = oracle.gae(g[f"values_{n}"], g[f"masks_{n}"], g[f"rewards_{n}"], ddof=0)
+        assert rel_err(ret, g[f"ret_ppo_{n}"]) < 1e-12 and rel_err(adv, g[f"adv_ppo_{n}"]) < 1e-10
+        ret, adv = oracle.gae(g[f"values_{n}"], g[f"masks_{n}"], g[f"rewards_{n}"], ddof=1)
+        # ppo_trainer.py runs this in fp32 tensors: compare at fp32 resolution
+        assert rel_err(ret, g[f"ret_trainer_{n}"], 1.0) < 1e-5 and rel_err(adv, g[f"adv_trainer_{n}"], 1.0) < 1e-5
+
+
+def test_g11_visual_reward(oracle):
+    rows = golden("g11_visual_reward")["rows"]
+    seen = set()
+    for r in rows:
+        last = None if np.isnan(r[12]) else r[12]
+        out = oracle.visual_reward(500, r[0:3], r[3:6], r[6:9], r[9:12], last, int(r[13]), r[14:17], r[17:20])
+        assert abs(out[0] - r[20]) < 1e-12 and abs(out[1] - r[21]) < 1e-12
+        assert out[2] == bool(r[22]) and out[3] == int(r[23])
+        seen.add(r[20] if r[22] else "run")
+    assert {5.0, 1.0, 0.0, -1.0, -5.0, -2.0, "run"} <= seen, seen
+
+
+def test_g12_lqr_gains(oracle):
+    g = golden("g12_lqr_gains")
+    kt, katt = oracle.lqr_gains(True)
+    assert rel_err(kt[0], g["K_t"][0, 0:2], 1e-6) < 1e-7 and rel_err(kt[1], g["K_t"][1, 2:4], 1e-6) < 1e-7
+    assert rel_err(kt[2], g["K_t"][2, 4:6], 1e-6) < 1e-7
+    for a in range(3):
+        assert rel_err(katt[a], g["K_att"][a + 1, 2 * a:2 * a + 2], 1e-6) < 1e-9
+    off = g["K_t"].copy()
+    for a in range(3):
+        off[a, 2 * a:2 * a + 2] = 0
+    assert np.max(np.abs(off)) < 1e-9
