@@ -1,0 +1,17 @@
+"""MI355X-native batched quadrotor RL environment.
+
+Drop-in for the hot path of rafaelcostafrf/autonomous_quadrotor_environment: the `quad`
+reset()/step()/reward API (environment/quadrotor_env.py), the LQR / PID inner-loop
+controllers, the PPO observation window + actor MLP and GAE -- executed by hand-written
+HIP kernels for gfx950 behind the C-ABI in include/qenv.h.  PyTorch is used only for
+device memory, streams and torch.distributed.
+"""
+from . import _lib  # noqa: F401  (raises if libqenv.so is missing: no CPU fallback)
+from .quadrotor_env import BatchedQuad, quad, random_init_states, euler_quat, quat_euler  # noqa: F401
+from .controllers import LqrController, PidController, pid_control  # noqa: F401
+from .ppo import ActorCriticWeights, dl_in_gen, gae, visual_reward, PolicyRollout  # noqa: F401
+from .distributed import shard_range, ShardedQuad, all_gather_returns  # noqa: F401
+
+__all__ = ["BatchedQuad", "quad", "random_init_states", "LqrController", "PidController", "pid_control",
+           "ActorCriticWeights", "dl_in_gen", "gae", "visual_reward", "PolicyRollout", "shard_range",
+           "ShardedQuad", "all_gather_returns"]

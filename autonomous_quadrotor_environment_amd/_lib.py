@@ -1,0 +1,83 @@
+"""ctypes binding of libqenv.so (the C-ABI declared in include/qenv.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is
+missing or a symbol cannot be bound, importing this module raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqenv.so")
+
+QENV_ABI_VERSION = 1
+F32, F64 = 0, 1
+MAIN, OPT = 0, 1
+RK45, DP5, RK4 = 0, 1, 2
+INTEGRATORS = {"rk45": RK45, "dp5": DP5, "rk4": RK4}
+VARIANTS = {"main": MAIN, "opt": OPT}
+CTRL_CONST, CTRL_LQR, CTRL_PID = 0, 1, 2
+STEP_FULL, STEP_DYNAMICS_ONLY, STEP_NO_AUX = 0, 1, 2
+FLAG_DONE, FLAG_SOLVED, FLAG_HAS_SHAPING = 1, 2, 4
+
+(FIELD_STATE, FIELD_ANG, FIELD_PREV_ANG, FIELD_ANG_VEL, FIELD_VQ, FIELD_W, FIELD_STEP_EFFORT,
+ FIELD_CLIPPED_ACTION, FIELD_ACCEL, FIELD_PREV_SHAPING, FIELD_REWARD, FIELD_ABS_SUM, FIELD_EP_RETURN,
+ FIELD_PID, FIELD_I, FIELD_FLAGS, FIELD_WINDOW) = range(17)
+
+
+class QenvConfig(C.Structure):
+    _fields_ = [("n_envs", C.c_int64), ("t_step", C.c_double), ("n_max", C.c_int32), ("T", C.c_int32),
+                ("training", C.c_int32), ("direct_control", C.c_int32), ("clipped", C.c_int32),
+                ("variant", C.c_int32), ("integrator", C.c_int32), ("dtype", C.c_int32)]
+
+
+class QenvError(RuntimeError):
+    pass
+
+
+# every symbol include/qenv.h declares: (name, restype, argtypes)
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+_dptr = C.POINTER(C.c_double)
+SYMBOLS = {
+    "qenv_abi_version": (_i, []),
+    "qenv_last_error": (C.c_char_p, []),
+    "qenv_workspace_bytes": (C.c_size_t, [C.POINTER(QenvConfig)]),
+    "qenv_create": (_i, [C.POINTER(QenvConfig), _vp, C.c_size_t, _vp, C.POINTER(_vp)]),
+    "qenv_destroy": (_i, [_vp]),
+    "qenv_set_stream": (_i, [_vp, _vp]),
+    "qenv_field": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_int32)]),
+    "qenv_reset": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "qenv_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "qenv_rollout": (_i, [_vp, _i, _i, _dptr, _i, _i]),
+    "qenv_lqr_action": (_i, [_vp, _vp]),
+    "qenv_pid_action": (_i, [_vp, _dptr, _vp]),
+    "qenv_pid_reset": (_i, [_vp, _vp]),
+    "qenv_window_push": (_i, [_vp, _vp, _vp, _i]),
+    "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_adv_normalize": (_i, [_i, _i64, _vp, _vp, _i, _vp]),
+    "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 14),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+        "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SYMBOLS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+if lib.qenv_abi_version() != QENV_ABI_VERSION:
+    raise ImportError(f"libqenv.so ABI {lib.qenv_abi_version()} != binding {QENV_ABI_VERSION}")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.qenv_last_error()
+        raise QenvError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,539 @@
+// qenv_core.hpp -- device-side math of the quadrotor hot path (gfx950 / CDNA4).
+//
+// One wavefront lane integrates one quadrotor.  Everything here is written so that
+// the whole env-step lives in VGPRs: fully unrolled Butcher tableaus, no local arrays
+// indexed at run time, wave-uniform configuration in SGPRs (kernel arguments).
+//
+// Reference behaviour restated (file:line relative to /root/reference):
+//   environment/quadrotor_env.py            f2F :247, f2w :197, drone_eq :274, step :458,
+//                                           done_condition :500, reward_function :511
+//   environment/quadrotor_env_opt.py        the "opt" variant of the same functions
+//   environment/quaternion_euler_utility.py quat_euler :39, deriv_quat :58, quat_rot_mat :71
+//   scipy/integrate/_ivp/{rk,common}.py     RK45 / select_initial_step (third party)
+//   environment/controller/lqr_quad.py:128-154, pid_vel_control.py:29-127
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qenv {
+
+// ---- scalar math per precision --------------------------------------------------------
+template <typename T> struct Mth;
+template <> struct Mth<float> {
+    static __device__ __forceinline__ float sqrt(float x) { return __fsqrt_rn(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return rsqrtf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
+    static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
+    static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
+    static __device__ __forceinline__ float asin(float x) { return asinf(x); }
+    static __device__ __forceinline__ float cos(float x) { return cosf(x); }
+    static __device__ __forceinline__ float sin(float x) { return sinf(x); }
+    static __device__ __forceinline__ float tan(float x) { return tanf(x); }
+    static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
+    static __device__ __forceinline__ float ulp_up(float t) { return nextafterf(t, INFINITY) - t; }
+};
+template <> struct Mth<double> {
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double abs(double x) { return fabs(x); }
+    static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
+    static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double tan(double x) { return ::tan(x); }
+    static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double ulp_up(double t) { return nextafter(t, (double)INFINITY) - t; }
+};
+
+// ---- physical constants (quadrotor_env.py:30-81), folded at compile time ----------------
+namespace phys {
+constexpr double M = 1.03, G = 9.82, RHO = 1.2041, C_D = 1.1;
+constexpr double K_F = 1.435e-5, K_M = 2.4086e-7, I_R = 5e-5, T2WR = 2.0;
+constexpr double JX = 16.83e-3, JY = 16.83e-3, JZ = 28.34e-3;
+constexpr double D = 0.26, BEAM = 0.05;
+constexpr double AX = BEAM * 2 * D, AY = BEAM * 2 * D, AZ = BEAM * 2 * D * 2;
+constexpr double PI = 3.14159265358979323846;
+constexpr double BB_VEL = 10.0, BB_ANG = PI / 2;
+// drag force coefficient 0.5 rho C_d A_k (drone_eq :323)
+constexpr double KDX = 0.5 * RHO * C_D * AX, KDY = 0.5 * RHO * C_D * AY, KDZ = 0.5 * RHO * C_D * AZ;
+// drag moments (drone_eq :328-334): sum over xx_j = D j/9, j=0..9, of xx^3 (main) or
+// xx^2 (opt, quadrotor_env_opt.py:260-263)
+constexpr double SUM_XX3 = D * D * D * 2025.0 / 729.0;
+constexpr double SUM_XX2 = D * D * 285.0 / 81.0;
+constexpr double CM0 = RHO * C_D * BEAM * D / 10.0;
+constexpr double F_MAX_ROTOR = T2WR * M * G / 4.0;   // 5.0573 N
+constexpr double U_MAX = F_MAX_ROTOR / K_F;          // max squared rotor speed
+}  // namespace phys
+
+// Wave-uniform configuration, passed by value in the kernel argument segment (SGPRs).
+template <typename T> struct Cfg {
+    T t_step;
+    T cm_xy, cm_z;   // drag-moment coefficients of the selected variant
+    T bb[9];         // done box: |v|(3), |ang|(3), |omega|(3)
+    T zero_control0; // zero_control = [zc0,0,0,0] (indirect) or [zc0]*4 (direct, zc0=0)
+    int32_t n_max;   // n + T
+    int32_t training, direct, clipped, variant;
+};
+
+// Actuation held constant over one env step: thrust, body moments and the rotor
+// gyroscopic term (drone_eq :287-292,:345).  Hoisted out of the RHS: the reference
+// recomputes f2F (4 sqrt) in every RHS evaluation although the action is constant.
+template <typename T> struct Act {
+    T F, Mx, My, Mz, omr;  // omr = (-w1+w2-w3+w4)*I_R
+};
+
+// f2F, quadrotor_env.py:247-272 (direct mode).  a = clipped action in [-1,1].
+template <typename T>
+__device__ __forceinline__ void mix_direct(const T a[4], T w[4], Act<T>& u) {
+    using m = Mth<T>;
+    const T c = T(phys::T2WR * phys::M * phys::G / 8.0);
+    T f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[k] = (a[k] + T(1)) * c;
+        w[k] = m::sqrt(f[k] * T(1.0 / phys::K_F));
+    }
+    u.F = (f[0] + f[1]) + (f[2] + f[3]);
+    u.Mx = (f[2] - f[0]) * T(phys::D);
+    u.My = (f[1] - f[3]) * T(phys::D);
+    u.Mz = ((f[1] - f[0]) + (f[3] - f[2])) * T(phys::K_M / phys::K_F);
+    u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
+}
+
+// f2w, quadrotor_env.py:197-245 / quadrotor_env_opt.py:144-176 (indirect mode), with the
+// closed-form inverse of the 4x4 mixing matrix.
+template <typename T>
+__device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool opt, T w[4], T effort[4],
+                                             T cl[4], Act<T>& u) {
+    using m = Mth<T>;
+    const T a = act[0] * T(1.0 / (4 * phys::K_F));
+    const T bx = act[1] * T(1.0 / (2 * phys::D * phys::K_F));
+    const T by = act[2] * T(1.0 / (2 * phys::D * phys::K_F));
+    const T c = act[3] * T(1.0 / (4 * phys::K_M));
+    T s[4] = {a - bx - c, a + by + c, a + bx - c, a - by + c};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (clipped || opt) {
+            s[k] = m::min(m::max(s[k], T(0)), T(phys::U_MAX));
+            w[k] = m::sqrt(s[k]);
+        } else {
+            w[k] = s[k] < T(0) ? -m::sqrt(-s[k]) : m::sqrt(s[k]);
+        }
+        effort[k] = opt ? s[k] * T(phys::K_F) : s[k] * T(phys::K_F / phys::F_MAX_ROTOR * 2.0) - T(1);
+    }
+    u.F = T(phys::K_F) * ((s[0] + s[1]) + (s[2] + s[3]));
+    u.Mx = T(phys::D * phys::K_F) * (s[2] - s[0]);
+    u.My = T(phys::D * phys::K_F) * (s[1] - s[3]);
+    u.Mz = T(phys::K_M) * ((s[1] - s[0]) + (s[3] - s[2]));
+    u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
+    cl[0] = u.F; cl[1] = u.Mx; cl[2] = u.My; cl[3] = u.Mz;
+}
+
+// State layout (quadrotor_env.py:399-400): x vx y vy z vz q0 q1 q2 q3 wx wy wz
+// RHS drone_eq, quadrotor_env.py:274-406, closed form.
+// `acc` returns the inertial acceleration (self.accel side output).
+template <typename T>
+__device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, T cm_xy, T cm_z, T dy[13]) {
+    using m = Mth<T>;
+    const T vx = y[1], vy = y[3], vz = y[5];
+    const T wx = y[10], wy = y[11], wz = y[12];
+    const T inv = m::rsqrt(y[6] * y[6] + y[7] * y[7] + y[8] * y[8] + y[9] * y[9]);
+    const T a = y[6] * inv, b = y[7] * inv, c = y[8] * inv, d = y[9] * inv;
+    const T aa = a * a, bb = b * b, cc = c * c, dd = d * d;
+    const T ab = a * b, ac = a * c, ad = a * d, bc = b * c, bd = b * d, cd = c * d;
+    const T r00 = (aa + bb) - (cc + dd), r01 = T(2) * (bc - ad), r02 = T(2) * (bd + ac);
+    const T r10 = T(2) * (bc + ad), r11 = (aa - bb) + (cc - dd), r12 = T(2) * (cd - ab);
+    const T r20 = T(2) * (bd - ac), r21 = T(2) * (cd + ab), r22 = (aa - bb) - (cc - dd);
+    // body velocity and aerodynamic drag
+    const T vbx = r00 * vx + r10 * vy + r20 * vz;
+    const T vby = r01 * vx + r11 * vy + r21 * vz;
+    const T vbz = r02 * vx + r12 * vy + r22 * vz;
+    const T fbx = -T(phys::KDX) * (m::abs(vbx) * vbx);
+    const T fby = -T(phys::KDY) * (m::abs(vby) * vby);
+    const T fbz = u.F - T(phys::KDZ) * (m::abs(vbz) * vbz);
+    // inertial acceleration
+    const T ax = (r00 * fbx + r01 * fby + r02 * fbz) * T(1.0 / phys::M);
+    const T ay = (r10 * fbx + r11 * fby + r12 * fbz) * T(1.0 / phys::M);
+    const T az = (r20 * fbx + r21 * fby + r22 * fbz) * T(1.0 / phys::M) - T(phys::G);
+    // moments: action + gyro (sic: x uses -wx, y uses +wy, :347-349) + drag - w x (J w)
+    const T mx = u.Mx - wx * u.omr - cm_xy * (m::abs(wx) * wx) - wy * wz * T(phys::JZ - phys::JY);
+    const T my = u.My + wy * u.omr - cm_xy * (m::abs(wy) * wy) - wz * wx * T(phys::JX - phys::JZ);
+    const T mz = u.Mz - cm_z * (m::abs(wz) * wz) - wx * wy * T(phys::JY - phys::JX);
+    dy[0] = vx; dy[1] = ax; dy[2] = vy; dy[3] = ay; dy[4] = vz; dy[5] = az;
+    // deriv_quat with the normalised quaternion (quaternion_euler_utility.py:58-69)
+    dy[6] = T(0.5) * (-wx * b - wy * c - wz * d);
+    dy[7] = T(0.5) * (wx * a + wz * c - wy * d);
+    dy[8] = T(0.5) * (wy * a - wz * b + wx * d);
+    dy[9] = T(0.5) * (wz * a + wy * b - wx * c);
+    dy[10] = mx * T(1.0 / phys::JX);
+    dy[11] = my * T(1.0 / phys::JY);
+    dy[12] = mz * T(1.0 / phys::JZ);
+}
+
+// ---- Dormand-Prince 5(4) tableau (scipy rk.py RK45) -----------------------------------
+namespace dp {
+constexpr double A21 = 1.0 / 5;
+constexpr double A31 = 3.0 / 40, A32 = 9.0 / 40;
+constexpr double A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9;
+constexpr double A51 = 19372.0 / 6561, A52 = -25360.0 / 2187, A53 = 64448.0 / 6561, A54 = -212.0 / 729;
+constexpr double A61 = 9017.0 / 3168, A62 = -355.0 / 33, A63 = 46732.0 / 5247, A64 = 49.0 / 176,
+                 A65 = -5103.0 / 18656;
+constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
+constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 17253.0 / 339200,
+                 E6 = -22.0 / 525, E7 = 1.0 / 40;
+}  // namespace dp
+
+// One DP5 step of size h from (y, k1 = f(y)) -> y_new, k7 = f(y_new), and the scaled
+// error norm of scipy's _estimate_error_norm (rk.py:108-109,143-144) if WITH_ERR.
+template <typename T, bool WITH_ERR>
+__device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T>& u, T cm_xy, T cm_z, T h,
+                                      T yn[13], T k7[13]) {
+    using m = Mth<T>;
+    T k2[13], k3[13], k4[13], k5[13], k6[13], ys[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A21) * k1[i]);
+    rhs(ys, u, cm_xy, cm_z, k2);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A31) * k1[i] + T(dp::A32) * k2[i]);
+    rhs(ys, u, cm_xy, cm_z, k3);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A41) * k1[i] + T(dp::A42) * k2[i] + T(dp::A43) * k3[i]);
+    rhs(ys, u, cm_xy, cm_z, k4);
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+        ys[i] = y[i] + h * (T(dp::A51) * k1[i] + T(dp::A52) * k2[i] + T(dp::A53) * k3[i] + T(dp::A54) * k4[i]);
+    rhs(ys, u, cm_xy, cm_z, k5);
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+        ys[i] = y[i] + h * (T(dp::A61) * k1[i] + T(dp::A62) * k2[i] + T(dp::A63) * k3[i] + T(dp::A64) * k4[i] +
+                            T(dp::A65) * k5[i]);
+    rhs(ys, u, cm_xy, cm_z, k6);
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+        yn[i] = y[i] + h * (T(dp::B1) * k1[i] + T(dp::B3) * k3[i] + T(dp::B4) * k4[i] + T(dp::B5) * k5[i] +
+                            T(dp::B6) * k6[i]);
+    rhs(yn, u, cm_xy, cm_z, k7);
+    T err2 = T(0);
+    if (WITH_ERR) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const T e = h * (T(dp::E1) * k1[i] + T(dp::E3) * k3[i] + T(dp::E4) * k4[i] + T(dp::E5) * k5[i] +
+                             T(dp::E6) * k6[i] + T(dp::E7) * k7[i]);
+            const T sc = T(1e-6) + m::max(m::abs(y[i]), m::abs(yn[i])) * T(1e-3);
+            const T r = e * m::rcp(sc);
+            err2 += r * r;
+        }
+    }
+    return err2;  // = 13 * error_norm^2
+}
+
+// solve_ivp(drone_eq, (0, tb), y, args=(u,)).y[:, -1] with scipy's RK45 defaults, restarted
+// every env step as the reference does (quadrotor_env.py:483).  select_initial_step:
+// common.py:66-133; accept/reject loop: rk.py:111-167 flattened to one attempted sub-step
+// per iteration.  On exit y = state at tb and kq = f(t_end, y_end)
+// (FSAL) whose rows 6..9 are the reference's V_q.  Every lane leaves the loop after at
+// most MAX_ATTEMPTS attempts.
+template <typename T>
+__device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13]) {
+    using m = Mth<T>;
+    constexpr int MAX_ATTEMPTS = 96;
+    T k1[13];
+    rhs(y, u, cm_xy, cm_z, k1);
+    T h_abs;
+    {
+        T d0 = T(0), d1 = T(0);
+        T isc[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            isc[i] = m::rcp(T(1e-6) + m::abs(y[i]) * T(1e-3));
+            const T a = y[i] * isc[i], b = k1[i] * isc[i];
+            d0 += a * a;
+            d1 += b * b;
+        }
+        d0 = m::sqrt(d0 * T(1.0 / 13)); d1 = m::sqrt(d1 * T(1.0 / 13));
+        T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : T(0.01) * d0 / d1;
+        h0 = m::min(h0, tb);
+        T y1[13], f1[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h0 * k1[i];
+        rhs(y1, u, cm_xy, cm_z, f1);
+        T d2 = T(0);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const T a = (f1[i] - k1[i]) * isc[i];
+            d2 += a * a;
+        }
+        d2 = m::sqrt(d2 * T(1.0 / 13)) / h0;
+        T h1;
+        if (d1 <= T(1e-15) && d2 <= T(1e-15)) h1 = m::max(T(1e-6), h0 * T(1e-3));
+        else h1 = m::pow(T(0.01) / m::max(d1, d2), T(0.2));
+        h_abs = m::min(m::min(T(100) * h0, h1), tb);
+    }
+    T t = T(0);
+    bool rejected = false;
+    for (int it = 0; it < MAX_ATTEMPTS && t < tb; ++it) {
+        const T min_step = T(10) * m::ulp_up(t);
+        if (!rejected && h_abs < min_step) h_abs = min_step;
+        if (h_abs < min_step) break;  // TOO_SMALL_STEP: solver fails, last accepted y stays
+        T t_new = t + h_abs;
+        if (t_new > tb) t_new = tb;
+        const T h = t_new - t;
+        h_abs = h;
+        T yn[13], k7[13];
+        const T err2 = dp5_step<T, true>(y, k1, u, cm_xy, cm_z, h, yn, k7);
+        const T err = m::sqrt(err2 * T(1.0 / 13));
+        if (err < T(1)) {
+            T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow(err, T(-0.2)));
+            if (rejected) factor = m::min(T(1), factor);
+            h_abs *= factor;
+            t = t_new;
+            rejected = false;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) { y[i] = yn[i]; k1[i] = k7[i]; }
+        } else {
+            h_abs *= m::max(T(0.2), T(0.9) * m::pow(err, T(-0.2)));
+            rejected = true;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) kq[i] = k1[i];
+}
+
+template <typename T>
+__device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13]) {
+    T k1[13], yn[13];
+    rhs(y, u, cm_xy, cm_z, k1);
+    dp5_step<T, false>(y, k1, u, cm_xy, cm_z, tb, yn, kq);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) y[i] = yn[i];
+}
+
+template <typename T>
+__device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, T cm_xy, T cm_z, T h, T kq[13]) {
+    T k1[13], k2[13], k3[13], k4[13], ys[13];
+    rhs(y, u, cm_xy, cm_z, k1);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) ys[i] = y[i] + T(0.5) * h * k1[i];
+    rhs(ys, u, cm_xy, cm_z, k2);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) ys[i] = y[i] + T(0.5) * h * k2[i];
+    rhs(ys, u, cm_xy, cm_z, k3);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * k3[i];
+    rhs(ys, u, cm_xy, cm_z, k4);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) y[i] = y[i] + h * T(1.0 / 6) * ((k1[i] + k4[i]) + T(2) * (k2[i] + k3[i]));
+    rhs(y, u, cm_xy, cm_z, kq);
+}
+
+enum { INT_RK45 = 0, INT_DP5 = 1, INT_RK4 = 2 };
+
+template <typename T, int INTEG>
+__device__ __forceinline__ void integrate(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13]) {
+    if (INTEG == INT_RK45) integrate_rk45(y, u, cm_xy, cm_z, tb, kq);
+    else if (INTEG == INT_DP5) integrate_dp5(y, u, cm_xy, cm_z, tb, kq);
+    else integrate_rk4(y, u, cm_xy, cm_z, tb, kq);
+}
+
+// ---- per-env bookkeeping carried between steps (registers in fused rollouts) -------------
+template <typename T> struct Book {
+    T prev_ang[3];
+    T ang[3];
+    T ang_vel[3];
+    T prev_shaping;
+    T abs_sum;
+    T ep_return;
+    T reward;
+    int32_t i;
+    int32_t flags;  // QENV_FLAG_*
+};
+
+constexpr int FLAG_DONE = 1, FLAG_SOLVED = 2, FLAG_HAS_SHAPING = 4;
+
+// quat_euler on the re-normalised end quaternion + finite-difference Euler rates,
+// quadrotor_env.py:488-493 (main) / quadrotor_env_opt.py:397-402 (opt: prev_ang = ang
+// BEFORE the update).
+template <typename T>
+__device__ __forceinline__ void euler_update(const T y[13], const Cfg<T>& cfg, Book<T>& bk) {
+    using m = Mth<T>;
+    const T inv = m::rsqrt(y[6] * y[6] + y[7] * y[7] + y[8] * y[8] + y[9] * y[9]);
+    const T q0 = y[6] * inv, q1 = y[7] * inv, q2 = y[8] * inv, q3 = y[9] * inv;
+    T ang[3];
+    ang[0] = m::atan2(T(2) * (q0 * q1 + q2 * q3), T(1) - T(2) * (q1 * q1 + q2 * q2));
+    ang[1] = m::asin(T(2) * (q0 * q2 - q3 * q1));
+    ang[2] = m::atan2(T(2) * (q0 * q3 + q1 * q2), T(1) - T(2) * (q2 * q2 + q3 * q3));
+    const T inv_dt = T(1) / cfg.t_step;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T prev = cfg.variant ? bk.ang[k] : bk.prev_ang[k];
+        bk.ang_vel[k] = (ang[k] - prev) * inv_dt;
+        bk.prev_ang[k] = cfg.variant ? prev : ang[k];
+        bk.ang[k] = ang[k];
+    }
+}
+
+// done_condition + reward_function + control_effort, quadrotor_env.py:500-577 /
+// quadrotor_env_opt.py:410-484.  `act` is self.action: the clipped
+// [-1,1] command (direct) or the RAW [F,M] request (indirect, quirk Q5).
+template <typename T>
+__device__ __forceinline__ void done_reward(const T y[13], const T act[4], const T effort[4], const Cfg<T>& cfg,
+                                            Book<T>& bk) {
+    using m = Mth<T>;
+    const T v0 = y[1], v1 = y[3], v2 = y[5];
+    const T* ang = bk.ang;
+    bool done = (bk.flags & FLAG_DONE) != 0;
+    const T c[9] = {v0, v1, v2, ang[0], ang[1], ang[2], y[10], y[11], y[12]};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) done = done || (m::abs(c[k]) >= cfg.bb[k]);
+    const bool timeout = bk.i >= cfg.n_max;
+    if (cfg.variant) done = done || timeout;
+
+    const T vv = v0 * v0 + v1 * v1 + v2 * v2;
+    const T psi = ang[2];
+    const T nv = m::sqrt(vv) * T(1.0 / phys::BB_VEL);
+    const T npsi = m::abs(psi) * T(0.25);
+    const T a01 = ang[0] * ang[0] + ang[1] * ang[1];
+    const T nang = m::sqrt(a01) * T(1.0 / phys::BB_ANG);
+    const T r_norm = m::sqrt(vv + psi * psi);
+    T shaping, pc, tr0;
+    if (cfg.variant) {
+        shaping = T(-100) * (nv + npsi + T(0.3) * nang);
+        pc = T(1); tr0 = T(0.001);
+        const T n3 = m::sqrt(a01 + psi * psi);
+        const T tr[3] = {T(0.001), T(0.01), T(0.1)}, trp[3] = {T(300), T(100), T(10)};
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool in = !hit && (r_norm < T(2) * tr[k]);
+            if (in) { shaping += trp[k]; if (n3 < T(3.4641016151377544) * tr[k]) shaping += trp[k]; }
+            hit = hit || in;
+        }
+    } else {
+        shaping = T(-5.0 / 20.0) * (T(15) * nv + T(4) * npsi + nang);
+        pc = T(0.003); tr0 = T(0.005);
+        const T n2 = m::sqrt(a01);
+        const T tr[3] = {T(0.005), T(0.01), T(0.1)}, trp[3] = {T(3), T(2), T(1)};
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool in = !hit && (r_norm < T(2) * tr[k]);
+            if (in) { shaping += trp[k]; if (n2 < T(5.656854249492381) * tr[k]) shaping += trp[k]; }
+            hit = hit || in;
+        }
+    }
+    T reward = (bk.flags & FLAG_HAS_SHAPING) ? shaping - bk.prev_shaping : T(0);
+    bk.prev_shaping = shaping;
+    T ss = T(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const T zc = (cfg.direct || k == 0) ? cfg.zero_control0 : T(0);
+        const T d = act[k] - zc;
+        ss += d * d;
+    }
+    reward += -ss * pc;
+    const T current = vv + a01 + psi * psi + (y[10] * y[10] + y[11] * y[11] + y[12] * y[12]);
+    int solved = (bk.flags & FLAG_SOLVED) ? 1 : 0;
+    if (current < T(9) * tr0 * tr0) {
+        reward = cfg.variant ? T(500) : reward + T(20);
+        solved = 1;
+        if (cfg.training) done = true;
+    } else if (timeout) {
+        solved = 0;
+        if (!cfg.variant) done = true;
+    } else if (done) {
+        reward = cfg.variant ? T(-200) : reward + T(-20);
+        solved = 0;
+    }
+    bk.reward = reward;
+    bk.ep_return += reward;
+    bk.flags = (done ? FLAG_DONE : 0) | (solved ? FLAG_SOLVED : 0) | FLAG_HAS_SHAPING;
+    bk.abs_sum += m::sqrt((effort[0] * effort[0] + effort[1] * effort[1]) + (effort[2] * effort[2] + effort[3] * effort[3]));
+}
+
+// Action pre-processing of step(), quadrotor_env.py:470-479: returns the held
+// actuation `u`, and fills w / effort / clipped_action / self.action.
+template <typename T>
+__device__ __forceinline__ void prepare_action(const T raw[4], const Cfg<T>& cfg, T w[4], T effort[4], T cl[4],
+                                               T act[4], Act<T>& u) {
+    using m = Mth<T>;
+    if (cfg.direct) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            act[k] = m::min(m::max(raw[k], T(-1)), T(1));
+            cl[k] = act[k];
+            effort[k] = cfg.variant ? (act[k] + T(1)) * T(phys::T2WR * phys::M * phys::G / 8.0) : act[k];
+        }
+        mix_direct(act, w, u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) act[k] = raw[k];
+        mix_indirect(raw, cfg.clipped != 0, cfg.variant != 0, w, effort, cl, u);
+    }
+}
+
+// ---- LQR law, lqr_quad.py:128-154 with the CARE gains in closed form (App. A.8) ---------
+template <typename T> struct LqrGains { T kt[3]; T ka[3][2]; };  // velocity gains; attitude (e, e_dot)
+
+template <typename T>
+__device__ __forceinline__ void lqr_law(const T y[13], const Book<T>& bk, const LqrGains<T>& g, T act[4]) {
+    using m = Mth<T>;
+    const T F0 = g.kt[0] * y[1], F1 = g.kt[1] * y[3], F2 = g.kt[2] * y[5];
+    const T theta_t = m::atan2(F0, F2 + T(phys::G));
+    const T ct = m::cos(theta_t);
+    const T phi_t = m::atan2(-F1 * ct, F2 + T(phys::G));
+    act[0] = T(phys::M) * (F2 + T(phys::G)) / (ct * m::cos(phi_t));
+    act[1] = g.ka[0][0] * (bk.ang[0] - phi_t) + g.ka[0][1] * bk.ang_vel[0];
+    act[2] = g.ka[1][0] * (bk.ang[1] - theta_t) + g.ka[1][1] * bk.ang_vel[1];
+    act[3] = g.ka[2][0] * bk.ang[2] + g.ka[2][1] * bk.ang_vel[2];
+}
+
+// ---- PID law, pid_vel_control.py:29-127 ------------------------------
+template <typename T> struct PidGains { T p[6], i[6], d[6]; T ts; };
+template <typename T> struct PidState { T ix[6], x_old[6], ang_d_ant[3]; };
+
+template <typename T>
+__device__ __forceinline__ T pid_eval(const PidGains<T>& g, PidState<T>& s, int k, T x, T x_d, T dx_d) {
+    const T dx = (x - s.x_old[k]) / g.ts;
+    s.x_old[k] = x;
+    s.ix[k] = s.ix[k] + (x_d - x) * g.ts;
+    return g.p[k] * (x_d - x) + g.d[k] * (dx_d - dx) - g.i[k] * s.ix[k];
+}
+
+template <typename T>
+__device__ __forceinline__ void pid_law(const T y[13], const Book<T>& bk, const PidGains<T>& g, PidState<T>& s,
+                                        const T tgt[4], T t_step, T act[4]) {
+    using m = Mth<T>;
+    const T u1 = pid_eval(g, s, 0, y[1], tgt[0], T(0));
+    const T u2 = pid_eval(g, s, 1, y[3], tgt[1], T(0));
+    const T u3 = pid_eval(g, s, 2, y[5], tgt[2], T(0));
+    const T theta_d = m::atan2(u1, u3 + T(phys::G));
+    const T ctd = m::cos(theta_d);
+    const T phi_d = m::atan2(-u2 * ctd, u3 + T(phys::G));
+    act[0] = T(phys::M) * (u3 + T(phys::G)) / (ctd * m::cos(phi_d));
+    const T ang_d[3] = {phi_d, theta_d, tgt[3]};
+    T u567[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T v_ang_d = (ang_d[k] - s.ang_d_ant[k]) / t_step;
+        u567[k] = pid_eval(g, s, 3 + k, bk.ang[k], ang_d[k], v_ang_d);
+        s.ang_d_ant[k] = ang_d[k];
+    }
+    const T phi = bk.ang[0], theta = bk.ang[1];
+    const T sp = m::sin(phi), cp = m::cos(phi), ct = m::cos(theta), tt = m::tan(theta);
+    const T b1 = T(1.0 / phys::JX), b2 = tt * sp * T(1.0 / phys::JY), b3 = tt * cp * T(1.0 / phys::JZ);
+    const T b4 = cp * T(1.0 / phys::JY), b5 = -sp * T(1.0 / phys::JZ);
+    const T b6 = sp / ct * T(1.0 / phys::JY), b7 = cp / ct * T(1.0 / phys::JZ);
+    const T det = b4 * b7 - b5 * b6;
+    const T U3 = (b7 * u567[1] - b5 * u567[2]) / det;
+    const T U4 = (-b6 * u567[1] + b4 * u567[2]) / det;
+    act[1] = (u567[0] - b2 * U3 - b3 * U4) / b1;
+    act[2] = U3;
+    act[3] = U4;
+}
+
+}  // namespace qenv

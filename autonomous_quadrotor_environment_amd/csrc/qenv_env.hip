@@ -1,0 +1,557 @@
+// qenv_env.hip -- env kernels (reset / step / fused rollout / controllers) and their C-ABI
+// entry points (include/qenv.h).  gfx950 only.
+//
+// Data layout in HBM: one caller-provided workspace holding structure-of-arrays rows,
+// row r of env e at (row_base + r) * N + e, so a wavefront's 64 lanes touch 64
+// consecutive elements of each row (256 B for fp32): every global access is one fully
+// coalesced wave-wide transaction.  One lane = one quadrotor; 256-thread workgroups
+// (4 waves); the state never leaves VGPRs inside a step (or inside a fused rollout).
+#include "qenv_host.hpp"
+
+namespace qenv {
+
+// ---- kernel argument blocks (live in SGPRs) ------------------------------------------------
+template <typename T> struct StepArgs {
+    Cfg<T> cfg;
+    T* ws;                 // workspace rows of type T
+    int32_t* wsi;          // int rows (I, FLAGS)
+    int64_t N;
+    const T* actions;      // [4][N] or null (zero_control)
+    const uint8_t* mask;   // null or [N]: only envs with mask != 0 are stepped
+    T* out_obs;            // [14][N] or null
+    T* out_reward;         // [N] or null
+    uint8_t* out_done;     // [N] or null
+    int32_t mode;          // QENV_STEP_*
+};
+
+template <typename T> struct RolloutArgs {
+    Cfg<T> cfg;
+    T* ws;
+    int32_t* wsi;
+    int64_t N;
+    int32_t n_steps;
+    int32_t mode;
+    int32_t pid_first;
+    T const_action[4];
+    T pid_target[4];
+    LqrGains<T> lqr;
+    PidGains<T> pid;
+};
+
+template <typename T> __device__ __forceinline__ T ld(const T* base, int row, int64_t N, int64_t e) {
+    return base[(int64_t)row * N + e];
+}
+template <typename T> __device__ __forceinline__ void st(T* base, int row, int64_t N, int64_t e, T v) {
+    base[(int64_t)row * N + e] = v;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_book(const T* ws, const int32_t* wsi, int64_t N, int64_t e, bool opt, Book<T>& bk) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        bk.prev_ang[k] = ld(ws, ROW_PREV_ANG + k, N, e);
+        bk.ang[k] = opt ? ld(ws, ROW_ANG + k, N, e) : T(0);  // only the opt variant reads the old ang
+        bk.ang_vel[k] = T(0);
+    }
+    bk.prev_shaping = ld(ws, ROW_PREV_SHAPING, N, e);
+    bk.abs_sum = ld(ws, ROW_ABS_SUM, N, e);
+    bk.ep_return = ld(ws, ROW_EP_RETURN, N, e);
+    bk.reward = T(0);
+    bk.i = wsi[IROW_I * N + e];
+    bk.flags = wsi[IROW_FLAGS * N + e];
+}
+
+template <typename T>
+__device__ __forceinline__ void store_book(T* ws, int32_t* wsi, int64_t N, int64_t e, const Book<T>& bk, bool aux) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        st(ws, ROW_PREV_ANG + k, N, e, bk.prev_ang[k]);
+        st(ws, ROW_ANG + k, N, e, bk.ang[k]);
+        if (aux) st(ws, ROW_ANG_VEL + k, N, e, bk.ang_vel[k]);
+    }
+    st(ws, ROW_PREV_SHAPING, N, e, bk.prev_shaping);
+    st(ws, ROW_ABS_SUM, N, e, bk.abs_sum);
+    st(ws, ROW_EP_RETURN, N, e, bk.ep_return);
+    st(ws, ROW_REWARD, N, e, bk.reward);
+    wsi[IROW_I * N + e] = bk.i;
+    wsi[IROW_FLAGS * N + e] = bk.flags;
+}
+
+// quad.step for N envs: one launch, one lane per env.
+template <typename T, int INTEG>
+__global__ __launch_bounds__(256) void k_step(const StepArgs<T> a) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.N) return;
+    if (a.mask && a.mask[e] == 0) return;
+    const int64_t N = a.N;
+    const Cfg<T>& cfg = a.cfg;
+    T y[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) y[k] = ld(a.ws, ROW_STATE + k, N, e);
+    T raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        raw[k] = a.actions ? a.actions[(int64_t)k * N + e] : ((cfg.direct || k == 0) ? cfg.zero_control0 : T(0));
+    T w[4], effort[4], cl[4], act[4], kq[13];
+    Act<T> u;
+    prepare_action(raw, cfg, w, effort, cl, act, u);
+    integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, y[k]);
+    if (a.mode == QENV_STEP_DYNAMICS_ONLY) return;
+
+    Book<T> bk;
+    load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
+    bk.i += 1;
+    euler_update(y, cfg, bk);
+    done_reward(y, act, effort, cfg, bk);
+    const bool aux = a.mode != QENV_STEP_NO_AUX;
+    store_book(a.ws, a.wsi, N, e, bk, aux);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st(a.ws, ROW_VQ + k, N, e, kq[6 + k]);
+    if (aux) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st(a.ws, ROW_W + k, N, e, w[k]);
+            st(a.ws, ROW_EFFORT + k, N, e, effort[k]);
+            st(a.ws, ROW_CLIPPED + k, N, e, cl[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st(a.ws, ROW_ACCEL + k, N, e, kq[1 + 2 * k]);
+    }
+    if (a.out_obs) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) a.out_obs[(int64_t)k * N + e] = y[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.out_obs[(int64_t)(10 + k) * N + e] = kq[6 + k];
+    }
+    if (a.out_reward) a.out_reward[e] = bk.reward;
+    if (a.out_done) a.out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
+}
+
+// n_steps env steps in one launch, controller on device, state in VGPRs throughout.
+template <typename T, int INTEG, int CTRL>
+__global__ __launch_bounds__(256) void k_rollout(const RolloutArgs<T> a) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.N) return;
+    const int64_t N = a.N;
+    const Cfg<T>& cfg = a.cfg;
+    T y[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) y[k] = ld(a.ws, ROW_STATE + k, N, e);
+    const bool dyn_only = a.mode == QENV_STEP_DYNAMICS_ONLY;
+    Book<T> bk;
+    if (!dyn_only) {
+        load_book(a.ws, a.wsi, N, e, true, bk);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bk.ang_vel[k] = ld(a.ws, ROW_ANG_VEL + k, N, e);
+    }
+    PidState<T> ps;
+    if (CTRL == QENV_CTRL_PID) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ps.ix[k] = ld(a.ws, ROW_PID + k, N, e); ps.x_old[k] = ld(a.ws, ROW_PID + 6 + k, N, e); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(a.ws, ROW_PID + 12 + k, N, e);
+    }
+    T w[4], effort[4], cl[4], act[4], kq[13], raw[4];
+    Act<T> u;
+    if (CTRL == QENV_CTRL_CONST) {  // constant action: mix once for the whole rollout
+        prepare_action(a.const_action, cfg, w, effort, cl, act, u);
+    }
+    for (int s = 0; s < a.n_steps; ++s) {
+        if (CTRL == QENV_CTRL_LQR) {
+            lqr_law(y, bk, a.lqr, raw);
+            prepare_action(raw, cfg, w, effort, cl, act, u);
+        } else if (CTRL == QENV_CTRL_PID) {
+            if (s == 0 && a.pid_first) {
+                raw[0] = T(phys::M * phys::G); raw[1] = raw[2] = raw[3] = T(0);
+            } else {
+                pid_law(y, bk, a.pid, ps, a.pid_target, cfg.t_step, raw);
+            }
+            prepare_action(raw, cfg, w, effort, cl, act, u);
+        }
+        integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq);
+        if (!dyn_only) {
+            bk.i += 1;
+            euler_update(y, cfg, bk);
+            done_reward(y, act, effort, cfg, bk);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, y[k]);
+    if (dyn_only) return;
+    store_book(a.ws, a.wsi, N, e, bk, true);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        st(a.ws, ROW_VQ + k, N, e, kq[6 + k]);
+        st(a.ws, ROW_W + k, N, e, w[k]);
+        st(a.ws, ROW_EFFORT + k, N, e, effort[k]);
+        st(a.ws, ROW_CLIPPED + k, N, e, cl[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st(a.ws, ROW_ACCEL + k, N, e, kq[1 + 2 * k]);
+    if (CTRL == QENV_CTRL_PID) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { st(a.ws, ROW_PID + k, N, e, ps.ix[k]); st(a.ws, ROW_PID + 6 + k, N, e, ps.x_old[k]); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st(a.ws, ROW_PID + 12 + k, N, e, ps.ang_d_ant[k]);
+    }
+}
+
+// quad.reset front half (quadrotor_env.py:428-445): load initial states, clear counters.
+template <typename T>
+__global__ __launch_bounds__(256) void k_reset(T* ws, int32_t* wsi, int64_t N, const T* init, const uint8_t* mask) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    if (mask && mask[e] == 0) return;
+    using m = Mth<T>;
+    T q[4];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const T v = init[(int64_t)k * N + e];
+        st(ws, ROW_STATE + k, N, e, v);
+        if (k >= 6 && k < 10) q[k - 6] = v;
+    }
+    // self.ang = quat_euler(q) (:438); only the opt variant reads it back (prev_ang = ang)
+    st(ws, ROW_ANG + 0, N, e, m::atan2(T(2) * (q[0] * q[1] + q[2] * q[3]), T(1) - T(2) * (q[1] * q[1] + q[2] * q[2])));
+    st(ws, ROW_ANG + 1, N, e, m::asin(T(2) * (q[0] * q[2] - q[3] * q[1])));
+    st(ws, ROW_ANG + 2, N, e, m::atan2(T(2) * (q[0] * q[3] + q[1] * q[2]), T(1) - T(2) * (q[2] * q[2] + q[3] * q[3])));
+    st(ws, ROW_PREV_SHAPING, N, e, T(0));
+    st(ws, ROW_ABS_SUM, N, e, T(0));
+    st(ws, ROW_EP_RETURN, N, e, T(0));
+    st(ws, ROW_REWARD, N, e, T(0));
+    wsi[IROW_I * N + e] = 0;
+    wsi[IROW_FLAGS * N + e] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_actions(T* out, int64_t N, T a0, T a1, T a2, T a3, const uint8_t* mask) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    (void)mask;
+    out[e] = a0; out[N + e] = a1; out[2 * N + e] = a2; out[3 * N + e] = a3;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_rows(T* dst, const T* src, int rows, int64_t N) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    for (int r = 0; r < rows; ++r) dst[(int64_t)r * N + e] = src[(int64_t)r * N + e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_lqr_action(const T* ws, int64_t N, LqrGains<T> g, T* out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    T y[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) y[k] = T(0);
+    y[1] = ld(ws, ROW_STATE + 1, N, e); y[3] = ld(ws, ROW_STATE + 3, N, e); y[5] = ld(ws, ROW_STATE + 5, N, e);
+    Book<T> bk;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { bk.ang[k] = ld(ws, ROW_ANG + k, N, e); bk.ang_vel[k] = ld(ws, ROW_ANG_VEL + k, N, e); }
+    T act[4];
+    lqr_law(y, bk, g, act);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pid_action(T* ws, int64_t N, PidGains<T> g, T t0, T t1, T t2, T t3, T t_step,
+                                                    T* out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    T y[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) y[k] = T(0);
+    y[1] = ld(ws, ROW_STATE + 1, N, e); y[3] = ld(ws, ROW_STATE + 3, N, e); y[5] = ld(ws, ROW_STATE + 5, N, e);
+    Book<T> bk;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { bk.ang[k] = ld(ws, ROW_ANG + k, N, e); bk.ang_vel[k] = T(0); }
+    PidState<T> ps;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ps.ix[k] = ld(ws, ROW_PID + k, N, e); ps.x_old[k] = ld(ws, ROW_PID + 6 + k, N, e); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(ws, ROW_PID + 12 + k, N, e);
+    const T tgt[4] = {t0, t1, t2, t3};
+    T act[4];
+    pid_law(y, bk, g, ps, tgt, t_step, act);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { st(ws, ROW_PID + k, N, e, ps.ix[k]); st(ws, ROW_PID + 6 + k, N, e, ps.x_old[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st(ws, ROW_PID + 12 + k, N, e, ps.ang_d_ant[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pid_reset(T* ws, int64_t N, const uint8_t* mask) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    if (mask && mask[e] == 0) return;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) st(ws, ROW_PID + k, N, e, T(0));
+}
+
+// ---- host-side helpers -------------------------------------------------------------------------
+template <typename T> static Cfg<T> make_cfg(const qenv_s* q) {
+    Cfg<T> c;
+    const qenv_config& f = q->cfg;
+    const bool opt = f.variant == QENV_OPT;
+    c.t_step = (T)f.t_step;
+    c.cm_xy = (T)(phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3));
+    c.cm_z = (T)(2.0 * phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3));
+    double bb[9];
+    if (opt) {
+        const double b[9] = {10, 10, 10, phys::BB_ANG, phys::BB_ANG, 4, 30, 30, 30};
+        for (int k = 0; k < 9; ++k) bb[k] = f.training ? b[k] : b[k] * 1000;
+    } else {
+        const double b[9] = {10, 10, 10, phys::BB_ANG, phys::BB_ANG, 0.75 * phys::PI, 20, 20, 20};
+        for (int k = 0; k < 9; ++k) bb[k] = b[k];
+    }
+    for (int k = 0; k < 9; ++k) c.bb[k] = (T)bb[k];
+    c.zero_control0 = f.direct_control ? (T)(2.0 / phys::T2WR - 1.0) : (T)(phys::M * phys::G);
+    c.n_max = f.n_max + f.T;
+    c.training = f.training ? 1 : 0;
+    c.direct = f.direct_control ? 1 : 0;
+    c.clipped = f.clipped ? 1 : 0;
+    c.variant = opt ? 1 : 0;
+    return c;
+}
+
+// CARE solution for the decoupled double integrators of lqr_quad.py:25-111 (App. A.8)
+template <typename T> static LqrGains<T> make_lqr(bool clipped) {
+    double q_att[6], q_t[6], r_att = 40, r_t;
+    if (clipped) {
+        const double qa[6] = {5, 1, 5, 1, 0.05, 0.01}, qt[6] = {1e-8, 1, 1e-8, 1, 1e-8, 0.8};
+        for (int k = 0; k < 6; ++k) { q_att[k] = qa[k] * 50; q_t[k] = qt[k] * 10; }
+        r_t = 10;
+    } else {
+        const double qa[6] = {5, 0.3, 5, 0.3, 2, 0.3}, qt[6] = {1e-8, 1, 1e-8, 1, 1e-8, 0.5};
+        for (int k = 0; k < 6; ++k) { q_att[k] = qa[k] * 160; q_t[k] = qt[k] * 60; }
+        r_t = 5;
+    }
+    const double b_att[3] = {1 / phys::JX, 1 / phys::JY, 1 / phys::JZ};
+    LqrGains<T> g;
+    for (int a = 0; a < 3; ++a) {
+        double k1 = std::sqrt(q_att[2 * a] / r_att);
+        double k2 = std::sqrt(q_att[2 * a + 1] / r_att + 2 * k1 / b_att[a]);
+        g.ka[a][0] = (T)(-k1); g.ka[a][1] = (T)(-k2);
+        k1 = std::sqrt(q_t[2 * a] / r_t);
+        k2 = std::sqrt(q_t[2 * a + 1] / r_t + 2 * k1 * phys::M);
+        g.kt[a] = (T)(-k2);  // positions are zeroed in state_t (lqr_quad.py:129), only the velocity gain acts
+    }
+    return g;
+}
+
+// pid_vel_control.py:17-27
+template <typename T> static PidGains<T> make_pid(bool clipped) {
+    PidGains<T> g;
+    const double P = clipped ? 1 : 2, Pz = clipped ? 0.4 : 1, Pa = clipped ? 20 : 180, Da = clipped ? 20 : 50,
+                 Pp = clipped ? 5 : 40, Dp = clipped ? 5 : 20;
+    const double p[6] = {P, P, Pz, Pa, Pa, Pp}, d[6] = {0, 0, 0, Da, Da, Dp};
+    for (int k = 0; k < 6; ++k) { g.p[k] = (T)p[k]; g.i[k] = (T)0; g.d[k] = (T)d[k]; }
+    g.ts = (T)0.01;
+    return g;
+}
+
+static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 255) / 256)); }
+
+template <typename T> static int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
+                                         void* out_reward, uint8_t* out_done, int flags) {
+    StepArgs<T> a;
+    a.cfg = make_cfg<T>(q);
+    a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N;
+    a.actions = (const T*)actions; a.mask = mask;
+    a.out_obs = (T*)out_obs; a.out_reward = (T*)out_reward; a.out_done = out_done; a.mode = flags;
+    const dim3 g = grid_for(q->N), b(256);
+    switch (q->cfg.integrator) {
+        case QENV_RK45: hipLaunchKernelGGL((k_step<T, INT_RK45>), g, b, 0, q->stream, a); break;
+        case QENV_DP5: hipLaunchKernelGGL((k_step<T, INT_DP5>), g, b, 0, q->stream, a); break;
+        default: hipLaunchKernelGGL((k_step<T, INT_RK4>), g, b, 0, q->stream, a); break;
+    }
+    return check_launch("k_step");
+}
+
+template <typename T, int INTEG> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T>& a) {
+    const dim3 g = grid_for(q->N), b(256);
+    switch (controller) {
+        case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_CONST>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_LQR>), g, b, 0, q->stream, a); break;
+        default: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_PID>), g, b, 0, q->stream, a); break;
+    }
+}
+
+template <typename T> static int do_rollout(qenv_s* q, int controller, int n_steps, const double* const_action,
+                                            int pid_first, int flags) {
+    RolloutArgs<T> a;
+    a.cfg = make_cfg<T>(q);
+    a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
+    for (int k = 0; k < 4; ++k) {
+        a.const_action[k] = const_action ? (T)const_action[k]
+                                         : ((q->cfg.direct_control || k == 0) ? a.cfg.zero_control0 : (T)0);
+        a.pid_target[k] = (T)0;
+    }
+    a.lqr = make_lqr<T>(q->cfg.clipped != 0);
+    a.pid = make_pid<T>(q->cfg.clipped != 0);
+    switch (q->cfg.integrator) {
+        case QENV_RK45: launch_rollout<T, INT_RK45>(q, controller, a); break;
+        case QENV_DP5: launch_rollout<T, INT_DP5>(q, controller, a); break;
+        default: launch_rollout<T, INT_RK4>(q, controller, a); break;
+    }
+    return check_launch("k_rollout");
+}
+
+template <typename T> static int do_reset(qenv_s* q, const void* init, const uint8_t* mask, void* out_states,
+                                          void* out_actions) {
+    const dim3 g = grid_for(q->N), b(256);
+    hipLaunchKernelGGL((k_reset<T>), g, b, 0, q->stream, (T*)q->ws, q->wsi, q->N, (const T*)init, mask);
+    int rc = check_launch("k_reset");
+    const Cfg<T> c = make_cfg<T>(q);
+    for (int t = 0; t < q->cfg.T && rc == 0; ++t) {
+        T* obs = out_states ? (T*)out_states + (int64_t)t * 14 * q->N : nullptr;
+        rc = do_step<T>(q, nullptr, mask, obs, nullptr, nullptr, QENV_STEP_FULL);
+        if (rc == 0 && out_actions) {
+            T* oa = (T*)out_actions + (int64_t)t * 4 * q->N;
+            const T z = c.zero_control0;
+            hipLaunchKernelGGL((k_fill_actions<T>), g, b, 0, q->stream, oa, q->N, z, c.direct ? z : (T)0,
+                               c.direct ? z : (T)0, c.direct ? z : (T)0, mask);
+            rc = check_launch("k_fill_actions");
+        }
+    }
+    return rc;
+}
+
+}  // namespace qenv
+
+using namespace qenv;
+
+// ---- C-ABI ----------------------------------------------------------------------------------------
+extern "C" {
+
+int qenv_abi_version(void) { return QENV_ABI_VERSION; }
+const char* qenv_last_error(void) { return g_err; }
+
+size_t qenv_workspace_bytes(const qenv_config* cfg) {
+    if (!cfg || cfg->n_envs <= 0 || cfg->T < 1) return 0;
+    return ws_layout(*cfg).total;
+}
+
+int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* stream, qenv_t* out) {
+    if (!cfg || !workspace || !out) return fail(QENV_ERR_ARG, "qenv_create: null argument");
+    if (cfg->n_envs <= 0 || cfg->T < 1 || cfg->T > 64 || cfg->t_step <= 0)
+        return fail(QENV_ERR_ARG, "qenv_create: n_envs, T (1..64) and t_step must be positive");
+    if (cfg->dtype != QENV_F32 && cfg->dtype != QENV_F64) return fail(QENV_ERR_ARG, "qenv_create: bad dtype");
+    if (cfg->integrator < QENV_RK45 || cfg->integrator > QENV_RK4) return fail(QENV_ERR_ARG, "qenv_create: bad integrator");
+    if (cfg->variant != QENV_MAIN && cfg->variant != QENV_OPT) return fail(QENV_ERR_ARG, "qenv_create: bad variant");
+    const WsLayout L = ws_layout(*cfg);
+    if (bytes < L.total) return fail(QENV_ERR_WORKSPACE, "qenv_create: workspace smaller than qenv_workspace_bytes()");
+    if (((uintptr_t)workspace & 255) != 0) return fail(QENV_ERR_WORKSPACE, "qenv_create: workspace must be 256-byte aligned");
+    qenv_s* q = new (std::nothrow) qenv_s;
+    if (!q) return fail(QENV_ERR_ARG, "qenv_create: out of host memory");
+    q->cfg = *cfg; q->N = cfg->n_envs; q->ws = workspace; q->ws_bytes = bytes; q->stream = (hipStream_t)stream;
+    q->wsi = (int32_t*)((char*)workspace + L.int_off);
+    q->window = (float*)((char*)workspace + L.win_off);
+    q->win_head = 0;
+    hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
+    if (e != hipSuccess) { delete q; return fail_hip(e, "hipMemsetAsync(workspace)"); }
+    *out = q;
+    return QENV_OK;
+}
+
+int qenv_destroy(qenv_t q) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_destroy: null handle");
+    delete q;
+    return QENV_OK;
+}
+
+int qenv_set_stream(qenv_t q, void* stream) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_set_stream: null handle");
+    q->stream = (hipStream_t)stream;
+    return QENV_OK;
+}
+
+int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
+    if (!q || !dev_ptr) return fail(QENV_ERR_ARG, "qenv_field: null argument");
+    static const int row_of[] = {ROW_STATE, ROW_ANG, ROW_PREV_ANG, ROW_ANG_VEL, ROW_VQ, ROW_W, ROW_EFFORT, ROW_CLIPPED,
+                                 ROW_ACCEL, ROW_PREV_SHAPING, ROW_REWARD, ROW_ABS_SUM, ROW_EP_RETURN, ROW_PID};
+    static const int rows_of[] = {13, 3, 3, 3, 4, 4, 4, 4, 3, 1, 1, 1, 1, 15};
+    const size_t esz = q->cfg.dtype == QENV_F64 ? 8 : 4;
+    if (field_id >= 0 && field_id <= QENV_FIELD_PID) {
+        *dev_ptr = (char*)q->ws + (size_t)row_of[field_id] * q->N * esz;
+        if (rows) *rows = rows_of[field_id];
+    } else if (field_id == QENV_FIELD_I || field_id == QENV_FIELD_FLAGS) {
+        *dev_ptr = q->wsi + (field_id == QENV_FIELD_I ? IROW_I : IROW_FLAGS) * q->N;
+        if (rows) *rows = 1;
+    } else if (field_id == QENV_FIELD_WINDOW) {
+        *dev_ptr = q->window;
+        if (rows) *rows = 15 * q->cfg.T;
+    } else {
+        return fail(QENV_ERR_ARG, "qenv_field: unknown field id");
+    }
+    return QENV_OK;
+}
+
+int qenv_reset(qenv_t q, const void* init_states, const uint8_t* mask, void* out_states, void* out_actions) {
+    if (!q || !init_states) return fail(QENV_ERR_ARG, "qenv_reset: null argument");
+    return q->cfg.dtype == QENV_F64 ? do_reset<double>(q, init_states, mask, out_states, out_actions)
+                                    : do_reset<float>(q, init_states, mask, out_states, out_actions);
+}
+
+int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, uint8_t* out_done, int flags) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_step: null handle");
+    if (flags < QENV_STEP_FULL || flags > QENV_STEP_NO_AUX) return fail(QENV_ERR_ARG, "qenv_step: bad flags");
+    return q->cfg.dtype == QENV_F64 ? do_step<double>(q, actions, nullptr, out_obs, out_reward, out_done, flags)
+                                    : do_step<float>(q, actions, nullptr, out_obs, out_reward, out_done, flags);
+}
+
+int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_action, int pid_first_action, int flags) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_rollout: null handle");
+    if (controller < QENV_CTRL_CONST || controller > QENV_CTRL_PID) return fail(QENV_ERR_ARG, "qenv_rollout: bad controller");
+    if (n_steps < 0) return fail(QENV_ERR_ARG, "qenv_rollout: negative n_steps");
+    if (flags < QENV_STEP_FULL || flags > QENV_STEP_NO_AUX) return fail(QENV_ERR_ARG, "qenv_rollout: bad flags");
+    if (flags == QENV_STEP_DYNAMICS_ONLY && controller != QENV_CTRL_CONST)
+        return fail(QENV_ERR_STATE, "qenv_rollout: DYNAMICS_ONLY needs the constant-action controller");
+    if (controller != QENV_CTRL_CONST && q->cfg.direct_control)
+        return fail(QENV_ERR_STATE, "qenv_rollout: LQR/PID command [F,Mx,My,Mz]; create the handle with direct_control=0");
+    if (n_steps == 0) return QENV_OK;
+    return q->cfg.dtype == QENV_F64 ? do_rollout<double>(q, controller, n_steps, const_action, pid_first_action, flags)
+                                    : do_rollout<float>(q, controller, n_steps, const_action, pid_first_action, flags);
+}
+
+int qenv_lqr_action(qenv_t q, void* out_actions) {
+    if (!q || !out_actions) return fail(QENV_ERR_ARG, "qenv_lqr_action: null argument");
+    const dim3 g = grid_for(q->N), b(256);
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_lqr_action<double>), g, b, 0, q->stream, (const double*)q->ws, q->N,
+                           make_lqr<double>(q->cfg.clipped != 0), (double*)out_actions);
+    else
+        hipLaunchKernelGGL((k_lqr_action<float>), g, b, 0, q->stream, (const float*)q->ws, q->N,
+                           make_lqr<float>(q->cfg.clipped != 0), (float*)out_actions);
+    return check_launch("k_lqr_action");
+}
+
+int qenv_pid_action(qenv_t q, const double* targets, void* out_actions) {
+    if (!q || !out_actions) return fail(QENV_ERR_ARG, "qenv_pid_action: null argument");
+    const dim3 g = grid_for(q->N), b(256);
+    double t[4] = {0, 0, 0, 0};
+    if (targets) for (int k = 0; k < 4; ++k) t[k] = targets[k];
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_pid_action<double>), g, b, 0, q->stream, (double*)q->ws, q->N,
+                           make_pid<double>(q->cfg.clipped != 0), t[0], t[1], t[2], t[3], q->cfg.t_step, (double*)out_actions);
+    else
+        hipLaunchKernelGGL((k_pid_action<float>), g, b, 0, q->stream, (float*)q->ws, q->N,
+                           make_pid<float>(q->cfg.clipped != 0), (float)t[0], (float)t[1], (float)t[2], (float)t[3],
+                           (float)q->cfg.t_step, (float*)out_actions);
+    return check_launch("k_pid_action");
+}
+
+int qenv_pid_reset(qenv_t q, const uint8_t* mask) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_pid_reset: null handle");
+    const dim3 g = grid_for(q->N), b(256);
+    if (q->cfg.dtype == QENV_F64) hipLaunchKernelGGL((k_pid_reset<double>), g, b, 0, q->stream, (double*)q->ws, q->N, mask);
+    else hipLaunchKernelGGL((k_pid_reset<float>), g, b, 0, q->stream, (float*)q->ws, q->N, mask);
+    return check_launch("k_pid_reset");
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// qenv_host.hpp -- handle, workspace layout and error plumbing shared by the .hip units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/qenv.h"
+#include "qenv_core.hpp"
+
+namespace qenv {
+
+// Workspace rows of the handle's dtype (row r of env e at (r*N + e)).
+enum {
+    ROW_STATE = 0,          // 13
+    ROW_ANG = 13,           // 3
+    ROW_PREV_ANG = 16,      // 3
+    ROW_ANG_VEL = 19,       // 3
+    ROW_VQ = 22,            // 4
+    ROW_W = 26,             // 4
+    ROW_EFFORT = 30,        // 4
+    ROW_CLIPPED = 34,       // 4
+    ROW_ACCEL = 38,         // 3
+    ROW_PREV_SHAPING = 41,  // 1
+    ROW_REWARD = 42,        // 1
+    ROW_ABS_SUM = 43,       // 1
+    ROW_EP_RETURN = 44,     // 1
+    ROW_PID = 45,           // 15
+    ROWS_T = 60
+};
+enum { IROW_I = 0, IROW_FLAGS = 1, IROWS = 2 };
+
+struct WsLayout {
+    size_t int_off, win_off, total;
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline WsLayout ws_layout(const qenv_config& c) {
+    const size_t esz = c.dtype == QENV_F64 ? 8 : 4;
+    const size_t N = (size_t)c.n_envs;
+    WsLayout L;
+    L.int_off = align256((size_t)ROWS_T * N * esz);
+    L.win_off = align256(L.int_off + (size_t)IROWS * N * sizeof(int32_t));
+    L.total = align256(L.win_off + (size_t)15 * c.T * N * sizeof(float));
+    return L;
+}
+
+}  // namespace qenv
+
+struct qenv_s {
+    qenv_config cfg;
+    int64_t N;
+    void* ws;
+    size_t ws_bytes;
+    int32_t* wsi;
+    float* window;
+    int32_t win_head;  // ring slot the next push writes
+    hipStream_t stream;
+};
+
+namespace qenv {
+
+inline thread_local char g_err[256] = "";
+
+static inline int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+static inline int fail_hip(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return QENV_ERR_HIP;
+}
+static inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? (int)QENV_OK : fail_hip(e, what);
+}
+
+}  // namespace qenv

@@ -1,0 +1,361 @@
+// qenv_ppo.hip -- PPO inner-loop kernels: observation ring, actor/critic MLP forward on the
+// fp32 MFMA pipe, GAE reverse scan, advantage normalisation, landing reward.  gfx950 only.
+//
+// Reference behaviour restated (relative to /root/reference):
+//   environment/controller/dl_auxiliary.py:15-32   observation window
+//   environment/controller/model.py:27-42          actor / critic MLP
+//   environment/controller/ppo.py:125-141, visual_landing/ppo_trainer.py:133-148   GAE
+//   visual_landing/rl_reward_fuction.py:3-102      visual_reward
+#include "qenv_host.hpp"
+
+namespace qenv {
+
+// ---- observation ring -------------------------------------------------------------------------
+// dl_in_gen.dl_input shifts a 15*T window left and appends [action(4), vel(3), q(4), q_dot(4)].
+// Here the window is a ring of T slices (row block `slot`), so a push writes 60 B/env and
+// nothing is shifted; the MLP kernel reads the slices oldest-first starting at `head`.
+template <typename T>
+__global__ __launch_bounds__(256) void k_window_push(float* win, int64_t N, int slot, const T* obs, const T* act) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    float* w = win + (int64_t)slot * 15 * N + e;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[(int64_t)k * N] = (float)act[(int64_t)k * N + e];
+    w[4 * N] = (float)obs[1 * N + e];
+    w[5 * N] = (float)obs[3 * N + e];
+    w[6 * N] = (float)obs[5 * N + e];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[(int64_t)(7 + k) * N] = (float)obs[(int64_t)(6 + k) * N + e];
+}
+
+// ---- MLP forward on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains) ----------------------------
+// Orientation: D[h][e] = sum_k W[h][k] X[k][e]: A = weights (row = hidden unit), B = activations
+// (column = env), so a layer's accumulator tile (column on the lane, rows in the 16 registers)
+// is directly the next layer's B operand: register j of lane-half p holds hidden row
+// 32 t + (j&3) + 8 (j>>2) + 4 p, and the next layer simply pairs the two rows a register holds
+// across the lane halves as one k-step, reading the matching two weight columns.  No LDS
+// round trip, no shuffles between layers.  Weights are staged once per workgroup into LDS,
+// transposed to [k][h] so the 32 lanes of a half read 32 consecutive floats (conflict-free).
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct MlpArgs {
+    const float* win;   // [15*T][N] ring
+    int64_t N;
+    int32_t T, head, n_out, final_tanh;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    void* out;          // [n_out][N]
+    int32_t out_f64;
+};
+
+__device__ __forceinline__ int acc_row(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }
+
+template <int H, int BLOCK, bool W2_LDS>
+__global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
+    constexpr int HP = H < 32 ? 32 : H;  // hidden rows padded to the 32-row MFMA tile
+    constexpr int NT = HP / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K1 = 15 * a.T;
+    const int K1P = (K1 + 1) & ~1;
+    float* W1t = lds;                                   // [K1P][HP]
+    float* W2t = W1t + (size_t)K1P * HP;                // [HP][HP]   (k-major), only if W2_LDS
+    float* W3s = W2t + (W2_LDS ? (size_t)HP * HP : 0);  // [4][HP]
+    float* b1s = W3s + 4 * HP;
+    float* b2s = b1s + HP;
+    float* b3s = b2s + HP;  // [4]
+    for (int idx = threadIdx.x; idx < K1P * HP; idx += BLOCK) {
+        const int k = idx / HP, h = idx % HP;  // write-coalesced, conflict-free
+        W1t[idx] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
+    }
+    if (W2_LDS)
+        for (int idx = threadIdx.x; idx < HP * HP; idx += BLOCK) {
+            const int k = idx / HP, h = idx % HP;
+            W2t[idx] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
+        }
+    for (int idx = threadIdx.x; idx < 4 * HP; idx += BLOCK) {
+        const int o = idx / HP, h = idx % HP;
+        W3s[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
+    }
+    for (int h = threadIdx.x; h < HP; h += BLOCK) {
+        b1s[h] = h < H ? a.b1[h] : 0.f;
+        b2s[h] = h < H ? a.b2[h] : 0.f;
+    }
+    if (threadIdx.x < 4) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const int wave = threadIdx.x >> 6, waves_per_block = BLOCK / 64;
+    const int64_t n_tiles = (a.N + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * waves_per_block + wave; tile < n_tiles;
+         tile += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t e = tile * 32 + col;
+        const bool valid = e < a.N;
+        f32x16 acc1[NT], acc2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+                acc2[t][j] = b2s[32 * t + acc_row(j, half)];
+            }
+        // layer 1: k-step s covers window elements k = 2s (lanes 0-31) and 2s+1 (lanes 32-63)
+        for (int s = 0; s < K1P / 2; ++s) {
+            const int k = 2 * s + half;
+            float x = 0.f;
+            if (valid && k < K1) {
+                int slice = a.head + k / 15;
+                if (slice >= a.T) slice -= a.T;
+                x = a.win[(int64_t)(slice * 15 + k % 15) * a.N + e];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[k * HP + 32 * t + col], x, acc1[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = tanhf(acc1[t][j]);
+        // layer 2: register j of input tile ti IS the B operand of the k-step that pairs hidden
+        // rows 32 ti + acc_row(j,0) and 32 ti + acc_row(j,1)
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = 32 * ti + acc_row(j, half);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float w = W2_LDS ? W2t[k * HP + 32 * t + col]
+                                           : ((32 * t + col) < H ? a.W2[(size_t)(32 * t + col) * H + k] : 0.f);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, acc1[ti][j], acc2[t], 0, 0, 0);
+                }
+            }
+        // layer 3 on the VALU: each lane holds half of its env's hidden vector
+        float o3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float hv = tanhf(acc2[t][j]);
+                const int h = 32 * t + acc_row(j, half);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) o3[o] = fmaf(W3s[o * HP + h], hv, o3[o]);
+            }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = o3[o] + __shfl_xor(o3[o], 32);
+            v += b3s[o];
+            if (a.final_tanh) v = tanhf(v);
+            if (valid && half == 0 && o < a.n_out) {
+                if (a.out_f64) ((double*)a.out)[(int64_t)o * a.N + e] = (double)v;
+                else ((float*)a.out)[(int64_t)o * a.N + e] = v;
+            }
+        }
+    }
+}
+
+template <int H, int BLOCK, bool W2_LDS>
+static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
+    constexpr int HP = H < 32 ? 32 : H;
+    const int K1P = (15 * T + 1) & ~1;
+    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 4 * HP + 2 * HP + 4);
+    if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, BLOCK, W2_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
+    const int64_t n_tiles = (a.N + 31) / 32;
+    const int wpb = BLOCK / 64;
+    int64_t blocks = (n_tiles + wpb - 1) / wpb;
+    if (blocks > 256) blocks = 256;  // one resident workgroup per CU; waves grid-stride over env tiles
+    hipLaunchKernelGGL((k_mlp<H, BLOCK, W2_LDS>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+    return check_launch("k_mlp");
+}
+
+// ---- GAE ---------------------------------------------------------------------------------------
+// One lane per env scans its own time series backwards (rows are time-major, so each step
+// is a coalesced row access); the advantage moments for the global normalisation are reduced
+// with wavefront shuffles and one double atomicAdd pair per wave.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* values, const T* masks, const T* rewards,
+                                             T* returns, T* adv, double* stats) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    if (e < N) {
+        const T gmma = T(0.99), lmbda = T(0.99);
+        T gae = T(0);
+        T v_next = values[(int64_t)n_steps * N + e];
+        for (int i = n_steps - 1; i >= 0; --i) {
+            const int64_t o = (int64_t)i * N + e;
+            const T v = values[o], mk = masks[o];
+            const T delta = rewards[o] + gmma * v_next * mk - v;
+            gae = delta + gmma * lmbda * mk * gae;
+            const T ret = gae + v;
+            returns[o] = ret;
+            const T ad = ret - v;
+            adv[o] = ad;
+            s1 += (double)ad;
+            s2 += (double)ad * (double)ad;
+            v_next = v;
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&stats[1], s1);
+            atomicAdd(&stats[2], s2);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (double)N * (double)n_steps);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_adv_normalize(int64_t n, T* adv, const double* stats, int ddof) {
+    const double cnt = stats[0], mean = stats[1] / cnt;
+    double var = (stats[2] - cnt * mean * mean) / (cnt - ddof);
+    if (var < 0) var = 0;
+    const double inv = 1.0 / (sqrt(var) + 1e-10);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        adv[i] = (T)(((double)adv[i] - mean) * inv);
+}
+
+// ---- visual_reward -----------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_visual_reward(int64_t N, int total_steps, const T* marker, const T* pos,
+                                                       const T* vel, const T* control, const T* last_shaping,
+                                                       const int32_t* step, const T* ang, const T* v_ang, T* out_reward,
+                                                       T* out_shaping, uint8_t* out_done, int32_t* out_solved) {
+    using m = Mth<T>;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    const T mx = marker[e], my = marker[N + e], mz = marker[2 * N + e] - T(5);
+    const T px = pos[e], py = pos[N + e], pz = pos[2 * N + e];
+    const T exy = m::sqrt((mx - px) * (mx - px) + (my - py) * (my - py));
+    const T ez = m::abs(mz - pz);
+    const T vx = vel[e], vy = vel[N + e], vz = vel[2 * N + e];
+    const T nvel = m::sqrt(vx * vx + vy * vy + vz * vz);
+    const T c0 = control[e], c1 = control[N + e], c2 = control[2 * N + e];
+    const T ce = m::sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+    const T shaping = T(-4) * (exy * T(2) + ez);
+    const T a0 = ang[e], a1 = ang[N + e];
+    const T w0 = v_ang[e], w1 = v_ang[N + e], w2 = v_ang[2 * N + e];
+    const bool soft = nvel < T(0.5196152422706632);   // ||ones(3)*0.30||
+    const bool landed = pz <= T(-4.95);
+    const bool on_target = exy < T(0.14);
+    const bool flat = (m::sqrt(a0 * a0 + a1 * a1) < T(0.4937019546242588)) &&  // ||ones(2)*0.3491||
+                      (m::sqrt(w0 * w0 + w1 * w1 + w2 * w2) < T(1.4142135623730951));
+    const bool astray = (exy > ez / T(7) * T(5) + T(0.2)) || (ez > T(7));
+    const bool max_steps = step[e] > total_steps;
+    const T last = last_shaping[e];
+    T reward = (last != T(0)) ? shaping - last - T(0.1) * ce : -T(0.1) * ce;
+    bool done = false;
+    int solved = 0;
+    if (landed) {
+        if (soft) {
+            if (flat) { if (on_target) { reward = T(5); solved = 1; } else reward = T(1); }
+            else reward = T(0);
+        } else reward = T(-1);
+        done = true;
+    } else if (astray) { reward = T(-5); done = true; }
+    if (max_steps) { reward = T(-2); done = true; }
+    out_reward[e] = reward;
+    out_shaping[e] = shaping;
+    out_done[e] = done ? 1 : 0;
+    out_solved[e] = solved;
+}
+
+}  // namespace qenv
+
+using namespace qenv;
+
+extern "C" {
+
+int qenv_window_push(qenv_t q, const void* obs, const void* actions, int reset_first) {
+    if (!q || !obs || !actions) return fail(QENV_ERR_ARG, "qenv_window_push: null argument");
+    if (reset_first) {
+        hipError_t e = hipMemsetAsync(q->window, 0, sizeof(float) * 15 * (size_t)q->cfg.T * (size_t)q->N, q->stream);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(window)");
+        q->win_head = 0;
+    }
+    const dim3 g((unsigned)((q->N + 255) / 256)), b(256);
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_window_push<double>), g, b, 0, q->stream, q->window, q->N, q->win_head, (const double*)obs,
+                           (const double*)actions);
+    else
+        hipLaunchKernelGGL((k_window_push<float>), g, b, 0, q->stream, q->window, q->N, q->win_head, (const float*)obs,
+                           (const float*)actions);
+    q->win_head = (q->win_head + 1) % q->cfg.T;
+    return check_launch("k_window_push");
+}
+
+int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const float* W1, const float* b1, const float* W2,
+                     const float* b2, const float* W3, const float* b3, void* out) {
+    if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_mlp_forward: null argument");
+    if (n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_forward: n_out must be 1..4");
+    MlpArgs a;
+    a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = n_out; a.final_tanh = final_tanh;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
+    a.out_f64 = q->cfg.dtype == QENV_F64;
+    switch (hidden) {
+        case 16: return launch_mlp<16, 512, true>(a, q->cfg.T, q->stream);
+        case 32: return launch_mlp<32, 512, true>(a, q->cfg.T, q->stream);
+        case 64: return launch_mlp<64, 512, true>(a, q->cfg.T, q->stream);
+        case 128: return launch_mlp<128, 512, true>(a, q->cfg.T, q->stream);
+        case 256: return launch_mlp<256, 256, false>(a, q->cfg.T, q->stream);
+        default: return fail(QENV_ERR_ARG, "qenv_mlp_forward: hidden must be one of 16, 32, 64, 128, 256");
+    }
+}
+
+int qenv_gae(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,
+             void* returns, void* adv, double* stats, void* stream) {
+    if (!values || !masks || !rewards || !returns || !adv) return fail(QENV_ERR_ARG, "qenv_gae: null argument");
+    if (n_envs <= 0 || n_steps <= 0) return fail(QENV_ERR_ARG, "qenv_gae: n_envs and n_steps must be positive");
+    const dim3 g((unsigned)((n_envs + 255) / 256)), b(256);
+    if (dtype == QENV_F64)
+        hipLaunchKernelGGL((k_gae<double>), g, b, 0, (hipStream_t)stream, n_envs, n_steps, (const double*)values,
+                           (const double*)masks, (const double*)rewards, (double*)returns, (double*)adv, stats);
+    else if (dtype == QENV_F32)
+        hipLaunchKernelGGL((k_gae<float>), g, b, 0, (hipStream_t)stream, n_envs, n_steps, (const float*)values,
+                           (const float*)masks, (const float*)rewards, (float*)returns, (float*)adv, stats);
+    else return fail(QENV_ERR_ARG, "qenv_gae: bad dtype");
+    return check_launch("k_gae");
+}
+
+int qenv_adv_normalize(int dtype, int64_t n, void* adv, const double* stats, int ddof, void* stream) {
+    if (!adv || !stats) return fail(QENV_ERR_ARG, "qenv_adv_normalize: null argument");
+    if (n <= 0) return fail(QENV_ERR_ARG, "qenv_adv_normalize: n must be positive");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 g((unsigned)blocks), b(256);
+    if (dtype == QENV_F64)
+        hipLaunchKernelGGL((k_adv_normalize<double>), g, b, 0, (hipStream_t)stream, n, (double*)adv, stats, ddof);
+    else if (dtype == QENV_F32)
+        hipLaunchKernelGGL((k_adv_normalize<float>), g, b, 0, (hipStream_t)stream, n, (float*)adv, stats, ddof);
+    else return fail(QENV_ERR_ARG, "qenv_adv_normalize: bad dtype");
+    return check_launch("k_adv_normalize");
+}
+
+int qenv_visual_reward(int dtype, int64_t n_envs, int total_steps, const void* marker, const void* pos, const void* vel,
+                       const void* control, const void* last_shaping, const int32_t* step, const void* ang,
+                       const void* v_ang, void* out_reward, void* out_shaping, uint8_t* out_done, int32_t* out_solved,
+                       void* stream) {
+    if (!marker || !pos || !vel || !control || !last_shaping || !step || !ang || !v_ang || !out_reward || !out_shaping ||
+        !out_done || !out_solved)
+        return fail(QENV_ERR_ARG, "qenv_visual_reward: null argument");
+    if (n_envs <= 0) return fail(QENV_ERR_ARG, "qenv_visual_reward: n_envs must be positive");
+    const dim3 g((unsigned)((n_envs + 255) / 256)), b(256);
+    if (dtype == QENV_F64)
+        hipLaunchKernelGGL((k_visual_reward<double>), g, b, 0, (hipStream_t)stream, n_envs, total_steps,
+                           (const double*)marker, (const double*)pos, (const double*)vel, (const double*)control,
+                           (const double*)last_shaping, step, (const double*)ang, (const double*)v_ang, (double*)out_reward,
+                           (double*)out_shaping, out_done, out_solved);
+    else if (dtype == QENV_F32)
+        hipLaunchKernelGGL((k_visual_reward<float>), g, b, 0, (hipStream_t)stream, n_envs, total_steps,
+                           (const float*)marker, (const float*)pos, (const float*)vel, (const float*)control,
+                           (const float*)last_shaping, step, (const float*)ang, (const float*)v_ang, (float*)out_reward,
+                           (float*)out_shaping, out_done, out_solved);
+    else return fail(QENV_ERR_ARG, "qenv_visual_reward: bad dtype");
+    return check_launch("k_visual_reward");
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""PPO inner loop on the device: observation ring, actor/critic MLP (fp32 MFMA), GAE,
+landing reward and the rollout collector.
+
+Reference (relative to /root/reference):
+  environment/controller/dl_auxiliary.py:15-32   dl_in_gen
+  environment/controller/model.py:20-85          ActorCritic
+  environment/controller/ppo.py:125-141,211-269  get_advantages, worker rollouts
+  visual_landing/ppo_trainer.py:133-148          get_advantages (ddof=1)
+  visual_landing/rl_reward_fuction.py:3-102      visual_reward
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .quadrotor_env import BatchedQuad, quad
+
+
+class ActorCriticWeights:
+    """float32 device copies of model.py's actor / critic Linear layers, torch layout
+    ([out, in] row-major), read directly by the MFMA kernel."""
+
+    def __init__(self, actor, critic, device="cuda", std=0.1):
+        self.device = torch.device(device)
+        def dev(t):
+            t = t.detach() if isinstance(t, torch.Tensor) else torch.from_numpy(np.asarray(t))
+            return t.to(device=self.device, dtype=torch.float32).contiguous()
+        self.actor = [dev(t) for t in actor]
+        self.critic = None if critic is None else [dev(t) for t in critic]
+        self.std = float(std)
+        self.hidden = self.actor[0].shape[0]
+        self.state_dim = self.actor[0].shape[1]
+
+    @classmethod
+    def from_state_dict(cls, sd, device="cuda"):
+        """`sd`: torch state_dict of model.py's ActorCritic (keys actor.{0,2,4}.{weight,bias}, ...)
+        or the same keys with '_' (re-exported .npz)."""
+        def get(k):
+            v = sd[k] if k in sd else sd[k.replace(".", "_")]
+            return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        actor = [get(f"actor.{l}.{p}") for l in (0, 2, 4) for p in ("weight", "bias")]
+        has_critic = ("critic.0.weight" in sd) or ("critic_0_weight" in sd)
+        critic = [get(f"critic.{l}.{p}") for l in (0, 2, 4) for p in ("weight", "bias")] if has_critic else None
+        std = float(get("std")) if ("std" in sd) else 0.1
+        return cls(actor, critic, device, std)
+
+    @classmethod
+    def random(cls, hidden, state_dim=75, action_dim=4, device="cuda", seed=0):
+        """nn.Linear default init (uniform +-1/sqrt(fan_in)) from a numpy stream."""
+        rng = np.random.RandomState(seed)
+
+        def lin(o, i):
+            b = 1.0 / np.sqrt(i)
+            return rng.uniform(-b, b, (o, i)), rng.uniform(-b, b, o)
+        def mlp(out):
+            W1, b1 = lin(hidden, state_dim); W2, b2 = lin(hidden, hidden); W3, b3 = lin(out, hidden)
+            return [W1, b1, W2, b2, W3, b3]
+        return cls(mlp(action_dim), mlp(1), device)
+
+    def head(self, name):
+        if name == "actor":
+            return self.actor
+        if self.critic is None:
+            raise ValueError("no critic weights loaded")
+        return self.critic
+
+
+class dl_in_gen:
+    """dl_auxiliary.py:15-32 for one `quad`: the T-slice window lives in the env's device
+    ring; dl_input() pushes slices and returns the window in the reference's time order."""
+
+    def __init__(self, T, state_size, action_size, env=None):
+        if env is None:
+            raise ValueError("dl_in_gen(T, state_size, action_size, env=<quad>): the window is kept on the device of "
+                             "the env it observes")
+        self._b = env._b if isinstance(env, quad) else env
+        if self._b.T != T:
+            raise ValueError(f"window length T={T} must equal the env's T={self._b.T}")
+        self.hist_size = (state_size - 3) + action_size + 1
+        self.deep_learning_in_size = self.hist_size * T
+        self.T = T
+        self._pushes = 0
+        self._pending_reset = True
+        self.deep_learning_input = np.zeros(self.deep_learning_in_size, dtype=np.float32)
+
+    def reset(self):
+        self._pending_reset = True
+        self._pushes = 0
+        self.deep_learning_input = np.zeros(self.deep_learning_in_size, dtype=np.float32)
+
+    def dl_input(self, states, actions):
+        b = self._b
+        for s, a in zip(np.atleast_2d(states), np.atleast_2d(actions)):
+            b.window_push(torch.from_numpy(np.asarray(s, dtype=np.float64).reshape(14, 1)),
+                          torch.from_numpy(np.asarray(a, dtype=np.float64).reshape(4, 1)), self._pending_reset)
+            self._pending_reset = False
+            self._pushes += 1
+        ring = b.window[:, 0].cpu().numpy().reshape(self.T, self.hist_size)
+        head = self._pushes % self.T  # oldest slice
+        self.deep_learning_input = np.concatenate([ring[(head + j) % self.T] for j in range(self.T)]).astype(np.float32)
+        return self.deep_learning_input
+
+
+def gae(values, masks, rewards, ddof=0, group=None, normalize=True):
+    """PPO.get_advantages (ppo.py:125-141 ddof=0; ppo_trainer.py:133-148 ddof=1) on a
+    time-major rollout: values [n+1, N], masks [n, N], rewards [n, N] device tensors.
+    Returns (returns [n, N], normalised advantages [n, N]).  With `group`
+    (torch.distributed) the normalisation moments are all-reduced so every shard uses the
+    global mean/std, exactly like a single learner."""
+    n, N = rewards.shape
+    assert values.shape == (n + 1, N) and masks.shape == (n, N)
+    dt = L.F64 if values.dtype == torch.float64 else L.F32
+    values, masks, rewards = values.contiguous(), masks.to(values.dtype).contiguous(), rewards.contiguous()
+    ret = torch.empty_like(rewards)
+    adv = torch.empty_like(rewards)
+    stats = torch.zeros(3, dtype=torch.float64, device=values.device)
+    stream = C.c_void_p(torch.cuda.current_stream(values.device).cuda_stream)
+    L.check(L.lib.qenv_gae(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(ret), L.ptr(adv),
+                           L.ptr(stats), stream), "qenv_gae")
+    if not normalize:
+        return ret, adv
+    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                             and torch.distributed.get_world_size() > 1 and group is not False):
+        torch.distributed.all_reduce(stats, group=group if group not in (None, False) else None)
+    L.check(L.lib.qenv_adv_normalize(dt, n * N, L.ptr(adv), L.ptr(stats), int(ddof), stream), "qenv_adv_normalize")
+    return ret, adv
+
+
+def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, ang, v_ang):
+    """Batched visual_landing/rl_reward_fuction.py:3-102.  [3, N] tensors (marker, pos, vel,
+    control, ang, v_ang), last_shaping [N] (0 = none), step int32 [N].
+    Returns (reward [N], shaping [N], done [N] bool, n_solved [N] int32)."""
+    N = pos.shape[1]
+    dt = L.F64 if pos.dtype == torch.float64 else L.F32
+    c = lambda t: t.to(pos.dtype).contiguous()
+    marker, pos, vel, control, ang, v_ang, last_shaping = map(c, (marker, pos, vel, control, ang, v_ang, last_shaping))
+    step = step.to(torch.int32).contiguous()
+    rew = torch.empty(N, dtype=pos.dtype, device=pos.device)
+    sh = torch.empty_like(rew)
+    done = torch.empty(N, dtype=torch.uint8, device=pos.device)
+    ns = torch.empty(N, dtype=torch.int32, device=pos.device)
+    stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+    L.check(L.lib.qenv_visual_reward(dt, N, int(total_steps), L.ptr(marker), L.ptr(pos), L.ptr(vel), L.ptr(control),
+                                     L.ptr(last_shaping), L.ptr(step), L.ptr(ang), L.ptr(v_ang), L.ptr(rew), L.ptr(sh),
+                                     L.ptr(done), L.ptr(ns), stream), "qenv_visual_reward")
+    return rew, sh, done.bool(), ns
+
+
+class PolicyRollout:
+    """Rollout collector of ppo.py's worker loop (:223-269) for N envs at once:
+    window -> actor (MFMA) -> [+ injected Gaussian noise] -> env.step -> window push ->
+    critic, stored time-major; `finish()` runs GAE.  Episodes that end are re-started from
+    caller-supplied initial states (auto-reset), as the worker's `while` loop does."""
+
+    def __init__(self, env: BatchedQuad, weights: ActorCriticWeights, horizon):
+        assert env.direct_control_flag, "the PPO controller commands the four rotors (direct_control=1)"
+        self.env, self.w, self.horizon = env, weights, int(horizon)
+        N, dev, dt = env.n_envs, env.device, env.dtype
+        self.actions = torch.empty(horizon, 4, N, device=dev, dtype=dt)
+        self.rewards = torch.empty(horizon, N, device=dev, dtype=dt)
+        self.masks = torch.empty(horizon, N, device=dev, dtype=dt)
+        self.values = torch.zeros(horizon + 1, N, device=dev, dtype=dt)
+        self.t = 0
+
+    def start(self, init_states):
+        env = self.env
+        states, actions = env.reset(init_states)
+        for k in range(env.T):
+            env.window_push(states[k], actions[k], reset_first=(k == 0))
+        self.t = 0
+
+    def step(self, noise=None, deterministic=False):
+        """One env step for all envs.  noise: [4, N] standard-normal tensor (injected so CPU
+        and GPU runs can share it)."""
+        env, t = self.env, self.t
+        mean = env.mlp_forward(self.w, "actor")
+        if self.w.critic is not None:
+            env.mlp_forward(self.w, "critic", out=self.values[t:t + 1])
+        act = mean if (deterministic or noise is None) else mean + self.w.std * noise.to(mean.dtype)
+        self.actions[t].copy_(act)
+        obs, rew, done = env.step(act)
+        env.window_push(obs, act)
+        self.rewards[t].copy_(rew)
+        self.masks[t].copy_((~done).to(self.rewards.dtype))
+        self.t += 1
+        return obs, rew, done
+
+    def finish(self, ddof=0, group=False):
+        n = self.t
+        if self.w.critic is not None:
+            self.env.mlp_forward(self.w, "critic", out=self.values[n:n + 1])
+            self.values[n].mul_(self.masks[n - 1])
+        return gae(self.values[:n + 1], self.masks[:n], self.rewards[:n], ddof=ddof, group=group)

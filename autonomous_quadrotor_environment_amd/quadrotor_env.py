@@ -1,0 +1,406 @@
+"""Host-side mirror of the reference environment API on top of libqenv.so.
+
+* ``BatchedQuad`` -- N quadrotors, structure-of-arrays device tensors ([rows, N]), one HIP
+  kernel launch per ``step()`` (or per fused ``rollout()``).
+* ``quad``        -- the reference's duck-typed class for ONE env
+  (/root/reference/environment/quadrotor_env.py:111-577): same constructor, ``seed``,
+  ``reset``, ``step`` and the attributes controllers read after ``step``, so
+  environment/controller/* scripts and visual_landing/ppo_trainer.py-style loops run unchanged.
+
+Nothing here computes dynamics: every number comes from the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+# constants callers read off the reference module (quadrotor_env.py:30-81)
+M, G = 1.03, 9.82
+T2WR = 2
+J = np.array([[16.83e-3, 0, 0], [0, 16.83e-3, 0], [0, 0, 28.34e-3]])
+BB_POS, BB_VEL, BB_ANG = 5, 10, np.pi / 2
+
+
+def euler_quat(ang):
+    """quaternion_euler_utility.py:17-36 (host side, used only to build initial states)."""
+    phi, theta, psi = (float(a) for a in ang)
+    cp, sp = np.cos(phi / 2), np.sin(phi / 2)
+    ct, st = np.cos(theta / 2), np.sin(theta / 2)
+    cps, sps = np.cos(psi / 2), np.sin(psi / 2)
+    q = np.array([cp * ct * cps + sp * st * sps, sp * ct * cps - cp * st * sps,
+                  cp * st * cps + sp * ct * sps, cp * ct * sps - sp * st * cps])
+    return q / np.linalg.norm(q)
+
+
+def quat_euler(q):
+    """quaternion_euler_utility.py:39-48 (host side convenience)."""
+    q = np.asarray(q, dtype=np.float64).ravel()
+    return np.array([np.arctan2(2 * (q[0] * q[1] + q[2] * q[3]), 1 - 2 * (q[1] ** 2 + q[2] ** 2)),
+                     np.arcsin(2 * (q[0] * q[2] - q[3] * q[1])),
+                     np.arctan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] ** 2 + q[3] ** 2))])
+
+
+def random_init_states(rng, n_envs, variant="main"):
+    """Initial 13-states in the reference's RNG draw order (reset(): quadrotor_env.py:426,
+    440-445; robust_control.reset consumes 12 draws first, :97-101), env after env on one
+    legacy MT19937 stream.  `rng`: np.random.RandomState, the np.random module, or a seed.
+    Returns float64 [n_envs, 13]."""
+    if isinstance(rng, (int, np.integer)):
+        rng = np.random.RandomState(int(rng))
+    out = np.zeros((n_envs, 13))
+    for k in range(n_envs):
+        if variant == "main":
+            rng.random_sample(4); rng.normal(0, 0.3, 1); rng.random_sample(4)
+            rng.normal(np.zeros(3), 0.1 * np.ones(3), [3])
+        ang = rng.rand(3) - 0.5
+        out[k, 0:5:2] = np.clip(rng.normal([0, 0, 0], 2), -BB_POS / 2, BB_POS / 2)
+        out[k, 1:6:2] = np.clip(rng.normal([0, 0, 0], 2), -BB_VEL / 2, BB_VEL / 2)
+        out[k, 6:10] = euler_quat(ang)
+        out[k, 10:13] = np.clip(rng.normal([0, 0, 0], 2), -BB_VEL * 1.5, BB_POS * 1.5)
+    return out
+
+
+def _draw_block(g, n):
+    """n initial states with the reference's distributions (quadrotor_env.py:440-445)."""
+    ang = g.random((n, 3)) - 0.5
+    out = np.zeros((n, 13))
+    out[:, 0:5:2] = np.clip(g.normal(0, 2, (n, 3)), -BB_POS / 2, BB_POS / 2)
+    out[:, 1:6:2] = np.clip(g.normal(0, 2, (n, 3)), -BB_VEL / 2, BB_VEL / 2)
+    cp, sp = np.cos(ang[:, 0] / 2), np.sin(ang[:, 0] / 2)
+    ct, st = np.cos(ang[:, 1] / 2), np.sin(ang[:, 1] / 2)
+    cs, ss = np.cos(ang[:, 2] / 2), np.sin(ang[:, 2] / 2)
+    q = np.stack([cp * ct * cs + sp * st * ss, sp * ct * cs - cp * st * ss, cp * st * cs + sp * ct * ss,
+                  cp * ct * ss - sp * st * cs], 1)
+    out[:, 6:10] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    out[:, 10:13] = np.clip(g.normal(0, 2, (n, 3)), -BB_VEL * 1.5, BB_POS * 1.5)
+    return out
+
+
+def fast_random_init_states(seed, n_envs, lo=0, hi=None, chunk=4096):
+    """Vectorised initial states with the reference's distributions but NOT its draw order:
+    env index -> (chunk, offset) with one Philox stream per chunk keyed by (seed, chunk), so
+    any shard [lo, hi) of the global batch is bit-identical whatever the number of GPUs.
+    Returns float64 [hi-lo, 13]."""
+    hi = n_envs if hi is None else hi
+    out = np.empty((hi - lo, 13))
+    for c in range(lo // chunk, (hi - 1) // chunk + 1):
+        g = np.random.Generator(np.random.Philox(key=np.array([int(seed), c], dtype=np.uint64)))
+        block = _draw_block(g, chunk)
+        a, b = max(lo, c * chunk), min(hi, (c + 1) * chunk)
+        out[a - lo:b - lo] = block[a - c * chunk:b - c * chunk]
+    return out
+
+
+class BatchedQuad:
+    """N independent quadrotors stepped by one HIP kernel launch.
+
+    All tensors are structure-of-arrays on the device: state [13, N], actions [4, N],
+    observations [14, N].  Constructor arguments follow the reference's
+    ``quad(t_step, n, training, euler, direct_control, T, clipped)`` (quadrotor_env.py:112)
+    after the leading ``n_envs``.
+    """
+
+    def __init__(self, n_envs, t_step, n, training=True, euler=0, direct_control=1, T=1, clipped=True,
+                 variant="main", integrator="rk45", device="cuda", dtype=torch.float32):
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be torch.float32 or torch.float64")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedQuad runs on the GPU only (device='cuda[:i]'); there is no CPU path")
+        self.n_envs = int(n_envs)
+        self.dtype = dtype
+        self.t_step = t_step
+        self.T = int(T)
+        self.n = int(n) + self.T
+        self.training = bool(training)
+        self.direct_control_flag = direct_control
+        self.clipped = clipped
+        self.variant = variant
+        self.integrator = integrator
+        self.state_size, self.action_size = 13, 4
+        self.mass, self.gravity = M, G
+        self.J_mat = J
+        self._cfg = L.QenvConfig(self.n_envs, float(t_step), int(n), self.T, int(bool(training)),
+                                 int(bool(direct_control)), int(bool(clipped)), L.VARIANTS[variant],
+                                 L.INTEGRATORS[integrator], L.F64 if dtype == torch.float64 else L.F32)
+        nbytes = L.lib.qenv_workspace_bytes(C.byref(self._cfg))
+        if nbytes == 0:
+            raise L.QenvError("qenv_workspace_bytes rejected the configuration")
+        with torch.cuda.device(self.device):
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._h = C.c_void_p()
+            L.check(L.lib.qenv_create(C.byref(self._cfg), L.ptr(self._ws), nbytes, self._stream(), C.byref(self._h)),
+                    "qenv_create")
+        self._fields = {}
+        if direct_control:
+            self.zero_control = np.ones(4) * (2 / T2WR - 1)
+        else:
+            self.zero_control = np.array([M * G, 0, 0, 0])
+        if variant == "opt":
+            bb = np.array([10, 10, 10, np.pi / 2, np.pi / 2, 4, 30, 30, 30], dtype=float)
+            self.bb_cond = bb if training else bb * 1000
+        else:
+            self.bb_cond = np.array([10, 10, 10, np.pi / 2, np.pi / 2, 3 / 4 * np.pi, 20, 20, 20])
+
+    # ---- plumbing -------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _bind(self):
+        L.check(L.lib.qenv_set_stream(self._h, self._stream()), "qenv_set_stream")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            L.lib.qenv_destroy(h)
+            self._h = None
+
+    def _field(self, fid, dtype=None):
+        if fid not in self._fields:
+            p, rows = C.c_void_p(), C.c_int32()
+            L.check(L.lib.qenv_field(self._h, fid, C.byref(p), C.byref(rows)), "qenv_field")
+            dt = dtype or self.dtype
+            esz = torch.empty(0, dtype=dt).element_size()
+            off = p.value - self._ws.data_ptr()
+            nb = rows.value * self.n_envs * esz
+            self._fields[fid] = self._ws[off:off + nb].view(dt).view(rows.value, self.n_envs)
+        return self._fields[fid]
+
+    def _as_rows(self, x, rows, name):
+        """Accept [rows, N] (native) or [N, rows]; return a contiguous device tensor [rows, N]."""
+        if x is None:
+            return None
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        x = x.to(device=self.device, dtype=self.dtype)
+        if x.dim() == 1 and x.numel() == rows:
+            x = x.view(rows, 1).expand(rows, self.n_envs)
+        if x.shape == (rows, self.n_envs):
+            return x.contiguous()
+        if x.shape == (self.n_envs, rows):
+            return x.t().contiguous()
+        raise ValueError(f"{name}: expected shape [{rows}, {self.n_envs}] (or its transpose), got {tuple(x.shape)}")
+
+    # ---- attributes (device views into the workspace, [rows, N]) -----------------------------
+    state = property(lambda s: s._field(L.FIELD_STATE))
+    previous_state = state
+    ang = property(lambda s: s._field(L.FIELD_ANG))
+    prev_ang = property(lambda s: s._field(L.FIELD_PREV_ANG))
+    ang_vel = property(lambda s: s._field(L.FIELD_ANG_VEL))
+    V_q = property(lambda s: s._field(L.FIELD_VQ))
+    w = property(lambda s: s._field(L.FIELD_W))
+    step_effort = property(lambda s: s._field(L.FIELD_STEP_EFFORT))
+    clipped_action = property(lambda s: s._field(L.FIELD_CLIPPED_ACTION))
+    accel = property(lambda s: s._field(L.FIELD_ACCEL))
+    prev_shaping = property(lambda s: s._field(L.FIELD_PREV_SHAPING)[0])
+    reward = property(lambda s: s._field(L.FIELD_REWARD)[0])
+    abs_sum = property(lambda s: s._field(L.FIELD_ABS_SUM)[0])
+    episode_return = property(lambda s: s._field(L.FIELD_EP_RETURN)[0])
+    pid_state = property(lambda s: s._field(L.FIELD_PID))
+    i = property(lambda s: s._field(L.FIELD_I, torch.int32)[0])
+    flags = property(lambda s: s._field(L.FIELD_FLAGS, torch.int32)[0])
+    window = property(lambda s: s._field(L.FIELD_WINDOW, torch.float32))
+    done = property(lambda s: (s.flags & L.FLAG_DONE) != 0)
+    solved = property(lambda s: ((s.flags & L.FLAG_SOLVED) != 0).to(torch.int32))
+
+    @property
+    def quat_state(self):
+        return torch.cat([self.state[0:10], self.V_q], 0)
+
+    # ---- reference API ----------------------------------------------------------------------
+    def seed(self, seed):
+        self._rng = np.random.RandomState(seed)
+
+    def reset(self, det_state=None, mask=None, return_history=True):
+        """quad.reset (quadrotor_env.py:408-454).  det_state: [13, N] / [N, 13] / [13] tensor
+        or array; None draws every env's state in the reference's RNG order on the host.
+        Returns (states [T, 14, N], actions [T, 4, N])."""
+        if det_state is None:
+            rng = getattr(self, "_rng", None) or np.random.RandomState()
+            self._rng = rng
+            det_state = random_init_states(rng, self.n_envs, self.variant).T.copy()
+        init = self._as_rows(det_state, 13, "det_state")
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        states = torch.empty(self.T, 14, self.n_envs, device=self.device, dtype=self.dtype) if return_history else None
+        actions = torch.empty(self.T, 4, self.n_envs, device=self.device, dtype=self.dtype) if return_history else None
+        if return_history and mask is not None:
+            states.zero_(); actions.zero_()
+        self._bind()
+        L.check(L.lib.qenv_reset(self._h, L.ptr(init), L.ptr(m), L.ptr(states), L.ptr(actions)), "qenv_reset")
+        return states, actions
+
+    def step(self, action=None, flags=L.STEP_FULL, out=None):
+        """quad.step for all envs.  action [4, N] (or [N, 4]); None = zero_control.
+        Returns (quat_state [14, N], reward [N], done [N] bool)."""
+        act = self._as_rows(action, 4, "action")
+        self._bind()
+        if flags == L.STEP_DYNAMICS_ONLY:
+            L.check(L.lib.qenv_step(self._h, L.ptr(act), None, None, None, flags), "qenv_step")
+            return None, None, None
+        if out is None:
+            obs = torch.empty(14, self.n_envs, device=self.device, dtype=self.dtype)
+            rew = torch.empty(self.n_envs, device=self.device, dtype=self.dtype)
+            done = torch.empty(self.n_envs, device=self.device, dtype=torch.uint8)
+        else:
+            obs, rew, done = out
+        L.check(L.lib.qenv_step(self._h, L.ptr(act), L.ptr(obs), L.ptr(rew), L.ptr(done), flags), "qenv_step")
+        return obs, rew, done.bool() if out is None else done
+
+    def rollout(self, controller="const", n_steps=1, action=None, pid_first_action=False, flags=L.STEP_FULL):
+        """n_steps fused env steps in one launch with an on-device controller
+        ('const' | 'lqr' | 'pid'); state stays in registers between steps."""
+        ctrl = {"const": L.CTRL_CONST, "lqr": L.CTRL_LQR, "pid": L.CTRL_PID}[controller]
+        ca = None
+        if action is not None:
+            ca = (C.c_double * 4)(*[float(a) for a in np.asarray(action).ravel()])
+        self._bind()
+        L.check(L.lib.qenv_rollout(self._h, ctrl, int(n_steps), ca, int(bool(pid_first_action)), flags), "qenv_rollout")
+
+    def lqr_action(self, out=None):
+        out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        self._bind()
+        L.check(L.lib.qenv_lqr_action(self._h, L.ptr(out)), "qenv_lqr_action")
+        return out
+
+    def pid_action(self, targets=None, out=None):
+        out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        tg = None if targets is None else (C.c_double * 4)(*[float(a) for a in targets])
+        self._bind()
+        L.check(L.lib.qenv_pid_action(self._h, tg, L.ptr(out)), "qenv_pid_action")
+        return out
+
+    def pid_reset(self, mask=None):
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._bind()
+        L.check(L.lib.qenv_pid_reset(self._h, L.ptr(m)), "qenv_pid_reset")
+
+    # ---- PPO inner loop -----------------------------------------------------------------------
+    def window_push(self, obs, actions, reset_first=False):
+        o = self._as_rows(obs, 14, "obs")
+        a = self._as_rows(actions, 4, "actions")
+        self._bind()
+        L.check(L.lib.qenv_window_push(self._h, L.ptr(o), L.ptr(a), int(bool(reset_first))), "qenv_window_push")
+
+    def mlp_forward(self, weights, head="actor", out=None):
+        """ActorCritic.actor / .critic forward on the observation ring (model.py:27-42)."""
+        W1, b1, W2, b2, W3, b3 = weights.head(head)
+        n_out = W3.shape[0]
+        out = torch.empty(n_out, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        self._bind()
+        L.check(L.lib.qenv_mlp_forward(self._h, W1.shape[0], n_out, int(head == "actor"), L.ptr(W1), L.ptr(b1),
+                                       L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out)), "qenv_mlp_forward")
+        return out
+
+
+class quad:
+    """Drop-in for the reference's single-environment class (quadrotor_env.py:111-577 /
+    quadrotor_env_opt.py:78-484 with ``variant='opt'``).  numpy in, numpy out, same shapes;
+    every step is one HIP launch on a batch of one plus a single small device-to-host copy.
+    ``dtype`` defaults to float64 so trajectories match the fp64 reference to ~1e-12."""
+
+    def __init__(self, t_step, n, training=True, euler=0, direct_control=1, T=1, clipped=True,
+                 variant="main", integrator="rk45", device="cuda", dtype=torch.float64):
+        self._b = BatchedQuad(1, t_step, n, training=training, euler=euler, direct_control=direct_control, T=T,
+                              clipped=clipped, variant=variant, integrator=integrator, device=device, dtype=dtype)
+        b = self._b
+        self.clipped = clipped
+        self.ppo_training = bool(training)
+        self.mass, self.gravity = M, G
+        self.T = T
+        self.bb_cond = b.bb_cond
+        self.state_size, self.action_size = 13, 4
+        self.n = b.n
+        self.t_step = t_step
+        self.zero_control = b.zero_control
+        self.direct_control_flag = direct_control
+        self.J_mat = J
+        self.robust_control = False
+        self.i = 0
+        self.done = True
+        self.solved = 0
+        self.reward = 0
+        self.abs_sum = 0
+        self.ang = np.zeros(3)
+        self.ang_vel = np.zeros(3)
+        self.prev_ang = np.zeros(3)
+        self.action_hist = []
+        self.target_state = 9 * ((0.001 if variant == "opt" else 0.005) ** 2)
+        ev_cd = 'Training' if self.ppo_training else 'Eval'
+        print('Environment Condition: ' + ev_cd)  # quadrotor_env.py:185-187
+
+    def seed(self, seed):
+        np.random.seed(seed)  # the reference seeds the GLOBAL numpy stream (:193)
+
+    def _pull(self):
+        """One D2H copy of the whole (tiny) workspace, then refresh the numpy attributes."""
+        b = self._b
+        host = b._ws.cpu()
+        base = b._ws.data_ptr()
+
+        def rows(fid, dt=None):
+            t = b._field(fid, dt)
+            off = t.data_ptr() - base
+            dt = dt or b.dtype
+            return host[off:off + t.numel() * t.element_size()].view(dt).numpy().astype(
+                np.float64 if dt != torch.int32 else np.int64).reshape(t.shape[0])
+
+        self.state = rows(L.FIELD_STATE)
+        self.previous_state = self.state
+        self.ang = rows(L.FIELD_ANG)
+        self.prev_ang = rows(L.FIELD_PREV_ANG)
+        self.ang_vel = rows(L.FIELD_ANG_VEL)
+        self.V_q = rows(L.FIELD_VQ)
+        self.w = rows(L.FIELD_W).reshape(4, 1)
+        self.step_effort = rows(L.FIELD_STEP_EFFORT)
+        self.clipped_action = rows(L.FIELD_CLIPPED_ACTION)
+        self.accel = rows(L.FIELD_ACCEL).reshape(3, 1)
+        self.reward = float(rows(L.FIELD_REWARD)[0])
+        self.abs_sum = float(rows(L.FIELD_ABS_SUM)[0])
+        self.i = int(rows(L.FIELD_I, torch.int32)[0])
+        fl = int(rows(L.FIELD_FLAGS, torch.int32)[0])
+        self.done = bool(fl & L.FLAG_DONE)
+        self.solved = 1 if fl & L.FLAG_SOLVED else 0
+        self.prev_shaping = float(rows(L.FIELD_PREV_SHAPING)[0]) if fl & L.FLAG_HAS_SHAPING else None
+        self.quat_state = np.array([np.concatenate((self.state[0:10], self.V_q))])
+        self.current_state = float(np.sum(np.square(np.concatenate((self.state[1:6:2], self.ang, self.state[-3:])))))
+
+    # lazily derived side outputs of the last RHS call (drone_eq :315,:352,:371)
+    @property
+    def mat_rot(self):
+        q = self.state[6:10] / np.linalg.norm(self.state[6:10])
+        a, b, c, d = q
+        return np.array([[a * a + b * b - c * c - d * d, 2 * b * c - 2 * a * d, 2 * b * d + 2 * a * c],
+                         [2 * b * c + 2 * a * d, a * a - b * b + c * c - d * d, 2 * c * d - 2 * a * b],
+                         [2 * b * d - 2 * a * c, 2 * c * d + 2 * a * b, a * a - b * b - c * c + d * d]])
+
+    @property
+    def f_in(self):
+        return np.array([[0, 0, self.clipped_action[0] if not self.direct_control_flag
+                          else float(np.sum((self.clipped_action + 1) * T2WR * M * G / 8))]]).T
+
+    @property
+    def accelerometer_read(self):
+        return self.mat_rot.T @ (self.accel.flatten() + np.array([0, 0, -G]))
+
+    def reset(self, det_state=None):
+        b = self._b
+        if det_state is None:
+            x0 = random_init_states(np.random, 1, b.variant)  # global stream, reference draw order
+        else:
+            x0 = np.asarray(det_state, dtype=np.float64).reshape(1, 13)
+        self.action_hist = [self.zero_control for _ in range(self.T)]
+        states, actions = b.reset(torch.from_numpy(x0.T.copy()))
+        self.action = self.zero_control
+        self._pull()
+        return (states[:, :, 0].double().cpu().numpy(), actions[:, :, 0].double().cpu().numpy())
+
+    def step(self, action):
+        b = self._b
+        a = np.asarray(action, dtype=np.float64).reshape(4)
+        self.action = np.clip(a, -1, 1) if self.direct_control_flag else a
+        b.step(torch.from_numpy(a.reshape(4, 1)))
+        self._pull()
+        self.action_hist.append(self.clipped_action)
+        return self.quat_state, self.reward, self.done

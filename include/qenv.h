@@ -1,0 +1,215 @@
+/*
+ * qenv.h -- C-ABI of the MI355X-native batched quadrotor environment (libqenv.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference has no
+ * FFI layer: the path sits behind the duck-typed Python class `quad`
+ * (/root/reference/environment/quadrotor_env.py:111-577) and a handful of controller /
+ * PPO helpers.  Each entry point below names the reference interface it replaces.
+ * The Python host wrapper (autonomous_quadrotor_environment_amd/) binds these symbols
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - No torch types, no C++ types: plain pointers, sizes and enums.
+ *  - All array arguments are DEVICE pointers (HBM) in structure-of-arrays layout:
+ *    a "[R][N]" array holds R rows of N contiguous elements (row r, env e at r*N+e),
+ *    element type = the handle's dtype (float for QENV_F32, double for QENV_F64)
+ *    unless stated otherwise.  Pointers documented "nullable" may be NULL.
+ *  - The caller owns every buffer it passes in, including the workspace; getters
+ *    return pointers INTO the workspace (valid for the handle's lifetime).
+ *  - Every call enqueues work on the handle's HIP stream (qenv_set_stream) and
+ *    returns without synchronising; nothing allocates or frees device memory, so
+ *    call sequences can be captured into a hipGraph.
+ *  - Return value: 0 = ok, negative = error (see qenv_status); no exceptions cross
+ *    the ABI.  qenv_last_error() gives a thread-local message.
+ *  - One handle per GPU shard; calls on one handle must be serialised by the caller.
+ */
+#ifndef QENV_H
+#define QENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QENV_ABI_VERSION 1
+
+typedef struct qenv_s *qenv_t;
+
+typedef enum {
+    QENV_OK = 0,
+    QENV_ERR_ARG = -1,      /* bad argument (null, size, enum out of range)        */
+    QENV_ERR_WORKSPACE = -2,/* workspace too small or misaligned                   */
+    QENV_ERR_HIP = -3,      /* a HIP runtime call failed (message has the detail)  */
+    QENV_ERR_STATE = -4     /* call not valid in the handle's configuration        */
+} qenv_status;
+
+typedef enum { QENV_F32 = 0, QENV_F64 = 1 } qenv_dtype;
+
+/* quadrotor_env.py (MAIN) vs quadrotor_env_opt.py (OPT) dynamics/reward variant */
+typedef enum { QENV_MAIN = 0, QENV_OPT = 1 } qenv_variant;
+
+/* QENV_RK45: scipy.integrate.solve_ivp defaults restarted every step (adaptive
+ * Dormand-Prince 5(4), rtol 1e-3, atol 1e-6) = the reference's behaviour
+ * (quadrotor_env.py:483).  QENV_DP5: one fixed DP5 step of t_step.  QENV_RK4: classic
+ * RK4 (labelled option; BASELINE.json's wording). */
+typedef enum { QENV_RK45 = 0, QENV_DP5 = 1, QENV_RK4 = 2 } qenv_integrator;
+
+/* On-device inner-loop controllers for qenv_rollout */
+typedef enum {
+    QENV_CTRL_CONST = 0, /* one constant action for every env and step              */
+    QENV_CTRL_LQR = 1,   /* environment/controller/lqr_quad.py:128-154              */
+    QENV_CTRL_PID = 2    /* environment/controller/pid_vel_control.py:29-127        */
+} qenv_controller;
+
+/* Rows of the per-env workspace exposed through qenv_field (the attributes callers of
+ * `quad` read after step(): quadrotor_env.py:485-498). */
+typedef enum {
+    QENV_FIELD_STATE = 0,          /* [13][N]  state == previous_state               */
+    QENV_FIELD_ANG = 1,            /* [3][N]   Euler angles phi,theta,psi            */
+    QENV_FIELD_PREV_ANG = 2,       /* [3][N]                                         */
+    QENV_FIELD_ANG_VEL = 3,        /* [3][N]   finite-difference Euler rates         */
+    QENV_FIELD_VQ = 4,             /* [4][N]   quaternion rate of the last RHS call  */
+    QENV_FIELD_W = 5,              /* [4][N]   rotor speeds                          */
+    QENV_FIELD_STEP_EFFORT = 6,    /* [4][N]                                         */
+    QENV_FIELD_CLIPPED_ACTION = 7, /* [4][N]                                         */
+    QENV_FIELD_ACCEL = 8,          /* [3][N]   inertial accel of the last RHS call   */
+    QENV_FIELD_PREV_SHAPING = 9,   /* [1][N]                                         */
+    QENV_FIELD_REWARD = 10,        /* [1][N]                                         */
+    QENV_FIELD_ABS_SUM = 11,       /* [1][N]   control-effort accumulator            */
+    QENV_FIELD_EP_RETURN = 12,     /* [1][N]   sum of rewards since reset            */
+    QENV_FIELD_PID = 13,           /* [15][N]  ix[6], x_old[6], ang_d_ant[3]         */
+    QENV_FIELD_I = 14,             /* [1][N]   int32 step counter                    */
+    QENV_FIELD_FLAGS = 15,         /* [1][N]   int32 bit0 done, bit1 solved,
+                                               bit2 prev_shaping valid              */
+    QENV_FIELD_WINDOW = 16,        /* [15*T][N] float32 observation ring (row block
+                                               s = slice written at push s mod T)   */
+    QENV_FIELD_COUNT_ = 17
+} qenv_field_id;
+
+#define QENV_FLAG_DONE 1
+#define QENV_FLAG_SOLVED 2
+#define QENV_FLAG_HAS_SHAPING 4
+
+/* qenv_step flags */
+#define QENV_STEP_FULL 0          /* obs + Euler + done + reward + effort (quad.step)     */
+#define QENV_STEP_DYNAMICS_ONLY 1 /* integrate state only (BASELINE config 2)             */
+#define QENV_STEP_NO_AUX 2        /* FULL but skip the attribute rows nobody reads in
+                                     batched rollouts (w, effort, clipped_action, accel,
+                                     ang_vel) -- 224 B/env-step of SURVEY.md section 8d   */
+
+/* quad.__init__(t_step, n, training, euler, direct_control, T, clipped),
+ * quadrotor_env.py:112-187 (euler is unused by the reference as well). */
+typedef struct {
+    int64_t n_envs;
+    double t_step;
+    int32_t n_max;          /* `n`; the handle adds T like the reference (:157)        */
+    int32_t T;              /* warm-up steps in reset / observation window length      */
+    int32_t training;       /* truthy -> solved sets done (:565); OPT: PPO_TRAINING    */
+    int32_t direct_control; /* 1: action = 4 rotor commands in [-1,1]; 0: [F,Mx,My,Mz] */
+    int32_t clipped;        /* f2w clipping (:218)                                     */
+    int32_t variant;        /* qenv_variant                                            */
+    int32_t integrator;     /* qenv_integrator                                         */
+    int32_t dtype;          /* qenv_dtype                                              */
+} qenv_config;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+int qenv_abi_version(void);
+const char *qenv_last_error(void);
+
+/* Bytes of device memory the handle needs for n_envs (256-byte aligned base). */
+size_t qenv_workspace_bytes(const qenv_config *cfg);
+
+/* Replaces quad.__init__ (quadrotor_env.py:112).  `workspace` is caller-allocated
+ * device memory of at least qenv_workspace_bytes(cfg); it is zeroed on `stream`. */
+int qenv_create(const qenv_config *cfg, void *workspace, size_t workspace_bytes, void *stream,
+                qenv_t *out);
+int qenv_destroy(qenv_t q);
+int qenv_set_stream(qenv_t q, void *stream); /* hipStream_t */
+
+/* Device pointer of a workspace row block + its row count (quad attributes). */
+int qenv_field(qenv_t q, int field_id, void **dev_ptr, int32_t *rows);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+
+/* Replaces quad.reset(det_state) (quadrotor_env.py:408-454): loads the initial
+ * 13-states, clears counters/flags/prev_shaping/abs_sum (NOT prev_ang, :172), then runs
+ * the T warm-up steps with zero_control.
+ *   init_states [13][N]: explicit states (det_state, or the host-side replay of the
+ *                        reference's RNG draw order for the random branch)
+ *   mask        nullable uint8 [N]: reset only envs with mask != 0
+ *   out_states  nullable [T][14][N], out_actions nullable [T][4][N]            */
+int qenv_reset(qenv_t q, const void *init_states, const uint8_t *mask, void *out_states,
+               void *out_actions);
+
+/* Replaces quad.step(action) (quadrotor_env.py:458-498) for all N envs.
+ *   actions    [4][N], nullable = zero_control for every env
+ *   out_obs    nullable [14][N]  quat_state = [state[0:10], V_q]
+ *   out_reward nullable [N];  out_done nullable uint8 [N]
+ *   flags      QENV_STEP_*                                                       */
+int qenv_step(qenv_t q, const void *actions, void *out_obs, void *out_reward, uint8_t *out_done,
+              int flags);
+
+/* n_steps fused steps in ONE launch with the controller evaluated on device and the
+ * state held in registers between steps -- the loop bodies of lqr_quad.py:123-168 and
+ * pid_vel_control.py:141-164 (both ignore `done` and keep stepping), or a constant
+ * action.  const_action: HOST pointer to 4 doubles (CONST only, nullable =
+ * zero_control).  pid_first_action: PID only, nonzero = the first step uses
+ * [M*G,0,0,0] like pid_vel_control.py:146.  Rewards are summed into EP_RETURN.
+ * flags: QENV_STEP_* (DYNAMICS_ONLY skips Euler/done/reward, CONST only). */
+int qenv_rollout(qenv_t q, int controller, int n_steps, const double *const_action,
+                 int pid_first_action, int flags);
+
+/* Stand-alone controller laws writing actions [4][N] from the workspace rows
+ * (state, ang, ang_vel) -- for callers that interleave them with qenv_step.
+ * LQR: lqr_quad.py:128-154.  PID: pid_control.control(xd, 0, psd, 0),
+ * pid_vel_control.py:98-110; targets: HOST pointer to 4 doubles {vx,vy,vz,psi}
+ * (nullable = zeros); updates the PID rows of the workspace. */
+int qenv_lqr_action(qenv_t q, void *out_actions);
+int qenv_pid_action(qenv_t q, const double *targets, void *out_actions);
+int qenv_pid_reset(qenv_t q, const uint8_t *mask); /* new pid_control(), :144 */
+
+/* ---- PPO inner loop ------------------------------------------------------------------ */
+
+/* Replaces dl_in_gen.dl_input (environment/controller/dl_auxiliary.py:25-32): append
+ * one slice [action(4), vel(3), q(4), q_dot(4)] built from obs [14][N] and actions
+ * [4][N] to each env's T-slice float32 ring.  reset_first != 0 zeroes the ring first
+ * (dl_in_gen.reset). */
+int qenv_window_push(qenv_t q, const void *obs, const void *actions, int reset_first);
+
+/* Replaces ActorCritic.actor / .critic forward (environment/controller/model.py:27-42):
+ * y = [tanh](W3 tanh(W2 tanh(W1 x + b1) + b2) + b3) on the observation ring, fp32
+ * MFMA.  Weights: float32 device, row-major [out][in] exactly as torch's nn.Linear
+ * (W1 [H][15*T], W2 [H][H], W3 [n_out][H]); H in {16,32,64,128,256}; n_out <= 4.
+ * out [n_out][N] in the handle's dtype. */
+int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const float *W1,
+                     const float *b1, const float *W2, const float *b2, const float *W3,
+                     const float *b3, void *out);
+
+/* Replaces PPO.get_advantages (environment/controller/ppo.py:125-141, ddof=0;
+ * visual_landing/ppo_trainer.py:133-148, ddof=1) on a time-major rollout:
+ *   values [n_steps+1][N], masks [n_steps][N] (1 - terminal), rewards [n_steps][N]
+ *   -> returns [n_steps][N], adv [n_steps][N] (un-normalised: returns - values)
+ *   -> stats: device double[3] = {count, sum(adv), sum(adv^2)} accumulated (caller
+ *      zeroes it; all-reduce it across shards before qenv_adv_normalize).
+ * Independent of any handle; n_envs envs scanned in parallel along time. */
+int qenv_gae(int dtype, int64_t n_envs, int n_steps, const void *values, const void *masks,
+             const void *rewards, void *returns, void *adv, double *stats, void *stream);
+int qenv_adv_normalize(int dtype, int64_t n_elems, void *adv, const double *stats, int ddof,
+                       void *stream);
+
+/* Replaces visual_reward (visual_landing/rl_reward_fuction.py:3-102), batched.
+ * marker,pos,vel,control,ang,v_ang [3][N]; last_shaping [N] (0 = none, like the
+ * reference's truthiness test); step int32 [N]; outputs reward, shaping [N],
+ * done uint8 [N], n_solved int32 [N]. */
+int qenv_visual_reward(int dtype, int64_t n_envs, int total_steps, const void *marker,
+                       const void *pos, const void *vel, const void *control,
+                       const void *last_shaping, const int32_t *step, const void *ang,
+                       const void *v_ang, void *out_reward, void *out_shaping, uint8_t *out_done,
+                       int32_t *out_solved, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QENV_H */

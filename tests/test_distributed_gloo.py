@@ -1,0 +1,52 @@
+"""CPU, world_size 2, gloo: the N>1 path's host logic -- env-range sharding and the all-gather
+of per-env episode returns (even and ragged shards) -- plus the 3-scalar moment all-reduce that
+keeps GAE's advantage normalisation identical to a single learner."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from .conftest import ROOT
+
+
+def _worker(rank, world, port, n_global, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autonomous_quadrotor_environment_amd.distributed import all_gather_returns, shard_range
+    from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+    lo, hi = shard_range(n_global, rank, world)
+    # a per-env quantity that is a pure function of the global env index and the seeded init state
+    x0 = fast_random_init_states(9, n_global, lo, hi)
+    local = torch.from_numpy(x0[:, 1] + np.arange(lo, hi))
+    full = all_gather_returns(local, n_global)
+    # global advantage moments: sum of per-shard {count, sum, sumsq}
+    stats = torch.tensor([hi - lo, float(local.sum()), float((local ** 2).sum())], dtype=torch.float64)
+    dist.all_reduce(stats)
+    q.put((rank, full.numpy(), stats.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global", [4096, 1001])
+def test_all_gather_returns_world2(n_global):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (n_global % 17)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+    want = fast_random_init_states(9, n_global)[:, 1] + np.arange(n_global)
+    for rank, full, stats in res:
+        assert np.array_equal(full, want), rank
+        assert stats[0] == n_global and abs(stats[1] - want.sum()) < 1e-6 and abs(stats[2] - (want ** 2).sum()) < 1e-3

@@ -1,0 +1,338 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the Python host wrapper) against
+the golden vectors of the reference and against the fp64 CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star: "within 1e-5 rel fp32"):
+  fp64 handle : 1e-9 relative (same algorithm, different operation order / libm)
+  fp32 handle : 1e-5 relative with the 1e-3 absolute floor of SURVEY.md App. C E3 for one-step
+                (teacher-forced) checks; closed-loop tolerances are stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "f64": torch.float64}
+ONE_STEP_TOL = {"f32": 1e-5, "f64": 1e-9}
+
+
+@pytest.fixture(scope="module")
+def aq():
+    import autonomous_quadrotor_environment_amd as aq
+    assert torch.cuda.is_available()
+    return aq
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+def _dev(x, dt):
+    return torch.from_numpy(np.ascontiguousarray(x)).to("cuda", DT[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("name,kw", [
+    ("g4_step_direct", dict(direct_control=1)),
+    ("g4_step_indirect", dict(direct_control=0)),
+    ("g4_step_indirect_unclipped", dict(direct_control=0, clipped=False)),
+    ("g4_step_direct_eval", dict(direct_control=1, training=False)),
+    ("g13_step_opt_direct", dict(direct_control=1, variant="opt", training=False)),
+    ("g13_step_opt_indirect", dict(direct_control=0, variant="opt", training=False)),
+])
+def test_reset_then_step_golden(aq, name, kw, dt):
+    """G4/G13: reset(det_state) + step(action) for every fixture sample as ONE batch."""
+    g = golden(name)
+    n = len(g["x0"])
+    env = aq.BatchedQuad(n, 0.01, 1000, T=1, dtype=DT[dt], **kw)
+    tol = ONE_STEP_TOL[dt]
+    states, actions = env.reset(_dev(g["x0"].T, dt))
+    assert states.shape == (1, 14, n) and actions.shape == (1, 4, n)
+    for pre in ("r_", "s_"):
+        if pre == "s_":
+            obs, rew, done = env.step(_dev(g["action"].T, dt))
+            assert rel_err(_np(obs).T, g["s_quat_state"]) < tol
+            assert np.max(np.abs(_np(rew) - g["s_reward"])) < (1e-8 if dt == "f64" else 2e-3)
+        else:
+            assert rel_err(_np(states[0]).T, g["r_quat_state"]) < tol
+        assert rel_err(_np(env.state).T, g[pre + "state"]) < tol, (name, pre)
+        assert rel_err(_np(env.quat_state).T, g[pre + "quat_state"]) < tol
+        assert rel_err(_np(env.ang).T, g[pre + "ang"]) < tol
+        # finite-difference Euler rates amplify the angle rounding by 1/t_step
+        assert rel_err(_np(env.ang_vel).T, g[pre + "ang_vel"], 1.0) < tol * 100
+        ok = np.abs(_np(env.reward) - g[pre + "reward"]) < (1e-8 if dt == "f64" else 2e-3)
+        done_ok = _np(env.done.to(torch.float32)) == g[pre + "done"]
+        solved_ok = _np(env.solved) == g[pre + "solved"]
+        if dt == "f64":
+            assert ok.all() and done_ok.all() and solved_ok.all()
+        else:  # a bound sitting within fp32 rounding of the threshold may flip a branch
+            assert (ok & done_ok & solved_ok).mean() > 0.99
+        assert np.array_equal(_np(env.i), g[pre + "i"])
+        assert rel_err(_np(env.step_effort).T, g[pre + "step_effort"]) < tol * 10
+        assert rel_err(_np(env.clipped_action).T, g[pre + "clipped_action"]) < tol * 10
+        assert rel_err(_np(env.abs_sum), g[pre + "abs_sum"]) < tol * 10
+        if not kw["direct_control"] or pre == "s_":
+            assert rel_err(_np(env.w).T, g[pre + "w"], 1.0) < tol * 10
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("integrator", ["rk45", "dp5", "rk4"])
+def test_multi_step_vs_oracle(aq, oracle, dt, integrator):
+    """4096 random envs x 8 random-action steps, teacher-forced actions, vs the oracle run with
+    the SAME integrator on a 128-env subsample."""
+    n, steps = 4096, 8
+    x0 = oracle.random_init_states(21, n)
+    rng = np.random.RandomState(22)
+    acts = np.clip(rng.normal(0, 0.5, (steps, n, 4)), -1.2, 1.2)
+    env = aq.BatchedQuad(n, 0.01, 1000, training=False, direct_control=1, T=1, integrator=integrator, dtype=DT[dt])
+    env.reset(_dev(x0.T, dt))
+    rews = []
+    for k in range(steps):
+        _, r, _ = env.step(_dev(acts[k].T, dt))
+        rews.append(_np(r))
+    got = _np(env.state).T
+    got_ang = _np(env.ang).T
+    worst = 0.0
+    for e in range(0, n, 32):
+        ref = oracle.OracleQuad(0.01, 1000, training=False, direct_control=1, T=1, integrator=integrator)
+        ref.reset(x0[e])
+        for k in range(steps):
+            ref.step(acts[k, e])
+            assert abs(rews[k][e] - ref.reward) < (1e-8 if dt == "f64" else 5e-3)
+        worst = max(worst, rel_err(got[e], ref.state), rel_err(got_ang[e], ref.ang))
+    assert worst < (2e-9 if dt == "f64" else 2e-5), worst
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_integrators_agree_with_reference_step(aq, dt):
+    """fixed DP5 stays within ~1.3e-7 and RK4 within ~6e-6 of the reference's
+    adaptive RK45 per step (golden G4 state after reset+step)."""
+    g = golden("g4_step_direct")
+    n = len(g["x0"])
+    for integ, tol in (("dp5", 5e-7), ("rk4", 1e-5)):
+        env = aq.BatchedQuad(n, 0.01, 1000, T=1, direct_control=1, integrator=integ, dtype=DT[dt])
+        env.reset(_dev(g["x0"].T, dt))
+        env.step(_dev(g["action"].T, dt))
+        assert rel_err(_np(env.state).T, g["s_state"]) < tol + (1e-5 if dt == "f32" else 0)
+
+
+def _traj_err(rows, ref):
+    return rel_err(rows[:, :13], ref[:, :13]), rel_err(rows[:, 13:16], ref[:, 13:16])
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-7), ("f32", 2e-3)])
+def test_lqr_closed_loop_golden(aq, dt, tol):
+    """G6 LQR (lqr_quad.py loop), 4 seeds as one batch of 4 envs, 500 steps, step-by-step
+    controller kernel + env step; then the same run as ONE fused rollout launch."""
+    gs = [golden(f"g6_lqr_seed{s}") for s in (1, 2, 3, 4)]
+    x0 = np.stack([g["x0"] for g in gs], 1)
+    env = aq.BatchedQuad(4, 0.01, 500, training=True, direct_control=0, T=1, dtype=DT[dt])
+    env.reset(_dev(x0, dt))
+    ctl = aq.LqrController(env)
+    rows = [[] for _ in range(4)]
+    for k in range(500):
+        a = ctl.control()
+        env.step(a)
+        st, an, av = _np(env.state), _np(env.ang), _np(env.ang_vel)
+        for e in range(4):
+            rows[e].append(np.concatenate([st[:, e], an[:, e], av[:, e]]))
+    for e in range(4):
+        es, ea = _traj_err(np.array(rows[e]), gs[e]["traj"])
+        assert es < tol and ea < tol * 10, (e, es, ea)
+    env2 = aq.BatchedQuad(4, 0.01, 500, training=True, direct_control=0, T=1, dtype=DT[dt])
+    env2.reset(_dev(x0, dt))
+    env2.rollout("lqr", 500)
+    assert torch.equal(env2.state, env.state), "fused rollout must equal the step-by-step loop bit for bit"
+    assert torch.equal(env2.flags, env.flags) and torch.equal(env2.i, env.i)
+    assert torch.allclose(env2.episode_return, env.episode_return, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-7), ("f32", 5e-3)])
+def test_pid_config1_golden(aq, dt, tol):
+    """BASELINE config 1: PID, seed 1, 1000 steps (pid_vel_control.py:131-164)."""
+    g = golden("g6_pid_seed1")
+    env = aq.BatchedQuad(1, 0.01, 1000, training=True, direct_control=0, T=5, clipped=True, dtype=DT[dt])
+    env.reset(_dev(g["x0"].reshape(13, 1), dt))
+    ctl = aq.PidController(env)
+    action = _dev(np.array([[9.82 * 1.03, 0, 0, 0]]).T, dt)
+    rows = []
+    for k in range(1000):
+        env.step(action)
+        action = ctl.control((0, 0, 0), (0, 0, 0), 0, 0)
+        rows.append(np.concatenate([_np(env.state)[:, 0], _np(env.ang)[:, 0]]))
+    rows = np.array(rows)
+    assert rel_err(rows[:, :13], g["traj"][:, :13]) < tol
+    assert bool(env.solved[0]) == bool(g["traj"][-1, 25])
+    env2 = aq.BatchedQuad(1, 0.01, 1000, training=True, direct_control=0, T=5, clipped=True, dtype=DT[dt])
+    env2.reset(_dev(g["x0"].reshape(13, 1), dt))
+    env2.pid_reset()
+    env2.rollout("pid", 1000, pid_first_action=True)
+    assert torch.equal(env2.state, env.state)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["g6_hover", "g6_hover_perturbed"])
+def test_hover_golden(aq, dt, name):
+    """Config 2 single-env slice: zero action from (perturbed) hover, 1000 steps."""
+    g = golden(name)
+    env = aq.BatchedQuad(64, 0.01, 2000, training=False, direct_control=1, T=1, dtype=DT[dt])
+    env.reset(_dev(np.repeat(g["x0"][:, None], 64, 1), dt))
+    for k in range(1000):
+        env.step(None, flags=1)
+    st = _np(env.state)
+    assert np.all(st == st[:, :1]), "identical envs must produce identical lanes"
+    assert rel_err(st[:, 0], g["traj"][-1, :13]) < (1e-8 if dt == "f64" else 5e-4)
+    env2 = aq.BatchedQuad(64, 0.01, 2000, training=False, direct_control=1, T=1, dtype=DT[dt])
+    env2.reset(_dev(np.repeat(g["x0"][:, None], 64, 1), dt))
+    env2.rollout("const", 1000, flags=1)
+    assert torch.equal(env2.state, env.state)
+
+
+def test_quad_dropin_pid_config1(aq):
+    """The reference-shaped single-env class driven exactly like pid_vel_control.py:131-164."""
+    g = golden("g6_pid_seed1")
+    drone = aq.quad(0.01, 1000, training=True, euler=0, direct_control=0, T=5, clipped=True)
+    drone.seed(1)
+    state, action = drone.reset()
+    assert state.shape == (5, 14) and action.shape == (5, 4)
+    controller = aq.pid_control(drone)
+    action = np.array([9.82 * 1.03, 0, 0, 0])
+    rows = []
+    for j in range(1000):
+        obs, rew, done = drone.step(action)
+        assert obs.shape == (1, 14) and isinstance(rew, float) and isinstance(done, bool)
+        action = controller.control(np.array([0, 0, 0]), np.zeros(3), 0, 0)
+        rows.append(np.concatenate((drone.state, drone.ang, drone.ang_vel, drone.step_effort)))
+    rows = np.array(rows)
+    assert rel_err(rows[:, :13], g["traj"][:, :13]) < 1e-7
+    assert rel_err(rows[:, 19:23], g["traj"][:, 19:23]) < 1e-6
+    assert drone.solved == int(g["traj"][-1, 25]) and drone.i == 1005
+
+
+def test_quad_dropin_reset_seeded(aq):
+    g = golden("g5_reset")
+    for direct in (1, 0):
+        for T in (1, 5):
+            env = aq.quad(0.01, 1000, training=True, euler=0, direct_control=direct, T=T)
+            for seed in (0, 5, 11):
+                env.seed(seed)
+                s, a = env.reset()
+                assert rel_err(s, g[f"states_d{direct}_T{T}"][seed]) < 1e-9
+                assert np.array_equal(a, g[f"actions_d{direct}_T{T}"][seed])
+
+
+def test_mlp_forward_golden(aq):
+    """G9: actor / critic forward for N in {16, 128}: obs rows pushed through the ring."""
+    for N in (16, 128):
+        g = golden(f"g9_mlp_N{N}")
+        w = aq.ActorCriticWeights.from_state_dict({k: g[k] for k in g.files if k.startswith(("actor", "critic"))})
+        obs = g["obs"]  # [256, 75] = 5 slices of 15
+        env = aq.BatchedQuad(256, 0.01, 1000, direct_control=1, T=5)
+        for j in range(5):
+            env.window[15 * j:15 * (j + 1)].copy_(torch.from_numpy(obs[:, 15 * j:15 * (j + 1)].T.copy()))
+        mean = _np(env.mlp_forward(w, "actor")).T
+        val = _np(env.mlp_forward(w, "critic")).T
+        assert mean.shape == (256, 4) and val.shape == (256, 1)
+        assert np.max(np.abs(mean - g["mean64"])) < 2e-6
+        assert rel_err(val, g["value64"], 1.0) < 5e-6
+
+
+def test_ppo_actor_in_loop_golden(aq):
+    """G6 PPO: ppo_quad_eval.py:44-62 with the N=128 weights, 4 seeds as one batch."""
+    gs = [golden(f"g6_ppo128_seed{s}") for s in (1, 2, 3, 4)]
+    wg = golden("g9_mlp_N128")
+    w = aq.ActorCriticWeights.from_state_dict({k: wg[k] for k in wg.files if k.startswith(("actor", "critic"))})
+    x0 = np.stack([g["x0"] for g in gs], 1)
+    env = aq.BatchedQuad(4, 0.01, 500, training=False, direct_control=1, T=5)
+    ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None), horizon=500)
+    ro.start(torch.from_numpy(x0))
+    rows = [[] for _ in range(4)]
+    for k in range(500):
+        ro.step(deterministic=True)
+        st = _np(env.state)
+        for e in range(4):
+            rows[e].append(st[:, e])
+    for e in range(4):
+        assert np.max(np.abs(_np(ro.actions[:, :, e]) - gs[e]["actions"])) < 5e-3
+        assert rel_err(np.array(rows[e]), gs[e]["traj"][:, :13]) < 5e-3
+        assert bool(env.solved[e]) == bool(gs[e]["traj"][-1, 25])
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_gae_golden(aq, dt):
+    g = golden("g10_gae")
+    for n in (12, 1000):
+        v = _dev(np.repeat(g[f"values_{n}"][:, None], 3, 1), dt)
+        m = _dev(np.repeat(g[f"masks_{n}"][:, None], 3, 1), dt)
+        r = _dev(np.repeat(g[f"rewards_{n}"][:, None], 3, 1), dt)
+        ret, adv = aq.gae(v, m, r, ddof=0, group=False)
+        tol = 1e-9 if dt == "f64" else 2e-5
+        assert rel_err(_np(ret)[:, 1], g[f"ret_ppo_{n}"], 1.0) < tol
+        # three identical envs: mean is unchanged; ddof=0 std is unchanged too
+        assert rel_err(_np(adv)[:, 2], g[f"adv_ppo_{n}"], 1.0) < tol * 10
+        ret1, adv1 = aq.gae(v[:, :1], m[:, :1], r[:, :1], ddof=1, group=False)
+        assert rel_err(_np(adv1)[:, 0], g[f"adv_trainer_{n}"], 1.0) < 2e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_visual_reward_golden(aq, dt):
+    rows = golden("g11_visual_reward")["rows"]
+    last = np.nan_to_num(rows[:, 12], nan=0.0)
+    t = lambda a: _dev(a.T, dt)
+    rew, sh, done, ns = aq.visual_reward(500, t(rows[:, 0:3]), t(rows[:, 3:6]), t(rows[:, 6:9]), t(rows[:, 9:12]),
+                                         _dev(last, dt), torch.from_numpy(rows[:, 13].astype(np.int32)).cuda(),
+                                         t(rows[:, 14:17]), t(rows[:, 17:20]))
+    tol = 1e-10 if dt == "f64" else 2e-4
+    agree = (np.abs(_np(rew) - rows[:, 20]) < tol) & (_np(done.float()) == rows[:, 22]) & (_np(ns) == rows[:, 23])
+    assert agree.all() if dt == "f64" else agree.mean() > 0.98
+    assert np.max(np.abs(_np(sh) - rows[:, 21])) < (1e-10 if dt == "f64" else 1e-4)
+
+
+# ---- full-size (BASELINE config) property tests ------------------------------------------------
+def test_full_size_properties_config2(aq):
+    """65 536 envs, zero action, dynamics only (config 2): determinism, lane independence
+    (a permuted batch gives the permuted result), shard invariance (two half batches equal the
+    whole), quaternion norm drift, and equality of the fused rollout with repeated steps."""
+    n = 65536
+    from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+    x0 = fast_random_init_states(3, n)
+    x0[:, 1:6:2] *= 0.05; x0[:, 10:13] *= 0.05  # perturbed hover
+    x0_t = torch.from_numpy(x0.T.copy())
+
+    def run(xt, steps=50, fused=False):
+        env = aq.BatchedQuad(xt.shape[1], 0.01, 5000, training=False, direct_control=1, T=1)
+        env.reset(xt)
+        if fused:
+            env.rollout("const", steps, flags=1)
+        else:
+            for _ in range(steps):
+                env.step(None, flags=1)
+        return env.state.clone()
+
+    a = run(x0_t)
+    assert torch.equal(a, run(x0_t)), "same inputs must give bit-identical outputs"
+    assert torch.equal(a, run(x0_t, fused=True))
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    assert torch.equal(a[:, perm.cuda()], run(x0_t[:, perm]))
+    half = torch.cat([run(x0_t[:, :n // 2].contiguous()), run(x0_t[:, n // 2:].contiguous())], 1)
+    assert torch.equal(a, half), "sharding the env range must not change any env's result"
+    qn = torch.linalg.norm(a[6:10].double(), dim=0)
+    assert float((qn - 1).abs().max()) < 1e-4
+    assert bool(torch.isfinite(a).all())
+
+
+def test_full_size_lqr_config3_settles(aq):
+    """262 144 envs, LQR inner loop, random init (config 3): acceptance criterion of
+    classical_controller_results/results_analyzer.py:23-27 (|v| < 0.05 m/s at the end)."""
+    n = 262144
+    from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+    x0 = fast_random_init_states(3, n)
+    env = aq.BatchedQuad(n, 0.01, 500, training=True, direct_control=0, T=1, integrator="rk45")
+    env.reset(torch.from_numpy(x0.T.copy()))
+    env.rollout("lqr", 500)
+    v = torch.linalg.norm(env.state[1:6:2], dim=0)
+    frac = float((v < 0.05).float().mean())
+    assert frac > 0.97, frac
+    assert int(env.i.min()) == 501 and int(env.i.max()) == 501
