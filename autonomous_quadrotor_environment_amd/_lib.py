@@ -55,7 +55,8 @@ SYMBOLS = {
     "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adv_normalize": (_i, [_i, _i64, _vp, _vp, _i, _vp]),
-    "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 14),
+    "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 13),
+    "qenv_debug_copy_rows": (_i, [_i, _vp, _vp, _i, _i64, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -91,7 +91,7 @@ template <typename T> struct Act {
 template <typename T>
 __device__ __forceinline__ void mix_direct(const T a[4], T w[4], Act<T>& u) {
     using m = Mth<T>;
-    const T c = T(phys::T2WR * phys::M * phys::G / 8.0);
+    const T c = T(phys::M * phys::G) * T(phys::T2WR / 8.0);  // fl(M G)/4: four hover rotors sum to fl(M G) exactly
     T f[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -159,7 +159,9 @@ __device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, T cm_xy, T c
     // inertial acceleration
     const T ax = (r00 * fbx + r01 * fby + r02 * fbz) * T(1.0 / phys::M);
     const T ay = (r10 * fbx + r11 * fby + r12 * fbz) * T(1.0 / phys::M);
-    const T az = (r20 * fbx + r21 * fby + r22 * fbz) * T(1.0 / phys::M) - T(phys::G);
+    // (f_z - M G)/M instead of f_z/M - G: the same number, but the weight cancels before the
+    // scaling, so an exact hover (f_z == fl(M G)) has az == 0 exactly in fp32 as well
+    const T az = ((r20 * fbx + r21 * fby + r22 * fbz) - T(phys::M * phys::G)) * T(1.0 / phys::M);
     // moments: action + gyro (sic: x uses -wx, y uses +wy, :347-349) + drag - w x (J w)
     const T mx = u.Mx - wx * u.omr - cm_xy * (m::abs(wx) * wx) - wy * wz * T(phys::JZ - phys::JY);
     const T my = u.My + wy * u.omr - cm_xy * (m::abs(wy) * wy) - wz * wx * T(phys::JX - phys::JZ);

@@ -554,4 +554,14 @@ int qenv_pid_reset(qenv_t q, const uint8_t* mask) {
     return check_launch("k_pid_reset");
 }
 
+int qenv_debug_copy_rows(int dtype, void* dst, const void* src, int rows, int64_t n_envs, void* stream) {
+    if (!dst || !src || rows <= 0 || n_envs <= 0) return fail(QENV_ERR_ARG, "qenv_debug_copy_rows: bad argument");
+    const dim3 g = grid_for(n_envs), b(256);
+    if (dtype == QENV_F64)
+        hipLaunchKernelGGL((k_copy_rows<double>), g, b, 0, (hipStream_t)stream, (double*)dst, (const double*)src, rows, n_envs);
+    else
+        hipLaunchKernelGGL((k_copy_rows<float>), g, b, 0, (hipStream_t)stream, (float*)dst, (const float*)src, rows, n_envs);
+    return check_launch("k_copy_rows");
+}
+
 }  // extern "C"

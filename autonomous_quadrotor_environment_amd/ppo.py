@@ -120,9 +120,9 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True):
                            L.ptr(stats), stream), "qenv_gae")
     if not normalize:
         return ret, adv
-    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                             and torch.distributed.get_world_size() > 1 and group is not False):
-        torch.distributed.all_reduce(stats, group=group if group not in (None, False) else None)
+    if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size(group) > 1:
+        torch.distributed.all_reduce(stats, group=group)
     L.check(L.lib.qenv_adv_normalize(dt, n * N, L.ptr(adv), L.ptr(stats), int(ddof), stream), "qenv_adv_normalize")
     return ret, adv
 

@@ -153,7 +153,7 @@ class BatchedQuad:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and L is not None and getattr(L, "lib", None) is not None:  # module globals may be gone at exit
             L.lib.qenv_destroy(h)
             self._h = None
 

@@ -129,21 +129,23 @@ def time_region(run, per_call, steps, world, dev):
     return dt
 
 
-def kernel_launch_us(env, controller, flags, launch, steps_per_launch, reps=40):
-    """Average duration of ONE launch of the dominant kernel, HIP events on the launch stream
-    (the env launches on torch's current stream, so torch.cuda.Event brackets it)."""
+def kernel_launch_us(run, per_call, launch, reps=20):
+    """Average duration of ONE launch of the dominant kernel from HIP events on the launch stream
+    (the env launches on torch's current stream, so torch.cuda.Event brackets it).  launch='fused':
+    one event pair per launch.  launch='step': the kernels are a few microseconds long, less than
+    an event pair costs, so the pair brackets one hipGraph replay of `per_call` back-to-back
+    launches and the result is divided by per_call (it therefore includes the ~0.5 us dependent
+    launch boundary, which makes `achieved` conservative)."""
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     torch.cuda.synchronize()
     for a, b in evs:
         a.record()
-        if launch == "fused":
-            env.rollout(controller, steps_per_launch, flags=flags)
-        else:
-            env.step(None, flags=flags) if controller == "const" else env.rollout(controller, 1, flags=flags)
+        run()
         b.record()
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-    return float(np.mean(ts[: max(1, len(ts) * 3 // 4)]))  # drop the slowest quarter (clock ramps, interrupts)
+    us = float(np.mean(ts[: max(1, len(ts) * 3 // 4)]))  # drop the slowest quarter (clock ramps, interrupts)
+    return us if launch == "fused" else us / per_call
 
 
 def cpu_baseline(workload, integrator, seconds):
@@ -159,8 +161,8 @@ def cpu_baseline(workload, integrator, seconds):
     t0 = time.perf_counter()
     qo.batch_rollout(x0[:64], 50, direct=direct, integrator=integrator, controller=ctrl)
     rate1 = 64 * 50 / (time.perf_counter() - t0)
-    per_thread = int(max(64, min(4096, rate1 * seconds / 200)))
-    steps = 200
+    steps = 1000
+    per_thread = int(max(64, min(4096, rate1 * seconds / steps)))
     chunks = [x0[k * per_thread:(k + 1) * per_thread] for k in range(threads)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
@@ -212,7 +214,7 @@ def main():
 
     # dominant kernel, per-launch duration by HIP events on the launch stream
     spl = chunk if args.launch == "fused" else 1
-    k_us = kernel_launch_us(env, controller, flags, args.launch, spl)
+    k_us = kernel_launch_us(run, per_call, args.launch)
     esz = 1 if args.dtype == "f32" else 2
     algo_bytes = bytes_per_step * esz * (hi - lo) * spl
     achieved = algo_bytes / (k_us * 1e-6) / 1e9

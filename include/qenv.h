@@ -209,6 +209,13 @@ int qenv_visual_reward(int dtype, int64_t n_envs, int total_steps, const void *m
                        const void *v_ang, void *out_reward, void *out_shaping, uint8_t *out_done,
                        int32_t *out_solved, void *stream);
 
+/* Measurement utility (bench.py / profiles): dst[r][e] = src[r][e] with the SAME access shape as
+ * the env kernels (one dword or qword per lane, rows N apart), so the rocprofv3 FETCH_SIZE /
+ * WRITE_SIZE counters can be calibrated on a known byte count before they are used to price the
+ * env kernels' HBM traffic (MI355X_MICROARCH.md, HBM section).  No reference counterpart. */
+int qenv_debug_copy_rows(int dtype, void *dst, const void *src, int rows, int64_t n_envs,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif
