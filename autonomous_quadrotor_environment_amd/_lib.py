@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqenv.so")
+LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
 QENV_ABI_VERSION = 1
 F32, F64 = 0, 1

@@ -32,7 +32,14 @@ template <> struct Mth<float> {
     static __device__ __forceinline__ float sin(float x) { return sinf(x); }
     static __device__ __forceinline__ float tan(float x) { return tanf(x); }
     static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
-    static __device__ __forceinline__ float ulp_up(float t) { return nextafterf(t, INFINITY) - t; }
+    // step-size control only (x > 0): v_log_f32 / v_exp_f32, ~1e-6 relative -- the factor multiplies a
+    // step size that is then clamped to the remaining interval, it never touches the state directly
+    static __device__ __forceinline__ float pow_ctl(float x, float y) {
+        return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    }
+    static __device__ __forceinline__ float div_ctl(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    // nextafter(t, +inf) - t for finite t >= 0
+    static __device__ __forceinline__ float ulp_up(float t) { return __uint_as_float(__float_as_uint(t) + 1u) - t; }
 };
 template <> struct Mth<double> {
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
@@ -47,6 +54,8 @@ template <> struct Mth<double> {
     static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
     static __device__ __forceinline__ double tan(double x) { return ::tan(x); }
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double pow_ctl(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double div_ctl(double a, double b) { return a / b; }
     static __device__ __forceinline__ double ulp_up(double t) { return nextafter(t, (double)INFINITY) - t; }
 };
 
@@ -194,7 +203,7 @@ constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 
 // error norm of scipy's _estimate_error_norm (rk.py:108-109,143-144) if WITH_ERR.
 template <typename T, bool WITH_ERR>
 __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T>& u, T cm_xy, T cm_z, T h,
-                                      T yn[13], T k7[13]) {
+                                      T yn[13], T k7[13], T inc[13]) {
     using m = Mth<T>;
     T k2[13], k3[13], k4[13], k5[13], k6[13], ys[13];
 #pragma unroll
@@ -216,9 +225,11 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
                             T(dp::A65) * k5[i]);
     rhs(ys, u, cm_xy, cm_z, k6);
 #pragma unroll
-    for (int i = 0; i < 13; ++i)
-        yn[i] = y[i] + h * (T(dp::B1) * k1[i] + T(dp::B3) * k3[i] + T(dp::B4) * k4[i] + T(dp::B5) * k5[i] +
-                            T(dp::B6) * k6[i]);
+    for (int i = 0; i < 13; ++i) {
+        const T sum = T(dp::B1) * k1[i] + T(dp::B3) * k3[i] + T(dp::B4) * k4[i] + T(dp::B5) * k5[i] + T(dp::B6) * k6[i];
+        inc[i] = h * sum;
+        yn[i] = y[i] + h * sum;  // one fma: a single rounding of the new state
+    }
     rhs(yn, u, cm_xy, cm_z, k7);
     T err2 = T(0);
     if (WITH_ERR) {
@@ -241,10 +252,12 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
 // (FSAL) whose rows 6..9 are the reference's V_q.  Every lane leaves the loop after at
 // most MAX_ATTEMPTS attempts.
 template <typename T>
-__device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13]) {
+__device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13]) {
     using m = Mth<T>;
     constexpr int MAX_ATTEMPTS = 96;
     T k1[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) dy[i] = T(0);
     rhs(y, u, cm_xy, cm_z, k1);
     T h_abs;
     {
@@ -258,7 +271,7 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
             d1 += b * b;
         }
         d0 = m::sqrt(d0 * T(1.0 / 13)); d1 = m::sqrt(d1 * T(1.0 / 13));
-        T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : T(0.01) * d0 / d1;
+        T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : m::div_ctl(T(0.01) * d0, d1);
         h0 = m::min(h0, tb);
         T y1[13], f1[13];
 #pragma unroll
@@ -270,10 +283,10 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
             const T a = (f1[i] - k1[i]) * isc[i];
             d2 += a * a;
         }
-        d2 = m::sqrt(d2 * T(1.0 / 13)) / h0;
+        d2 = m::div_ctl(m::sqrt(d2 * T(1.0 / 13)), h0);
         T h1;
         if (d1 <= T(1e-15) && d2 <= T(1e-15)) h1 = m::max(T(1e-6), h0 * T(1e-3));
-        else h1 = m::pow(T(0.01) / m::max(d1, d2), T(0.2));
+        else h1 = m::pow_ctl(m::div_ctl(T(0.01), m::max(d1, d2)), T(0.2));
         h_abs = m::min(m::min(T(100) * h0, h1), tb);
     }
     T t = T(0);
@@ -286,19 +299,19 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
         if (t_new > tb) t_new = tb;
         const T h = t_new - t;
         h_abs = h;
-        T yn[13], k7[13];
-        const T err2 = dp5_step<T, true>(y, k1, u, cm_xy, cm_z, h, yn, k7);
+        T yn[13], k7[13], inc[13];
+        const T err2 = dp5_step<T, true>(y, k1, u, cm_xy, cm_z, h, yn, k7, inc);
         const T err = m::sqrt(err2 * T(1.0 / 13));
         if (err < T(1)) {
-            T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow(err, T(-0.2)));
+            T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow_ctl(err, T(-0.2)));
             if (rejected) factor = m::min(T(1), factor);
             h_abs *= factor;
             t = t_new;
             rejected = false;
 #pragma unroll
-            for (int i = 0; i < 13; ++i) { y[i] = yn[i]; k1[i] = k7[i]; }
+            for (int i = 0; i < 13; ++i) { y[i] = yn[i]; k1[i] = k7[i]; dy[i] += inc[i]; }
         } else {
-            h_abs *= m::max(T(0.2), T(0.9) * m::pow(err, T(-0.2)));
+            h_abs *= m::max(T(0.2), T(0.9) * m::pow_ctl(err, T(-0.2)));
             rejected = true;
         }
     }
@@ -307,16 +320,16 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
 }
 
 template <typename T>
-__device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13]) {
+__device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13]) {
     T k1[13], yn[13];
     rhs(y, u, cm_xy, cm_z, k1);
-    dp5_step<T, false>(y, k1, u, cm_xy, cm_z, tb, yn, kq);
+    dp5_step<T, false>(y, k1, u, cm_xy, cm_z, tb, yn, kq, dy);
 #pragma unroll
     for (int i = 0; i < 13; ++i) y[i] = yn[i];
 }
 
 template <typename T>
-__device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, T cm_xy, T cm_z, T h, T kq[13]) {
+__device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, T cm_xy, T cm_z, T h, T kq[13], T dy[13]) {
     T k1[13], k2[13], k3[13], k4[13], ys[13];
     rhs(y, u, cm_xy, cm_z, k1);
 #pragma unroll
@@ -329,17 +342,24 @@ __device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, T cm_xy,
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * k3[i];
     rhs(ys, u, cm_xy, cm_z, k4);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) y[i] = y[i] + h * T(1.0 / 6) * ((k1[i] + k4[i]) + T(2) * (k2[i] + k3[i]));
+    for (int i = 0; i < 13; ++i) {
+        const T sum = T(1.0 / 6) * ((k1[i] + k4[i]) + T(2) * (k2[i] + k3[i]));
+        dy[i] = h * sum;
+        y[i] = y[i] + h * sum;
+    }
     rhs(y, u, cm_xy, cm_z, kq);
 }
 
 enum { INT_RK45 = 0, INT_DP5 = 1, INT_RK4 = 2 };
 
 template <typename T, int INTEG>
-__device__ __forceinline__ void integrate(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13]) {
-    if (INTEG == INT_RK45) integrate_rk45(y, u, cm_xy, cm_z, tb, kq);
-    else if (INTEG == INT_DP5) integrate_dp5(y, u, cm_xy, cm_z, tb, kq);
-    else integrate_rk4(y, u, cm_xy, cm_z, tb, kq);
+// On exit: y = state at tb, kq = f(t_end, y_end), dy = y_end - y_start as the SUM OF THE
+// INTEGRATOR'S INCREMENTS (not the difference of the rounded states): the cancellation-free input
+// of the increment-based Euler rates below.
+__device__ __forceinline__ void integrate(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13]) {
+    if (INTEG == INT_RK45) integrate_rk45(y, u, cm_xy, cm_z, tb, kq, dy);
+    else if (INTEG == INT_DP5) integrate_dp5(y, u, cm_xy, cm_z, tb, kq, dy);
+    else integrate_rk4(y, u, cm_xy, cm_z, tb, kq, dy);
 }
 
 // ---- per-env bookkeeping carried between steps (registers in fused rollouts) -------------
@@ -355,13 +375,22 @@ template <typename T> struct Book {
     int32_t flags;  // QENV_FLAG_*
 };
 
-constexpr int FLAG_DONE = 1, FLAG_SOLVED = 2, FLAG_HAS_SHAPING = 4;
+constexpr int FLAG_DONE = 1, FLAG_SOLVED = 2, FLAG_HAS_SHAPING = 4, FLAG_ANG_OK = 8;
 
 // quat_euler on the re-normalised end quaternion + finite-difference Euler rates,
 // quadrotor_env.py:488-493 (main) / quadrotor_env_opt.py:397-402 (opt: prev_ang = ang
 // BEFORE the update).
+//
+// fp32 only: the reference's rate (ang - prev_ang)/t_step differences two angles that each carry
+// ~1e-7 of rounding and divides by 0.01, i.e. it injects ~1e-5 rad/s of noise per step into
+// the LQR/PID feedback.  When prev_ang is known to be the angle of the quaternion this step
+// started from (inc_ok), the same quantity is formed without cancellation from the integrator's
+// quaternion increment dq:  phi = atan2(n, d)  =>  dphi = atan2(dn*d0 - dd*n0, d1*d0 + n1*n0),
+// with dn, dd expanded in products of dq (relative accuracy 1e-7 OF THE INCREMENT), plus the
+// 2*pi wrap the plain difference would contain.  In fp64 the plain difference is kept.
 template <typename T>
-__device__ __forceinline__ void euler_update(const T y[13], const Cfg<T>& cfg, Book<T>& bk) {
+__device__ __forceinline__ void euler_update(const T q_old[4], const T y[13], const T dy[13], bool inc_ok,
+                                             const Cfg<T>& cfg, Book<T>& bk) {
     using m = Mth<T>;
     const T inv = m::rsqrt(y[6] * y[6] + y[7] * y[7] + y[8] * y[8] + y[9] * y[9]);
     const T q0 = y[6] * inv, q1 = y[7] * inv, q2 = y[8] * inv, q3 = y[9] * inv;
@@ -370,10 +399,53 @@ __device__ __forceinline__ void euler_update(const T y[13], const Cfg<T>& cfg, B
     ang[1] = m::asin(T(2) * (q0 * q2 - q3 * q1));
     ang[2] = m::atan2(T(2) * (q0 * q3 + q1 * q2), T(1) - T(2) * (q2 * q2 + q3 * q3));
     const T inv_dt = T(1) / cfg.t_step;
+    T dang[3] = {T(0), T(0), T(0)};
+    const bool use_inc = (sizeof(T) == 4) && inc_ok;
+    if (use_inc) {
+        const T a0 = q_old[0], b0 = q_old[1], c0 = q_old[2], d0 = q_old[3];
+        const T a1 = y[6], b1 = y[7], c1 = y[8], d1 = y[9];
+        const T da = dy[6], db = dy[7], dc = dy[8], dd = dy[9];
+        const T sa = da * (a1 + a0), sb = db * (b1 + b0), sc = dc * (c1 + c0), sd = dd * (d1 + d0);
+        // roll: n = 2(ab+cd), d = a^2-b^2-c^2+d^2 (scale-invariant, un-normalised q is fine)
+        {
+            const T n0 = T(2) * (a0 * b0 + c0 * d0), e0 = (a0 * a0 - b0 * b0) - (c0 * c0 - d0 * d0);
+            const T n1 = T(2) * (a1 * b1 + c1 * d1), e1 = (a1 * a1 - b1 * b1) - (c1 * c1 - d1 * d1);
+            const T dn = T(2) * ((da * b0 + a1 * db) + (dc * d0 + c1 * dd));
+            const T de = (sa - sb) - (sc - sd);
+            dang[0] = m::atan2(dn * e0 - de * n0, e1 * e0 + n1 * n0);
+        }
+        // yaw: n = 2(ad+bc), d = a^2+b^2-c^2-d^2
+        {
+            const T n0 = T(2) * (a0 * d0 + b0 * c0), e0 = (a0 * a0 + b0 * b0) - (c0 * c0 + d0 * d0);
+            const T n1 = T(2) * (a1 * d1 + b1 * c1), e1 = (a1 * a1 + b1 * b1) - (c1 * c1 + d1 * d1);
+            const T dn = T(2) * ((da * d0 + a1 * dd) + (db * c0 + b1 * dc));
+            const T de = (sa + sb) - (sc + sd);
+            dang[2] = m::atan2(dn * e0 - de * n0, e1 * e0 + n1 * n0);
+        }
+        // pitch: S = sin(theta) = 2(ac-db)/|q|^2
+        {
+            const T s0 = (a0 * a0 + b0 * b0) + (c0 * c0 + d0 * d0), s1 = (a1 * a1 + b1 * b1) + (c1 * c1 + d1 * d1);
+            const T m0 = T(2) * (a0 * c0 - d0 * b0);
+            const T dm = T(2) * ((da * c0 + a1 * dc) - (dd * b0 + d1 * db));
+            const T ds = (sa + sb) + (sc + sd);
+            const T S0 = m0 / s0, S1 = T(2) * (a1 * c1 - d1 * b1) / s1;
+            const T dS = (dm * s0 - m0 * ds) / (s0 * s1);
+            const T C0 = m::sqrt(m::max(T(0), T(1) - S0 * S0)), C1 = m::sqrt(m::max(T(0), T(1) - S1 * S1));
+            const T dC = -dS * (S1 + S0) / m::max(C1 + C0, T(1e-30));
+            dang[1] = m::atan2(dS * C0 - S0 * dC, C1 * C0 + S1 * S0);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const T prev = cfg.variant ? bk.ang[k] : bk.prev_ang[k];
-        bk.ang_vel[k] = (ang[k] - prev) * inv_dt;
+        const T direct = ang[k] - prev;
+        T rate = direct * inv_dt;
+        if (use_inc) {
+            // the plain difference equals dang + 2 pi j (j != 0 only when the angle wrapped)
+            const T j = rintf((float)((direct - dang[k]) * T(0.15915494309189535)));
+            rate = (dang[k] + T(6.283185307179586) * j) * inv_dt;
+        }
+        bk.ang_vel[k] = rate;
         bk.prev_ang[k] = cfg.variant ? prev : ang[k];
         bk.ang[k] = ang[k];
     }
@@ -453,7 +525,7 @@ __device__ __forceinline__ void done_reward(const T y[13], const T act[4], const
     }
     bk.reward = reward;
     bk.ep_return += reward;
-    bk.flags = (done ? FLAG_DONE : 0) | (solved ? FLAG_SOLVED : 0) | FLAG_HAS_SHAPING;
+    bk.flags = (done ? FLAG_DONE : 0) | (solved ? FLAG_SOLVED : 0) | FLAG_HAS_SHAPING | FLAG_ANG_OK;
     bk.abs_sum += m::sqrt((effort[0] * effort[0] + effort[1] * effort[1]) + (effort[2] * effort[2] + effort[3] * effort[3]));
 }
 

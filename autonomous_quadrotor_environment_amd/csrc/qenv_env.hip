@@ -22,6 +22,7 @@ template <typename T> struct StepArgs {
     T* out_reward;         // [N] or null
     uint8_t* out_done;     // [N] or null
     int32_t mode;          // QENV_STEP_*
+    int32_t ang_ok;        // every env's prev_ang row is the angle of its state row (see euler_update)
 };
 
 template <typename T> struct RolloutArgs {
@@ -32,6 +33,7 @@ template <typename T> struct RolloutArgs {
     int32_t n_steps;
     int32_t mode;
     int32_t pid_first;
+    int32_t ang_ok;
     T const_action[4];
     T pid_target[4];
     LqrGains<T> lqr;
@@ -77,9 +79,13 @@ __device__ __forceinline__ void store_book(T* ws, int32_t* wsi, int64_t N, int64
     wsi[IROW_FLAGS * N + e] = bk.flags;
 }
 
+#ifndef QENV_MIN_WAVES
+#define QENV_MIN_WAVES 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
+#endif
+
 // quad.step for N envs: one launch, one lane per env.
 template <typename T, int INTEG>
-__global__ __launch_bounds__(256) void k_step(const StepArgs<T> a) {
+__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T> a) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
     if (a.mask && a.mask[e] == 0) return;
@@ -92,10 +98,11 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs<T> a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         raw[k] = a.actions ? a.actions[(int64_t)k * N + e] : ((cfg.direct || k == 0) ? cfg.zero_control0 : T(0));
-    T w[4], effort[4], cl[4], act[4], kq[13];
+    T w[4], effort[4], cl[4], act[4], kq[13], dy[13];
+    const T q_old[4] = {y[6], y[7], y[8], y[9]};
     Act<T> u;
     prepare_action(raw, cfg, w, effort, cl, act, u);
-    integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq);
+    integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy);
 #pragma unroll
     for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, y[k]);
     if (a.mode == QENV_STEP_DYNAMICS_ONLY) return;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs<T> a) {
     Book<T> bk;
     load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
     bk.i += 1;
-    euler_update(y, cfg, bk);
+    euler_update(q_old, y, dy, a.ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
     done_reward(y, act, effort, cfg, bk);
     const bool aux = a.mode != QENV_STEP_NO_AUX;
     store_book(a.ws, a.wsi, N, e, bk, aux);
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void k_step(const StepArgs<T> a) {
 
 // n_steps env steps in one launch, controller on device, state in VGPRs throughout.
 template <typename T, int INTEG, int CTRL>
-__global__ __launch_bounds__(256) void k_rollout(const RolloutArgs<T> a) {
+__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T> a) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
     const int64_t N = a.N;
@@ -153,11 +160,12 @@ __global__ __launch_bounds__(256) void k_rollout(const RolloutArgs<T> a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(a.ws, ROW_PID + 12 + k, N, e);
     }
-    T w[4], effort[4], cl[4], act[4], kq[13], raw[4];
+    T w[4], effort[4], cl[4], act[4], kq[13], raw[4], dy[13];
     Act<T> u;
     if (CTRL == QENV_CTRL_CONST) {  // constant action: mix once for the whole rollout
         prepare_action(a.const_action, cfg, w, effort, cl, act, u);
     }
+    bool ang_ok = a.ang_ok != 0;
     for (int s = 0; s < a.n_steps; ++s) {
         if (CTRL == QENV_CTRL_LQR) {
             lqr_law(y, bk, a.lqr, raw);
@@ -170,11 +178,13 @@ __global__ __launch_bounds__(256) void k_rollout(const RolloutArgs<T> a) {
             }
             prepare_action(raw, cfg, w, effort, cl, act, u);
         }
-        integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq);
+        const T q_old[4] = {y[6], y[7], y[8], y[9]};
+        integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy);
         if (!dyn_only) {
             bk.i += 1;
-            euler_update(y, cfg, bk);
+            euler_update(q_old, y, dy, ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
             done_reward(y, act, effort, cfg, bk);
+            ang_ok = true;  // from here on every env's prev_ang belongs to the state in its registers
         }
     }
 #pragma unroll
@@ -364,6 +374,11 @@ template <typename T> static int do_step(qenv_s* q, const void* actions, const u
     a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N;
     a.actions = (const T*)actions; a.mask = mask;
     a.out_obs = (T*)out_obs; a.out_reward = (T*)out_reward; a.out_done = out_done; a.mode = flags;
+    a.ang_ok = q->ang_ok;
+    // host-side half of the prev_ang bookkeeping: a dynamics-only step moves every state without
+    // touching the angle rows; an unmasked full step re-synchronises all of them
+    if (flags == QENV_STEP_DYNAMICS_ONLY) q->ang_ok = 0;
+    else if (!mask) q->ang_ok = 1;
     const dim3 g = grid_for(q->N), b(256);
     switch (q->cfg.integrator) {
         case QENV_RK45: hipLaunchKernelGGL((k_step<T, INT_RK45>), g, b, 0, q->stream, a); break;
@@ -387,6 +402,8 @@ template <typename T> static int do_rollout(qenv_s* q, int controller, int n_ste
     RolloutArgs<T> a;
     a.cfg = make_cfg<T>(q);
     a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
+    a.ang_ok = q->ang_ok;
+    q->ang_ok = flags == QENV_STEP_DYNAMICS_ONLY ? 0 : 1;
     for (int k = 0; k < 4; ++k) {
         a.const_action[k] = const_action ? (T)const_action[k]
                                          : ((q->cfg.direct_control || k == 0) ? a.cfg.zero_control0 : (T)0);
@@ -453,6 +470,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->wsi = (int32_t*)((char*)workspace + L.int_off);
     q->window = (float*)((char*)workspace + L.win_off);
     q->win_head = 0;
+    q->ang_ok = 0;
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
     if (e != hipSuccess) { delete q; return fail_hip(e, "hipMemsetAsync(workspace)"); }
     *out = q;

@@ -49,7 +49,7 @@ def parse():
     p.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the workload's own size)")
     p.add_argument("--integrator", default="rk45", choices=["rk45", "dp5", "rk4"])
     p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    p.add_argument("--launch", default="step", choices=["step", "fused"],
+    p.add_argument("--launch", default="fused", choices=["step", "fused"],
                    help="step: one kernel launch per env step (quad.step API); fused: the whole K-step "
                         "region in ONE launch with the state held in registers (qenv_rollout)")
     p.add_argument("--chunk", type=int, default=0, help="env steps per graph replay / fused launch "

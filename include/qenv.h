@@ -91,6 +91,7 @@ typedef enum {
 #define QENV_FLAG_DONE 1
 #define QENV_FLAG_SOLVED 2
 #define QENV_FLAG_HAS_SHAPING 4
+#define QENV_FLAG_ANG_OK 8      /* prev_ang row belongs to the state row (internal bookkeeping) */
 
 /* qenv_step flags */
 #define QENV_STEP_FULL 0          /* obs + Euler + done + reward + effort (quad.step)     */
