@@ -17,11 +17,12 @@ INTEGRATORS = {"rk45": RK45, "dp5": DP5, "rk4": RK4}
 VARIANTS = {"main": MAIN, "opt": OPT}
 CTRL_CONST, CTRL_LQR, CTRL_PID = 0, 1, 2
 STEP_FULL, STEP_DYNAMICS_ONLY, STEP_NO_AUX = 0, 1, 2
+STEP_PUSH_WINDOW = 4
 FLAG_DONE, FLAG_SOLVED, FLAG_HAS_SHAPING = 1, 2, 4
 
 (FIELD_STATE, FIELD_ANG, FIELD_PREV_ANG, FIELD_ANG_VEL, FIELD_VQ, FIELD_W, FIELD_STEP_EFFORT,
  FIELD_CLIPPED_ACTION, FIELD_ACCEL, FIELD_PREV_SHAPING, FIELD_REWARD, FIELD_ABS_SUM, FIELD_EP_RETURN,
- FIELD_PID, FIELD_I, FIELD_FLAGS, FIELD_WINDOW) = range(17)
+ FIELD_PID, FIELD_I, FIELD_FLAGS, FIELD_WINDOW, FIELD_LAST_RETURN, FIELD_EPISODES) = range(19)
 
 
 class QenvConfig(C.Structure):
@@ -45,14 +46,16 @@ SYMBOLS = {
     "qenv_destroy": (_i, [_vp]),
     "qenv_set_stream": (_i, [_vp, _vp]),
     "qenv_field": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_int32)]),
-    "qenv_reset": (_i, [_vp, _vp, _vp, _vp, _vp]),
-    "qenv_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "qenv_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "qenv_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "qenv_rollout": (_i, [_vp, _i, _i, _dptr, _i, _i]),
     "qenv_lqr_action": (_i, [_vp, _vp]),
     "qenv_pid_action": (_i, [_vp, _dptr, _vp]),
     "qenv_pid_reset": (_i, [_vp, _vp]),
     "qenv_window_push": (_i, [_vp, _vp, _vp, _i]),
-    "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
+    "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adv_normalize": (_i, [_i, _i64, _vp, _vp, _i, _vp]),
     "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 13),

@@ -21,7 +21,10 @@ template <typename T> struct StepArgs {
     T* out_obs;            // [14][N] or null
     T* out_reward;         // [N] or null
     uint8_t* out_done;     // [N] or null
-    int32_t mode;          // QENV_STEP_*
+    T* out_mask;           // [N] or null: 1 - done
+    float* win;            // observation ring or null
+    int32_t win_slot;      // ring slot this step's slice goes to
+    int32_t mode;          // QENV_STEP_* (mode bits only)
     int32_t ang_ok;        // every env's prev_ang row is the angle of its state row (see euler_update)
 };
 
@@ -134,6 +137,15 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T> 
     }
     if (a.out_reward) a.out_reward[e] = bk.reward;
     if (a.out_done) a.out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
+    if (a.out_mask) a.out_mask[e] = (bk.flags & FLAG_DONE) ? T(0) : T(1);
+    if (a.win) {  // dl_in_gen.dl_input: [raw action(4), vel(3), q(4), q_dot(4)] (dl_auxiliary.py:27-31)
+        float* wv = a.win + (int64_t)a.win_slot * 15 * N + e;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wv[(int64_t)k * N] = (float)raw[k];
+        wv[4 * N] = (float)y[1]; wv[5 * N] = (float)y[3]; wv[6 * N] = (float)y[5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
+    }
 }
 
 // n_steps env steps in one launch, controller on device, state in VGPRs throughout.
@@ -215,6 +227,10 @@ __global__ __launch_bounds__(256) void k_reset(T* ws, int32_t* wsi, int64_t N, c
     if (e >= N) return;
     if (mask && mask[e] == 0) return;
     using m = Mth<T>;
+    if (mask) {  // an episode ends here: bank its return before the counters are cleared
+        st(ws, ROW_LAST_RETURN, N, e, ld(ws, ROW_EP_RETURN, N, e));
+        wsi[IROW_EPISODES * N + e] += 1;
+    }
     T q[4];
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
@@ -368,12 +384,17 @@ template <typename T> static PidGains<T> make_pid(bool clipped) {
 static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 255) / 256)); }
 
 template <typename T> static int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
-                                         void* out_reward, uint8_t* out_done, int flags) {
+                                         void* out_reward, uint8_t* out_done, void* out_mask, int flags_in,
+                                         int win_slot) {
+    const int flags = flags_in & QENV_STEP_MODE_MASK;
     StepArgs<T> a;
     a.cfg = make_cfg<T>(q);
     a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N;
     a.actions = (const T*)actions; a.mask = mask;
     a.out_obs = (T*)out_obs; a.out_reward = (T*)out_reward; a.out_done = out_done; a.mode = flags;
+    a.out_mask = (T*)out_mask;
+    a.win = win_slot >= 0 ? q->window : nullptr;
+    a.win_slot = win_slot;
     a.ang_ok = q->ang_ok;
     // host-side half of the prev_ang bookkeeping: a dynamics-only step moves every state without
     // touching the angle rows; an unmasked full step re-synchronises all of them
@@ -420,14 +441,17 @@ template <typename T> static int do_rollout(qenv_s* q, int controller, int n_ste
 }
 
 template <typename T> static int do_reset(qenv_s* q, const void* init, const uint8_t* mask, void* out_states,
-                                          void* out_actions) {
+                                          void* out_actions, int push_window) {
     const dim3 g = grid_for(q->N), b(256);
     hipLaunchKernelGGL((k_reset<T>), g, b, 0, q->stream, (T*)q->ws, q->wsi, q->N, (const T*)init, mask);
     int rc = check_launch("k_reset");
     const Cfg<T> c = make_cfg<T>(q);
     for (int t = 0; t < q->cfg.T && rc == 0; ++t) {
         T* obs = out_states ? (T*)out_states + (int64_t)t * 14 * q->N : nullptr;
-        rc = do_step<T>(q, nullptr, mask, obs, nullptr, nullptr, QENV_STEP_FULL);
+        // warm-up slice t goes to ring slot head+t: after T of them the reset env's ring is full and in
+        // phase with the (unmoved) head, whatever the other envs did meanwhile
+        rc = do_step<T>(q, nullptr, mask, obs, nullptr, nullptr, nullptr, QENV_STEP_FULL,
+                        push_window ? (q->win_head + t) % q->cfg.T : -1);
         if (rc == 0 && out_actions) {
             T* oa = (T*)out_actions + (int64_t)t * 4 * q->N;
             const T z = c.zero_control0;
@@ -498,8 +522,11 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
     if (field_id >= 0 && field_id <= QENV_FIELD_PID) {
         *dev_ptr = (char*)q->ws + (size_t)row_of[field_id] * q->N * esz;
         if (rows) *rows = rows_of[field_id];
-    } else if (field_id == QENV_FIELD_I || field_id == QENV_FIELD_FLAGS) {
-        *dev_ptr = q->wsi + (field_id == QENV_FIELD_I ? IROW_I : IROW_FLAGS) * q->N;
+    } else if (field_id == QENV_FIELD_LAST_RETURN) {
+        *dev_ptr = (char*)q->ws + (size_t)ROW_LAST_RETURN * q->N * esz;
+        if (rows) *rows = 1;
+    } else if (field_id == QENV_FIELD_I || field_id == QENV_FIELD_FLAGS || field_id == QENV_FIELD_EPISODES) {
+        *dev_ptr = q->wsi + (field_id == QENV_FIELD_I ? IROW_I : field_id == QENV_FIELD_FLAGS ? IROW_FLAGS : IROW_EPISODES) * q->N;
         if (rows) *rows = 1;
     } else if (field_id == QENV_FIELD_WINDOW) {
         *dev_ptr = q->window;
@@ -510,17 +537,28 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
     return QENV_OK;
 }
 
-int qenv_reset(qenv_t q, const void* init_states, const uint8_t* mask, void* out_states, void* out_actions) {
+int qenv_reset(qenv_t q, const void* init_states, const uint8_t* mask, void* out_states, void* out_actions,
+               int push_window) {
     if (!q || !init_states) return fail(QENV_ERR_ARG, "qenv_reset: null argument");
-    return q->cfg.dtype == QENV_F64 ? do_reset<double>(q, init_states, mask, out_states, out_actions)
-                                    : do_reset<float>(q, init_states, mask, out_states, out_actions);
+    return q->cfg.dtype == QENV_F64 ? do_reset<double>(q, init_states, mask, out_states, out_actions, push_window)
+                                    : do_reset<float>(q, init_states, mask, out_states, out_actions, push_window);
 }
 
-int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, uint8_t* out_done, int flags) {
+int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, uint8_t* out_done, void* out_mask,
+              int flags) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_step: null handle");
-    if (flags < QENV_STEP_FULL || flags > QENV_STEP_NO_AUX) return fail(QENV_ERR_ARG, "qenv_step: bad flags");
-    return q->cfg.dtype == QENV_F64 ? do_step<double>(q, actions, nullptr, out_obs, out_reward, out_done, flags)
-                                    : do_step<float>(q, actions, nullptr, out_obs, out_reward, out_done, flags);
+    const int mode = flags & QENV_STEP_MODE_MASK;
+    if (flags < 0 || (flags & ~(QENV_STEP_MODE_MASK | QENV_STEP_PUSH_WINDOW)) || mode > QENV_STEP_NO_AUX)
+        return fail(QENV_ERR_ARG, "qenv_step: bad flags");
+    const bool push = (flags & QENV_STEP_PUSH_WINDOW) != 0;
+    if (push && mode == QENV_STEP_DYNAMICS_ONLY)
+        return fail(QENV_ERR_STATE, "qenv_step: PUSH_WINDOW needs a full step (the slice holds q_dot)");
+    const int slot = push ? q->win_head : -1;
+    const int rc = q->cfg.dtype == QENV_F64
+                       ? do_step<double>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot)
+                       : do_step<float>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot);
+    if (push && rc == 0) q->win_head = (q->win_head + 1) % q->cfg.T;
+    return rc;
 }
 
 int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_action, int pid_first_action, int flags) {

@@ -29,9 +29,10 @@ enum {
     ROW_ABS_SUM = 43,       // 1
     ROW_EP_RETURN = 44,     // 1
     ROW_PID = 45,           // 15
-    ROWS_T = 60
+    ROW_LAST_RETURN = 60,   // 1
+    ROWS_T = 61
 };
-enum { IROW_I = 0, IROW_FLAGS = 1, IROWS = 2 };
+enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROWS = 3 };
 
 struct WsLayout {
     size_t int_off, win_off, total;

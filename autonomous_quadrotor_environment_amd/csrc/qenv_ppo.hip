@@ -45,6 +45,7 @@ struct MlpArgs {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     void* out;          // [n_out][N]
     int32_t out_f64;
+    float* obs_store;   // null or [15*T][N]: the window in time order
 };
 
 __device__ __forceinline__ int acc_row(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                 int slice = a.head + k / 15;
                 if (slice >= a.T) slice -= a.T;
                 x = a.win[(int64_t)(slice * 15 + k % 15) * a.N + e];
+                if (a.obs_store) a.obs_store[(int64_t)k * a.N + e] = x;  // each (k, e) is read by exactly one lane
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -166,6 +168,90 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     if (blocks > 256) blocks = 256;  // one resident workgroup per CU; waves grid-stride over env tiles
     hipLaunchKernelGGL((k_mlp<H, BLOCK, W2_LDS>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
     return check_launch("k_mlp");
+}
+
+// ---- counter-based RNG: Philox4x32-10 (Salmon et al. 2011) --------------------------------------
+// One call = 4 x 32 random bits as a pure function of (key, counter): any env/step can be drawn
+// independently, so streams are identical whatever the sharding or launch order.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    float sn, cs;
+    sincosf(6.283185307179586f * u01(b), &sn, &cs);
+    z0 = r * cs; z1 = r * sn;
+}
+
+// ActorCritic.act sampling (model.py:62-68): a = mean + std*eps, per-dimension Normal log-prob
+template <typename T>
+__global__ __launch_bounds__(256) void k_sample_action(int64_t N, const T* mean, T std, T log_norm, const T* noise,
+                                                       uint64_t seed, uint64_t step, int64_t env_offset, T* out_action,
+                                                       T* out_logprob) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    float z[4];
+    if (noise) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = (float)noise[(int64_t)k * N + e];
+    } else {
+        const uint64_t g = (uint64_t)(env_offset + e);
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0xAC710Du);
+        box_muller(c[0], c[1], z[0], z[1]);
+        box_muller(c[2], c[3], z[2], z[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const T eps = (T)z[k];
+        out_action[(int64_t)k * N + e] = mean[(int64_t)k * N + e] + std * eps;
+        if (out_logprob) out_logprob[(int64_t)k * N + e] = T(-0.5) * eps * eps + log_norm;
+    }
+}
+
+// random branch of quad.reset (quadrotor_env.py:440-445) with Philox streams
+template <typename T>
+__global__ __launch_bounds__(256) void k_sample_init(int64_t N, uint64_t seed, uint64_t episode, int64_t env_offset,
+                                                     const uint8_t* mask, T* out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    if (mask && mask[e] == 0) return;
+    const uint64_t g = (uint64_t)(env_offset + e);
+    float u[4], z[12];
+    for (int blk = 0; blk < 4; ++blk) {
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)episode, ((uint32_t)(episode >> 32) & 0x0FFFFFFFu) | ((uint32_t)blk << 28)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x1417u);
+        if (blk == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = u01(c[k]);
+        } else {
+            box_muller(c[0], c[1], z[4 * (blk - 1)], z[4 * (blk - 1) + 1]);
+            box_muller(c[2], c[3], z[4 * (blk - 1) + 2], z[4 * (blk - 1) + 3]);
+        }
+    }
+    const float phi = u[0] - 0.5f, theta = u[1] - 0.5f, psi = u[2] - 0.5f;
+    float sp, cp, st_, ct, ss, cs;
+    sincosf(0.5f * phi, &sp, &cp); sincosf(0.5f * theta, &st_, &ct); sincosf(0.5f * psi, &ss, &cs);
+    float q[4] = {cp * ct * cs + sp * st_ * ss, sp * ct * cs - cp * st_ * ss, cp * st_ * cs + sp * ct * ss,
+                  cp * ct * ss - sp * st_ * cs};
+    const float inv = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    auto clip = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        out[(int64_t)(2 * k) * N + e] = (T)clip(2.0f * z[k], -2.5f, 2.5f);          // position
+        out[(int64_t)(2 * k + 1) * N + e] = (T)clip(2.0f * z[3 + k], -5.0f, 5.0f);  // velocity
+        out[(int64_t)(10 + k) * N + e] = (T)clip(2.0f * z[6 + k], -15.0f, 7.5f);    // body rates (sic: asymmetric, :445)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[(int64_t)(6 + k) * N + e] = (T)(q[k] * inv);
 }
 
 // ---- GAE ---------------------------------------------------------------------------------------
@@ -289,13 +375,14 @@ int qenv_window_push(qenv_t q, const void* obs, const void* actions, int reset_f
 }
 
 int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const float* W1, const float* b1, const float* W2,
-                     const float* b2, const float* W3, const float* b3, void* out) {
+                     const float* b2, const float* W3, const float* b3, void* out, float* obs_store) {
     if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_mlp_forward: null argument");
     if (n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_forward: n_out must be 1..4");
     MlpArgs a;
     a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = n_out; a.final_tanh = final_tanh;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     a.out_f64 = q->cfg.dtype == QENV_F64;
+    a.obs_store = obs_store;
     switch (hidden) {
         case 16: return launch_mlp<16, 512, true>(a, q->cfg.T, q->stream);
         case 32: return launch_mlp<32, 512, true>(a, q->cfg.T, q->stream);
@@ -304,6 +391,33 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
         case 256: return launch_mlp<256, 256, false>(a, q->cfg.T, q->stream);
         default: return fail(QENV_ERR_ARG, "qenv_mlp_forward: hidden must be one of 16, 32, 64, 128, 256");
     }
+}
+
+int qenv_sample_action(qenv_t q, const void* mean, double std, const void* noise, uint64_t seed, uint64_t step,
+                       int64_t env_offset, void* out_action, void* out_logprob) {
+    if (!q || !mean || !out_action) return fail(QENV_ERR_ARG, "qenv_sample_action: null argument");
+    if (!(std > 0)) return fail(QENV_ERR_ARG, "qenv_sample_action: std must be positive");
+    const dim3 g((unsigned)((q->N + 255) / 256)), b(256);
+    const double log_norm = -std::log(std) - 0.9189385332046727;  // -log(std) - 0.5 log(2 pi)
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_sample_action<double>), g, b, 0, q->stream, q->N, (const double*)mean, std, log_norm,
+                           (const double*)noise, seed, step, env_offset, (double*)out_action, (double*)out_logprob);
+    else
+        hipLaunchKernelGGL((k_sample_action<float>), g, b, 0, q->stream, q->N, (const float*)mean, (float)std,
+                           (float)log_norm, (const float*)noise, seed, step, env_offset, (float*)out_action,
+                           (float*)out_logprob);
+    return check_launch("k_sample_action");
+}
+
+int qenv_sample_init_states(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset, const uint8_t* mask,
+                            void* out_states) {
+    if (!q || !out_states) return fail(QENV_ERR_ARG, "qenv_sample_init_states: null argument");
+    const dim3 g((unsigned)((q->N + 255) / 256)), b(256);
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_sample_init<double>), g, b, 0, q->stream, q->N, seed, episode, env_offset, mask, (double*)out_states);
+    else
+        hipLaunchKernelGGL((k_sample_init<float>), g, b, 0, q->stream, q->N, seed, episode, env_offset, mask, (float*)out_states);
+    return check_launch("k_sample_init");
 }
 
 int qenv_gae(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,

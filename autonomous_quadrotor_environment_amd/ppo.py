@@ -148,47 +148,66 @@ def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, an
 
 
 class PolicyRollout:
-    """Rollout collector of ppo.py's worker loop (:223-269) for N envs at once:
-    window -> actor (MFMA) -> [+ injected Gaussian noise] -> env.step -> window push ->
-    critic, stored time-major; `finish()` runs GAE.  Episodes that end are re-started from
-    caller-supplied initial states (auto-reset), as the worker's `while` loop does."""
+    """Rollout collector of ppo.py's worker loop (:223-269) for N envs at once, all on the device:
+    window -> actor + critic (fp32 MFMA) -> Normal sample -> env.step (+ window push) -> masked
+    auto-reset of finished episodes, stored time-major; `finish()` runs GAE.
 
-    def __init__(self, env: BatchedQuad, weights: ActorCriticWeights, horizon):
+    Every per-step buffer is preallocated, every call enqueues kernels only, so `step()` can be
+    captured into a hipGraph.  `env_offset` = this shard's first global env index (keeps the Philox
+    streams shard-invariant)."""
+
+    def __init__(self, env: BatchedQuad, weights: ActorCriticWeights, horizon, store_obs=False, auto_reset=False,
+                 seed=0, env_offset=0):
         assert env.direct_control_flag, "the PPO controller commands the four rotors (direct_control=1)"
         self.env, self.w, self.horizon = env, weights, int(horizon)
-        N, dev, dt = env.n_envs, env.device, env.dtype
-        self.actions = torch.empty(horizon, 4, N, device=dev, dtype=dt)
-        self.rewards = torch.empty(horizon, N, device=dev, dtype=dt)
-        self.masks = torch.empty(horizon, N, device=dev, dtype=dt)
-        self.values = torch.zeros(horizon + 1, N, device=dev, dtype=dt)
+        self.auto_reset, self.seed, self.env_offset = bool(auto_reset), int(seed), int(env_offset)
+        N, dev, dt, H = env.n_envs, env.device, env.dtype, self.horizon
+        self.actions = torch.zeros(H, 4, N, device=dev, dtype=dt)
+        self.logprobs = torch.zeros(H, 4, N, device=dev, dtype=dt)
+        self.rewards = torch.zeros(H, N, device=dev, dtype=dt)
+        self.masks = torch.ones(H, N, device=dev, dtype=dt)
+        self.values = torch.zeros(H + 1, N, device=dev, dtype=dt)
+        self.obs = torch.zeros(H, 15 * env.T, N, device=dev, dtype=torch.float32) if store_obs else None
+        self.mean = torch.zeros(4, N, device=dev, dtype=dt)
+        self.done = torch.zeros(N, device=dev, dtype=torch.uint8)
+        self.init = torch.zeros(13, N, device=dev, dtype=dt)
         self.t = 0
+        self.global_step = 0
 
-    def start(self, init_states):
+    def start(self, init_states=None):
+        """reset() + fill the window with the T warm-up slices (ppo.py:234-240)."""
         env = self.env
-        states, actions = env.reset(init_states)
-        for k in range(env.T):
-            env.window_push(states[k], actions[k], reset_first=(k == 0))
+        if init_states is None:
+            init_states = env.sample_init_states(self.seed, 0, self.env_offset, out=self.init)
+        env.reset(init_states, return_history=False, push_window=True)
         self.t = 0
 
     def step(self, noise=None, deterministic=False):
-        """One env step for all envs.  noise: [4, N] standard-normal tensor (injected so CPU
-        and GPU runs can share it)."""
-        env, t = self.env, self.t
-        mean = env.mlp_forward(self.w, "actor")
-        if self.w.critic is not None:
-            env.mlp_forward(self.w, "critic", out=self.values[t:t + 1])
-        act = mean if (deterministic or noise is None) else mean + self.w.std * noise.to(mean.dtype)
-        self.actions[t].copy_(act)
-        obs, rew, done = env.step(act)
-        env.window_push(obs, act)
-        self.rewards[t].copy_(rew)
-        self.masks[t].copy_((~done).to(self.rewards.dtype))
+        """One env step for all envs.  noise: injected [4, N] standard normal."""
+        env, t, w = self.env, self.t, self.w
+        store = None if self.obs is None else self.obs[t]
+        if deterministic:  # mean action, as ppo_quad_eval.py:55
+            act = env.mlp_forward(w, "actor", out=self.actions[t], obs_store=store)
+        else:
+            env.mlp_forward(w, "actor", out=self.mean, obs_store=store)
+            act = env.sample_action(self.mean, w.std, noise, self.seed, self.global_step + 1, self.env_offset,
+                                    out=self.actions[t], logprob=self.logprobs[t])
+        if w.critic is not None:
+            env.mlp_forward(w, "critic", out=self.values[t:t + 1])
+        env.step(act, flags=L.STEP_NO_AUX, out=(None, self.rewards[t], self.done), out_mask=self.masks[t],
+                 push_window=True)
+        if self.auto_reset:  # worker loop: `while` episodes until the batch is full (ppo.py:232-262)
+            env.sample_init_states(self.seed, self.global_step + 1, self.env_offset, mask=self.done, out=self.init)
+            env.reset(self.init, mask=self.done, return_history=False, push_window=True)
         self.t += 1
-        return obs, rew, done
+        self.global_step += 1
 
-    def finish(self, ddof=0, group=False):
+    def finish(self, ddof=0, group=False, bootstrap=False):
+        """GAE over the collected steps.  bootstrap=False appends V=0 like the reference
+        (ppo.py:385); True evaluates the critic on the final window."""
         n = self.t
-        if self.w.critic is not None:
+        if bootstrap and self.w.critic is not None:
             self.env.mlp_forward(self.w, "critic", out=self.values[n:n + 1])
-            self.values[n].mul_(self.masks[n - 1])
+        else:
+            self.values[n].zero_()
         return gae(self.values[:n + 1], self.masks[:n], self.rewards[:n], ddof=ddof, group=group)

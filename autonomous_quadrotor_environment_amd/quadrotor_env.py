@@ -202,6 +202,8 @@ class BatchedQuad:
     i = property(lambda s: s._field(L.FIELD_I, torch.int32)[0])
     flags = property(lambda s: s._field(L.FIELD_FLAGS, torch.int32)[0])
     window = property(lambda s: s._field(L.FIELD_WINDOW, torch.float32))
+    last_return = property(lambda s: s._field(L.FIELD_LAST_RETURN)[0])
+    episodes = property(lambda s: s._field(L.FIELD_EPISODES, torch.int32)[0])
     done = property(lambda s: (s.flags & L.FLAG_DONE) != 0)
     solved = property(lambda s: ((s.flags & L.FLAG_SOLVED) != 0).to(torch.int32))
 
@@ -213,9 +215,11 @@ class BatchedQuad:
     def seed(self, seed):
         self._rng = np.random.RandomState(seed)
 
-    def reset(self, det_state=None, mask=None, return_history=True):
+    def reset(self, det_state=None, mask=None, return_history=True, push_window=False):
         """quad.reset (quadrotor_env.py:408-454).  det_state: [13, N] / [N, 13] / [13] tensor
         or array; None draws every env's state in the reference's RNG order on the host.
+        mask: uint8/bool [N], only those envs are reset (their episode return is banked in
+        `last_return`).  push_window: the T warm-up slices refill the observation ring.
         Returns (states [T, 14, N], actions [T, 4, N])."""
         if det_state is None:
             rng = getattr(self, "_rng", None) or np.random.RandomState()
@@ -228,16 +232,22 @@ class BatchedQuad:
         if return_history and mask is not None:
             states.zero_(); actions.zero_()
         self._bind()
-        L.check(L.lib.qenv_reset(self._h, L.ptr(init), L.ptr(m), L.ptr(states), L.ptr(actions)), "qenv_reset")
+        L.check(L.lib.qenv_reset(self._h, L.ptr(init), L.ptr(m), L.ptr(states), L.ptr(actions),
+                                 int(bool(push_window))), "qenv_reset")
         return states, actions
 
-    def step(self, action=None, flags=L.STEP_FULL, out=None):
+    def step(self, action=None, flags=L.STEP_FULL, out=None, out_mask=None, push_window=False):
         """quad.step for all envs.  action [4, N] (or [N, 4]); None = zero_control.
+        out: optional preallocated (obs [14, N] | None, reward [N] | None, done uint8 [N] | None);
+        out_mask: optional [N] tensor receiving 1 - done; push_window: also append this step's
+        [action, vel, q, q_dot] slice to the observation ring (dl_in_gen.dl_input).
         Returns (quat_state [14, N], reward [N], done [N] bool)."""
         act = self._as_rows(action, 4, "action")
         self._bind()
-        if flags == L.STEP_DYNAMICS_ONLY:
-            L.check(L.lib.qenv_step(self._h, L.ptr(act), None, None, None, flags), "qenv_step")
+        if push_window:
+            flags |= L.STEP_PUSH_WINDOW
+        if (flags & 3) == L.STEP_DYNAMICS_ONLY:
+            L.check(L.lib.qenv_step(self._h, L.ptr(act), None, None, None, None, flags), "qenv_step")
             return None, None, None
         if out is None:
             obs = torch.empty(14, self.n_envs, device=self.device, dtype=self.dtype)
@@ -245,8 +255,9 @@ class BatchedQuad:
             done = torch.empty(self.n_envs, device=self.device, dtype=torch.uint8)
         else:
             obs, rew, done = out
-        L.check(L.lib.qenv_step(self._h, L.ptr(act), L.ptr(obs), L.ptr(rew), L.ptr(done), flags), "qenv_step")
-        return obs, rew, done.bool() if out is None else done
+        L.check(L.lib.qenv_step(self._h, L.ptr(act), L.ptr(obs), L.ptr(rew), L.ptr(done), L.ptr(out_mask), flags),
+                "qenv_step")
+        return obs, rew, (done.bool() if out is None else done)
 
     def rollout(self, controller="const", n_steps=1, action=None, pid_first_action=False, flags=L.STEP_FULL):
         """n_steps fused env steps in one launch with an on-device controller
@@ -283,14 +294,36 @@ class BatchedQuad:
         self._bind()
         L.check(L.lib.qenv_window_push(self._h, L.ptr(o), L.ptr(a), int(bool(reset_first))), "qenv_window_push")
 
-    def mlp_forward(self, weights, head="actor", out=None):
-        """ActorCritic.actor / .critic forward on the observation ring (model.py:27-42)."""
+    def mlp_forward(self, weights, head="actor", out=None, obs_store=None):
+        """ActorCritic.actor / .critic forward on the observation ring (model.py:27-42).
+        obs_store: optional float32 [15*T, N] receiving the window in time order."""
         W1, b1, W2, b2, W3, b3 = weights.head(head)
         n_out = W3.shape[0]
         out = torch.empty(n_out, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
         self._bind()
         L.check(L.lib.qenv_mlp_forward(self._h, W1.shape[0], n_out, int(head == "actor"), L.ptr(W1), L.ptr(b1),
-                                       L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out)), "qenv_mlp_forward")
+                                       L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), L.ptr(obs_store)),
+                "qenv_mlp_forward")
+        return out
+
+    def sample_action(self, mean, std, noise=None, seed=0, step=0, env_offset=0, out=None, logprob=None):
+        """ActorCritic.act sampling (model.py:62-68): mean + std*eps and the per-dimension log-prob.
+        noise: injected standard-normal [4, N] (for CPU/GPU parity runs); otherwise Philox keyed by
+        (seed; global env index env_offset+e, step)."""
+        out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        nz = None if noise is None else self._as_rows(noise, 4, "noise")
+        self._bind()
+        L.check(L.lib.qenv_sample_action(self._h, L.ptr(mean), float(std), L.ptr(nz), int(seed), int(step),
+                                         int(env_offset), L.ptr(out), L.ptr(logprob)), "qenv_sample_action")
+        return out
+
+    def sample_init_states(self, seed, episode=0, env_offset=0, mask=None, out=None):
+        """Device-side random branch of quad.reset (same distributions, Philox streams)."""
+        out = torch.zeros(13, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._bind()
+        L.check(L.lib.qenv_sample_init_states(self._h, int(seed), int(episode), int(env_offset), L.ptr(m), L.ptr(out)),
+                "qenv_sample_init_states")
         return out
 
 

@@ -85,7 +85,9 @@ typedef enum {
                                                bit2 prev_shaping valid              */
     QENV_FIELD_WINDOW = 16,        /* [15*T][N] float32 observation ring (row block
                                                s = slice written at push s mod T)   */
-    QENV_FIELD_COUNT_ = 17
+    QENV_FIELD_LAST_RETURN = 17,   /* [1][N]   return of the last finished episode    */
+    QENV_FIELD_EPISODES = 18,      /* [1][N]   int32 episodes finished (masked resets)  */
+    QENV_FIELD_COUNT_ = 19
 } qenv_field_id;
 
 #define QENV_FLAG_DONE 1
@@ -99,6 +101,9 @@ typedef enum {
 #define QENV_STEP_NO_AUX 2        /* FULL but skip the attribute rows nobody reads in
                                      batched rollouts (w, effort, clipped_action, accel,
                                      ang_vel) -- 224 B/env-step of SURVEY.md section 8d   */
+#define QENV_STEP_MODE_MASK 3
+#define QENV_STEP_PUSH_WINDOW 4   /* OR-ed in: also append [raw action, vel, q, q_dot] to the
+                                     observation ring (dl_in_gen.dl_input fused into the step) */
 
 /* quad.__init__(t_step, n, training, euler, direct_control, T, clipped),
  * quadrotor_env.py:112-187 (euler is unused by the reference as well). */
@@ -140,17 +145,22 @@ int qenv_field(qenv_t q, int field_id, void **dev_ptr, int32_t *rows);
  *   init_states [13][N]: explicit states (det_state, or the host-side replay of the
  *                        reference's RNG draw order for the random branch)
  *   mask        nullable uint8 [N]: reset only envs with mask != 0
- *   out_states  nullable [T][14][N], out_actions nullable [T][4][N]            */
+ *   out_states  nullable [T][14][N], out_actions nullable [T][4][N]
+ *   push_window nonzero: the T warm-up slices also refill the observation ring of the reset
+ *               envs (worker loop ppo.py:234-240) WITHOUT moving the ring head, so envs that
+ *               are not reset stay in phase.
+ * With a mask, each reset env first banks its episode return (LAST_RETURN, EPISODES). */
 int qenv_reset(qenv_t q, const void *init_states, const uint8_t *mask, void *out_states,
-               void *out_actions);
+               void *out_actions, int push_window);
 
 /* Replaces quad.step(action) (quadrotor_env.py:458-498) for all N envs.
  *   actions    [4][N], nullable = zero_control for every env
  *   out_obs    nullable [14][N]  quat_state = [state[0:10], V_q]
  *   out_reward nullable [N];  out_done nullable uint8 [N]
- *   flags      QENV_STEP_*                                                       */
+ *   out_mask   nullable [N]: 1 - done in the handle's dtype (the `masks` GAE consumes)
+ *   flags      QENV_STEP_* mode, optionally | QENV_STEP_PUSH_WINDOW                */
 int qenv_step(qenv_t q, const void *actions, void *out_obs, void *out_reward, uint8_t *out_done,
-              int flags);
+              void *out_mask, int flags);
 
 /* n_steps fused steps in ONE launch with the controller evaluated on device and the
  * state held in registers between steps -- the loop bodies of lqr_quad.py:123-168 and
@@ -183,10 +193,27 @@ int qenv_window_push(qenv_t q, const void *obs, const void *actions, int reset_f
  * y = [tanh](W3 tanh(W2 tanh(W1 x + b1) + b2) + b3) on the observation ring, fp32
  * MFMA.  Weights: float32 device, row-major [out][in] exactly as torch's nn.Linear
  * (W1 [H][15*T], W2 [H][H], W3 [n_out][H]); H in {16,32,64,128,256}; n_out <= 4.
- * out [n_out][N] in the handle's dtype. */
+ * out [n_out][N] in the handle's dtype.  obs_store nullable float32 [15*T][N]: the window in
+ * time order, as read by the first layer (the `states` a PPO rollout keeps, ppo.py:250). */
 int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const float *W1,
                      const float *b1, const float *W2, const float *b2, const float *W3,
-                     const float *b3, void *out);
+                     const float *b3, void *out, float *obs_store);
+
+/* Replaces ActorCritic.act's sampling (model.py:62-68): action = mean + std * eps,
+ * logprob = Normal(mean, std).log_prob(action) per dimension.
+ *   mean [4][N]; noise nullable [4][N] standard normal in the handle's dtype (injected, so a
+ *   CPU run can share it); without it eps comes from Philox4x32-10 keyed by (seed, stream)
+ *   with counter = (GLOBAL env index env_offset + e, step) -- shard- and replay-invariant.
+ *   out_action [4][N], out_logprob nullable [4][N]. */
+int qenv_sample_action(qenv_t q, const void *mean, double std, const void *noise, uint64_t seed,
+                       uint64_t step, int64_t env_offset, void *out_action, void *out_logprob);
+
+/* Random branch of quad.reset (quadrotor_env.py:440-445) on the device: Euler angles U(-.5,.5),
+ * pos/vel/body-rate N(0,2) clipped to +-2.5 / +-5 / [-15, 7.5], quaternion by euler_quat.  Same
+ * distributions as the reference, Philox streams instead of its MT19937 draw order (use the
+ * host replay for seed parity).  out [13][N]; only envs with mask != 0 are written (nullable). */
+int qenv_sample_init_states(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset,
+                            const uint8_t *mask, void *out_states);
 
 /* Replaces PPO.get_advantages (environment/controller/ppo.py:125-141, ddof=0;
  * visual_landing/ppo_trainer.py:133-148, ddof=1) on a time-major rollout:

@@ -36,15 +36,15 @@ def test_argument_validation_without_a_device(built):
     n32 = L.lib.qenv_workspace_bytes(C.byref(cfg))
     cfg.dtype = L.F64
     n64 = L.lib.qenv_workspace_bytes(C.byref(cfg))
-    # 60 rows of T + 2 int rows + 15*T float rows, 256-byte aligned sections
-    assert n32 == 60 * 1024 * 4 + 2 * 1024 * 4 + 75 * 1024 * 4
-    assert n64 == 60 * 1024 * 8 + 2 * 1024 * 4 + 75 * 1024 * 4
+    # 61 rows of T + 3 int rows + 15*T float rows, 256-byte aligned sections
+    assert n32 == 61 * 1024 * 4 + 3 * 1024 * 4 + 75 * 1024 * 4
+    assert n64 == 61 * 1024 * 8 + 3 * 1024 * 4 + 75 * 1024 * 4
     bad = L.QenvConfig(0, 0.01, 1000, 1, 1, 1, 1, 0, 0, 0)
     assert L.lib.qenv_workspace_bytes(C.byref(bad)) == 0
     h = C.c_void_p()
     assert L.lib.qenv_create(C.byref(cfg), None, 0, None, C.byref(h)) == -1
     assert b"null" in L.lib.qenv_last_error()
-    assert L.lib.qenv_step(None, None, None, None, None, 0) == -1
+    assert L.lib.qenv_step(None, None, None, None, None, None, 0) == -1
     assert L.lib.qenv_gae(0, 0, 10, None, None, None, None, None, None, None) == -1
     with pytest.raises(L.QenvError):
         L.check(L.lib.qenv_destroy(None), "qenv_destroy")
