@@ -50,17 +50,31 @@ struct MlpArgs {
 
 __device__ __forceinline__ int acc_row(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }
 
-template <int H, int BLOCK, bool W2_LDS>
+// tanh with ~1e-7 absolute error in ~12 VALU instructions (ocml's tanhf is ~3x that and the two
+// hidden layers need 256 of them per env): odd Taylor polynomial below 0.3 (next term < 2e-8),
+// 1 - 2/(exp(2|x|)+1) on v_exp_f32 / v_rcp_f32 above; saturates cleanly for large |x|.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float small = ax * (1.0f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f))));
+    return copysignf(ax < 0.3f ? small : big, x);
+}
+
+// K1 = 15*T window elements; TW > 0: compile-time window length (the whole observation of a tile
+// is prefetched into registers with back-to-back global loads before the first MFMA, and every
+// loop is unrolled so hipcc hoists the LDS operand reads ahead of the MFMAs); TW == 0: run-time T.
+template <int H, int TW, int BLOCK, bool W2_LDS>
 __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     constexpr int HP = H < 32 ? 32 : H;  // hidden rows padded to the 32-row MFMA tile
     constexpr int NT = HP / 32;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int K1 = 15 * a.T;
+    const int K1 = TW ? 15 * TW : 15 * a.T;
     const int K1P = (K1 + 1) & ~1;
     float* W1t = lds;                                   // [K1P][HP]
     float* W2t = W1t + (size_t)K1P * HP;                // [HP][HP]   (k-major), only if W2_LDS
-    float* W3s = W2t + (W2_LDS ? (size_t)HP * HP : 0);  // [4][HP]
-    float* b1s = W3s + 4 * HP;
+    float* W3t = W2t + (W2_LDS ? (size_t)HP * HP : 0);  // [HP][4]    (h-major: one ds_read_b128 per hidden unit)
+    float* b1s = W3t + 4 * HP;
     float* b2s = b1s + HP;
     float* b3s = b2s + HP;  // [4]
     for (int idx = threadIdx.x; idx < K1P * HP; idx += BLOCK) {
@@ -73,8 +87,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
             W2t[idx] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
         }
     for (int idx = threadIdx.x; idx < 4 * HP; idx += BLOCK) {
-        const int o = idx / HP, h = idx % HP;
-        W3s[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
+        const int h = idx / 4, o = idx % 4;
+        W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
     }
     for (int h = threadIdx.x; h < HP; h += BLOCK) {
         b1s[h] = h < H ? a.b1[h] : 0.f;
@@ -88,64 +102,116 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     const int64_t n_tiles = (a.N + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * waves_per_block + wave; tile < n_tiles;
          tile += (int64_t)gridDim.x * waves_per_block) {
+        // The weights in LDS and the ring offsets are invariant across tiles, so LICM would hoist hundreds of
+        // LDS reads / offsets out of this loop and spill them; an opaque memory clobber per tile stops that.
+        asm volatile("" ::: "memory");
         const int64_t e = tile * 32 + col;
         const bool valid = e < a.N;
-        f32x16 acc1[NT], acc2[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                acc1[t][j] = b1s[32 * t + acc_row(j, half)];
-                acc2[t][j] = b2s[32 * t + acc_row(j, half)];
-            }
+        f32x16 acc1[NT];
+        // Output tiles are the OUTER loop of both layers, so only one 16-register accumulator chain is
+        // being fed at a time (a 32x32x2 f32 MFMA chain issues back to back: its 64-cycle dependent latency
+        // equals its issue interval) and the live set stays ~110 VGPRs instead of spilling.
         // layer 1: k-step s covers window elements k = 2s (lanes 0-31) and 2s+1 (lanes 32-63)
-        for (int s = 0; s < K1P / 2; ++s) {
-            const int k = 2 * s + half;
-            float x = 0.f;
-            if (valid && k < K1) {
-                int slice = a.head + k / 15;
-                if (slice >= a.T) slice -= a.T;
-                x = a.win[(int64_t)(slice * 15 + k % 15) * a.N + e];
-                if (a.obs_store) a.obs_store[(int64_t)k * a.N + e] = x;  // each (k, e) is read by exactly one lane
+        if (TW) {
+            constexpr int KS = (15 * (TW ? TW : 1) + 1) / 2;
+            float xs[KS];
+            // 32-bit element offsets from the (scalar) ring base, no per-load predicates: out-of-range envs
+            // read env N-1 (masked at the final store), the one padded k-step is zeroed by a select
+            uint32_t N32 = (uint32_t)a.N;
+            int hsel = half;
+            asm volatile("" : "+s"(N32), "+v"(hsel));  // keeps the 38 row selects/offsets inside the tile loop
+            const uint32_t e32 = (uint32_t)(valid ? e : a.N - 1);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                constexpr int dummy = 0; (void)dummy;
+                const int k0 = 2 * s, k1 = 2 * s + 1;
+                int sl0 = a.head + k0 / 15, sl1 = a.head + k1 / 15;  // wave-uniform (SALU)
+                if (sl0 >= TW) sl0 -= TW;
+                if (sl1 >= TW) sl1 -= TW;
+                const uint32_t r0 = (uint32_t)(sl0 * 15 + k0 % 15);
+                const uint32_t r1 = k1 < 15 * TW ? (uint32_t)(sl1 * 15 + k1 % 15) : r0;
+                float x = a.win[(hsel ? r1 : r0) * N32 + e32];
+                if (k1 >= 15 * TW) x = hsel ? 0.f : x;
+                xs[s] = x;
+            }
+            if (a.obs_store && valid) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const uint32_t k = (uint32_t)(2 * s + half);
+                    if (2 * s + 1 < 15 * TW || half == 0) a.obs_store[k * N32 + e32] = xs[s];  // each (k, e) is held by exactly one lane
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[(2 * s + half) * HP + 32 * t + col], xs[s], acc1[t], 0, 0, 0);
+                    // fence the scheduler every 8 k-steps: without it hipcc hoists ALL the LDS operand reads of
+                    // the unrolled loop above the first MFMA and spills
+                    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+            for (int s = 0; s < K1P / 2; ++s) {
+                const int k = 2 * s + half;
+                float x = 0.f;
+                if (valid && k < K1) {
+                    int slice = a.head + k / 15;
+                    if (slice >= a.T) slice -= a.T;
+                    x = a.win[(int64_t)(slice * 15 + k % 15) * a.N + e];
+                    if (a.obs_store) a.obs_store[(int64_t)k * a.N + e] = x;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[k * HP + 32 * t + col], x, acc1[t], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[k * HP + 32 * t + col], x, acc1[t], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc1[t][j] = tanhf(acc1[t][j]);
-        // layer 2: register j of input tile ti IS the B operand of the k-step that pairs hidden
-        // rows 32 ti + acc_row(j,0) and 32 ti + acc_row(j,1)
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k = 32 * ti + acc_row(j, half);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float w = W2_LDS ? W2t[k * HP + 32 * t + col]
-                                           : ((32 * t + col) < H ? a.W2[(size_t)(32 * t + col) * H + k] : 0.f);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, acc1[ti][j], acc2[t], 0, 0, 0);
-                }
-            }
-        // layer 3 on the VALU: each lane holds half of its env's hidden vector
+        // layer 2 (MFMA) + layer 3 (VALU), one output tile at a time.  Register j of input tile ti IS the B
+        // operand of the k-step that pairs hidden rows 32 ti + acc_row(j,0) and 32 ti + acc_row(j,1); each lane
+        // then holds half of its env's hidden vector for the 4-output dot products.
         float o3[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int k = 32 * ti + acc_row(j, half);
+                    const float w = W2_LDS ? W2t[k * HP + 32 * t + col]
+                                           : ((32 * t + col) < H ? a.W2[(size_t)(32 * t + col) * H + k] : 0.f);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, acc1[ti][j], acc2, 0, 0, 0);
+                    if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float hv = tanhf(acc2[t][j]);
-                const int h = 32 * t + acc_row(j, half);
-#pragma unroll
-                for (int o = 0; o < 4; ++o) o3[o] = fmaf(W3s[o * HP + h], hv, o3[o]);
+                const float hv = fast_tanh(acc2[j]);
+                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * (32 * t + acc_row(j, half))]);
+                o3[0] = fmaf(w3.x, hv, o3[0]); o3[1] = fmaf(w3.y, hv, o3[1]);
+                o3[2] = fmaf(w3.z, hv, o3[2]); o3[3] = fmaf(w3.w, hv, o3[3]);
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+        }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             float v = o3[o] + __shfl_xor(o3[o], 32);
             v += b3s[o];
-            if (a.final_tanh) v = tanhf(v);
+            if (a.final_tanh) v = tanhf(v);  // the 4 outputs keep the exact tanh
             if (valid && half == 0 && o < a.n_out) {
                 if (a.out_f64) ((double*)a.out)[(int64_t)o * a.N + e] = (double)v;
                 else ((float*)a.out)[(int64_t)o * a.N + e] = v;
@@ -154,19 +220,21 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     }
 }
 
-template <int H, int BLOCK, bool W2_LDS>
+template <int H, int TW, int BLOCK, bool W2_LDS>
 static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
     const int K1P = (15 * T + 1) & ~1;
     const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 4 * HP + 2 * HP + 4);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, BLOCK, W2_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
+    if (TW && (int64_t)15 * TW * a.N >= ((int64_t)1 << 31))
+        return fail(QENV_ERR_ARG, "qenv_mlp_forward: 15*T*n_envs must stay below 2^31 (32-bit ring offsets)");
     const int64_t n_tiles = (a.N + 31) / 32;
     const int wpb = BLOCK / 64;
     int64_t blocks = (n_tiles + wpb - 1) / wpb;
     if (blocks > 256) blocks = 256;  // one resident workgroup per CU; waves grid-stride over env tiles
-    hipLaunchKernelGGL((k_mlp<H, BLOCK, W2_LDS>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
     return check_launch("k_mlp");
 }
 
@@ -383,12 +451,13 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     a.out_f64 = q->cfg.dtype == QENV_F64;
     a.obs_store = obs_store;
+    const bool t5 = q->cfg.T == 5;  // the reference's window (ppo.py:60, T = 5): fully unrolled variant
     switch (hidden) {
-        case 16: return launch_mlp<16, 512, true>(a, q->cfg.T, q->stream);
-        case 32: return launch_mlp<32, 512, true>(a, q->cfg.T, q->stream);
-        case 64: return launch_mlp<64, 512, true>(a, q->cfg.T, q->stream);
-        case 128: return launch_mlp<128, 512, true>(a, q->cfg.T, q->stream);
-        case 256: return launch_mlp<256, 256, false>(a, q->cfg.T, q->stream);
+        case 16: return t5 ? launch_mlp<16, 5, 512, true>(a, 5, q->stream) : launch_mlp<16, 0, 512, true>(a, q->cfg.T, q->stream);
+        case 32: return t5 ? launch_mlp<32, 5, 512, true>(a, 5, q->stream) : launch_mlp<32, 0, 512, true>(a, q->cfg.T, q->stream);
+        case 64: return t5 ? launch_mlp<64, 5, 512, true>(a, 5, q->stream) : launch_mlp<64, 0, 512, true>(a, q->cfg.T, q->stream);
+        case 128: return t5 ? launch_mlp<128, 5, 512, true>(a, 5, q->stream) : launch_mlp<128, 0, 512, true>(a, q->cfg.T, q->stream);
+        case 256: return launch_mlp<256, 0, 256, false>(a, q->cfg.T, q->stream);
         default: return fail(QENV_ERR_ARG, "qenv_mlp_forward: hidden must be one of 16, 32, 64, 128, 256");
     }
 }

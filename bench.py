@@ -37,7 +37,16 @@ WORKLOADS = {
                 "BASELINE configs[1]: 65536 envs/GPU, zero action, perturbed hover, dynamics only"),
     "config3": (262144, 0, "lqr", 2, BYTES_FULL,
                 "BASELINE configs[2]: 262144 envs/GPU, LQR inner loop, random init, full step"),
+    # PPO workloads: controller names select the runner below; bytes from SURVEY.md section 8d
+    "config4": (131072, 1, "ppo_actor", 2, BYTES_FULL + 360,
+                "BASELINE configs[3]: 131072 envs/GPU (1048576 on 8), PPO actor MLP 75-128-128-4 (fp32 MFMA) in the "
+                "loop, T=5 window, deterministic mean action, random init"),
+    "config5": (65536, 1, "ppo_rollout", 2, BYTES_FULL + 360 + 332 + 20,
+                "BASELINE configs[4]: 65536 envs/GPU (524288 on 8), full PPO rollout (actor+critic, Normal(mean,0.1) "
+                "Philox sampling, reward_fn, masked auto-reset) + GAE per 128-step horizon, returns all-gathered"),
 }
+MLP_FLOPS = 2 * (75 * 128 + 128 * 128 + 128 * 4)  # per env and forward: 53.0 kflop
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
 def parse():
@@ -70,6 +79,43 @@ def make_init(workload, n_global, lo, hi):
         x0[:, 6:10] = [1, 0, 0, 0]
         x0[:, 10:13] *= 0.05
     return x0
+
+
+def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_global):
+    """config 4 / 5: the rollout collector of ppo.py:223-269 on the device."""
+    from autonomous_quadrotor_environment_amd import ActorCriticWeights, PolicyRollout
+    from autonomous_quadrotor_environment_amd.distributed import all_gather_returns
+    w = ActorCriticWeights.random(128, 75, 4, device=env.device, seed=1)  # random-init weights of the reference's shape
+    w.std = 0.1
+    if controller == "ppo_actor":
+        ro = PolicyRollout(env, ActorCriticWeights(w.actor, None, env.device), chunk)
+
+        def body():
+            ro.t = 0
+            for _ in range(chunk):
+                ro.step(deterministic=True)
+        if not use_graph:
+            return body, chunk, ro
+        assert chunk % env.T == 0, "a graph replay must bring the ring head back (chunk % T == 0)"
+        side = torch.cuda.Stream(device=env.device)
+        side.wait_stream(torch.cuda.current_stream(env.device))
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream(env.device).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            body()
+        return graph.replay, chunk, ro
+    ro = PolicyRollout(env, w, chunk, store_obs=True, auto_reset=True, seed=seed, env_offset=env_offset)
+
+    def body():  # one horizon: rollout, GAE (global normalisation), episode returns all-gathered over RCCL
+        ro.t = 0
+        for _ in range(chunk):
+            ro.step()
+        ro.finish(ddof=0, group=None)
+        all_gather_returns(env.last_return, n_global)
+    return body, chunk, ro
 
 
 def make_runner(env, controller, flags, launch, chunk, use_graph):
@@ -155,18 +201,33 @@ def cpu_baseline(workload, integrator, seconds):
     qo.build()
     _, direct, controller, _, _, _ = WORKLOADS[workload]
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box's CPU share for one GPU is 16
-    ctrl = {"const": 0, "lqr": 1, "pid": 2}[controller]
     x0 = make_init(workload, 4096 * threads, 0, 4096 * threads)
+    if controller.startswith("ppo"):  # actor (+ critic for config 5) MLP in the loop, same random-init weights
+        rng = np.random.RandomState(1)  # the draw order of ActorCriticWeights.random(128, seed=1)
+
+        def lin(o, i):
+            b = 1.0 / np.sqrt(i)
+            return rng.uniform(-b, b, (o, i)), rng.uniform(-b, b, o)
+
+        def mlp(out):
+            W1, b1 = lin(128, 75); W2, b2 = lin(128, 128); W3, b3 = lin(out, 128)
+            return [W1, b1, W2, b2, W3, b3]
+        actor, critic = mlp(4), mlp(1)
+        batch = lambda c, n: qo.batch_ppo(c, n, actor, critic if controller == "ppo_rollout" else None, T=5,
+                                          integrator=integrator)
+    else:
+        ctrl = {"const": 0, "lqr": 1, "pid": 2}[controller]
+        batch = lambda c, n: qo.batch_rollout(c, n, direct=direct, integrator=integrator, controller=ctrl)
     # calibrate, then size the sample for ~`seconds` of wall time
     t0 = time.perf_counter()
-    qo.batch_rollout(x0[:64], 50, direct=direct, integrator=integrator, controller=ctrl)
+    batch(x0[:64], 50)
     rate1 = 64 * 50 / (time.perf_counter() - t0)
     steps = 1000
     per_thread = int(max(64, min(4096, rate1 * seconds / steps)))
     chunks = [x0[k * per_thread:(k + 1) * per_thread] for k in range(threads)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
-        list(ex.map(lambda c: qo.batch_rollout(c, steps, direct=direct, integrator=integrator, controller=ctrl), chunks))
+        list(ex.map(lambda c: batch(c, steps), chunks))
     dt = time.perf_counter() - t0
     total = threads * per_thread * steps
     return {"value": total / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
@@ -192,7 +253,15 @@ def main():
     lo, hi = shard_range(n_global, rank, world)
     dt = torch.float32 if args.dtype == "f32" else torch.float64
 
+    ppo = controller.startswith("ppo")
+
     def build_env(integrator):
+        if ppo:  # config 5 trains (solved/broken/timeout end episodes, 500-step episodes as ppo.py:301)
+            env = BatchedQuad(hi - lo, 0.01, 500, training=(controller == "ppo_rollout"), direct_control=1, T=5,
+                              integrator=integrator, device=dev, dtype=dt)
+            env.reset(torch.from_numpy(np.ascontiguousarray(make_init(args.workload, n_global, lo, hi).T)),
+                      return_history=False, push_window=True)
+            return env
         env = BatchedQuad(hi - lo, 0.01, 10 ** 9, training=False, direct_control=direct, T=1,
                           integrator=integrator, device=dev, dtype=dt)
         env.reset(torch.from_numpy(np.ascontiguousarray(make_init(args.workload, n_global, lo, hi).T)))
@@ -200,16 +269,26 @@ def main():
             env.pid_reset()
         return env
 
-    chunk = args.chunk or max(c for c in range(1, 251) if args.steps % c == 0 and (args.warmup % c == 0))
+    if controller == "ppo_rollout":  # one call = one 128-step horizon + GAE + all-gather
+        chunk = args.chunk or (128 if args.steps % 128 == 0 and args.warmup % 128 == 0 else
+                               max(c for c in range(1, 129) if args.steps % c == 0 and args.warmup % c == 0))
+    else:
+        chunk = args.chunk or max(c for c in range(1, 251) if args.steps % c == 0 and (args.warmup % c == 0)
+                                  and (not ppo or c % 5 == 0 or args.no_graph))
     if args.steps % chunk or args.warmup % chunk:
         raise SystemExit("--chunk must divide --steps and --warmup")
     env = build_env(args.integrator)
-    run, per_call = make_runner(env, controller, flags, args.launch, chunk, not args.no_graph)
+    if ppo:
+        args.launch = "step"
+        run, per_call, ro = make_ppo_runner(env, controller, chunk, (not args.no_graph) and controller == "ppo_actor",
+                                            seed=4, env_offset=lo, n_global=n_global)
+    else:
+        run, per_call = make_runner(env, controller, flags, args.launch, chunk, not args.no_graph)
     time_region(run, per_call, args.warmup, world, dev)         # W untimed warm-up steps
     secs = time_region(run, per_call, args.steps, world, dev)   # exactly K timed steps
     value = n_global * args.steps / secs
     finite = bool(torch.isfinite(env.state).all())
-    if flags != 1:
+    if flags != 1 and controller != "ppo_rollout":
         all_gather_returns(env.episode_return, n_global)  # the path's one exchange step (RCCL over xGMI)
 
     # dominant kernel, per-launch duration by HIP events on the launch stream
@@ -227,6 +306,24 @@ def main():
             traffic = None
     kname = ("k_rollout" if (args.launch == "fused" or controller != "const") else "k_step") + \
             f"<{'float' if args.dtype == 'f32' else 'double'},{args.integrator}>"
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kname,
+                "kernel_us": k_us, "algorithmic_bytes_per_launch": algo_bytes,
+                "bytes_per_env_step": bytes_per_step * esz, "env_steps_per_launch": (hi - lo) * spl}
+    if ppo:  # the dominant kernel of the PPO workloads is the fp32-MFMA MLP forward
+        heads = 2 if controller == "ppo_rollout" else 1
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        torch.cuda.synchronize()
+        for a_, b_ in evs:
+            a_.record(); env.mlp_forward(ro.w, "actor", out=ro.mean); b_.record()
+        torch.cuda.synchronize()
+        ts = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in evs)
+        mlp_us = float(np.mean(ts[:15]))
+        tfl = MLP_FLOPS * (hi - lo) / (mlp_us * 1e-6) / 1e12
+        roofline = {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tfl / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "k_mlp<128,512,true> (actor forward)",
+                    "kernel_us": mlp_us, "flops_per_launch": MLP_FLOPS * (hi - lo), "mlp_forwards_per_env_step": heads,
+                    "hbm_algorithmic_GBps_whole_step": bytes_per_step * esz * value / world / 1e9}
 
     out = {
         "metric": "quadrotor env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
@@ -237,13 +334,10 @@ def main():
                    "integrator": args.integrator, "launch": args.launch, "controller": controller,
                    "steps_per_graph_replay_or_launch": chunk, "hip_graph": (args.launch == "step" and not args.no_graph),
                    "parallelism": f"env-sharded x{world}", "finite": finite},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kname,
-                     "kernel_us": k_us, "algorithmic_bytes_per_launch": algo_bytes,
-                     "bytes_per_env_step": bytes_per_step * esz, "env_steps_per_launch": (hi - lo) * spl},
+        "roofline": roofline,
     }
 
-    if args.extras and world == 1:
+    if args.extras and world == 1 and not ppo:
         extras = {}
         for integ in ("rk45", "dp5", "rk4"):
             e2 = build_env(integ)

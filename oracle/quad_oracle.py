@@ -64,6 +64,7 @@ def lib():
         _lib = C.CDLL(_SO)
         assert _lib.qo_env_size() == C.sizeof(_Env), "oracle struct layout drifted"
         _lib.qo_batch_rollout.restype = C.c_long
+        _lib.qo_batch_ppo.restype = C.c_long
     return _lib
 
 
@@ -181,6 +182,19 @@ def batch_rollout(states, steps, t_step=0.01, direct=1, variant=VARIANT_MAIN, in
     lib().qo_batch_rollout(s.shape[0], int(steps), C.c_double(t_step), int(direct), int(variant),
                            INTEGRATORS[integrator], int(controller), _p(act), _p(s), _p(rs))
     return s, rs
+
+
+def batch_ppo(states, steps, actor, critic=None, T=5, t_step=0.01, integrator="rk45"):
+    """N envs with the actor (and optionally the critic) MLP in the loop; weights = lists
+    [W1, b1, W2, b2, W3, b3] (torch layout).  Returns (final states [N,13], value sums [N])."""
+    s = np.array(states, dtype=np.float64, order="C").reshape(-1, 13)
+    vs = np.zeros(s.shape[0])
+    a = [_a(w) for w in actor]
+    c = [_a(w) for w in critic] if critic is not None else [None] * 6
+    pp = lambda x: None if x is None else _p(x)
+    lib().qo_batch_ppo(s.shape[0], int(steps), C.c_double(t_step), INTEGRATORS[integrator], int(T), int(a[0].shape[0]),
+                       *[pp(x) for x in a], *[pp(x) for x in c], _p(s), _p(vs))
+    return s, vs
 
 
 # ---- quad-compatible class ------------------------------------------------------
