@@ -15,7 +15,7 @@ MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
 INTEGRATORS = {"rk45": RK45, "dp5": DP5, "rk4": RK4}
 VARIANTS = {"main": MAIN, "opt": OPT}
-CTRL_CONST, CTRL_LQR, CTRL_PID = 0, 1, 2
+CTRL_CONST, CTRL_LQR, CTRL_PID, CTRL_PIDPOS = 0, 1, 2, 3
 STEP_FULL, STEP_DYNAMICS_ONLY, STEP_NO_AUX = 0, 1, 2
 STEP_PUSH_WINDOW = 4
 FLAG_DONE, FLAG_SOLVED, FLAG_HAS_SHAPING = 1, 2, 4
@@ -52,6 +52,7 @@ SYMBOLS = {
     "qenv_lqr_action": (_i, [_vp, _vp]),
     "qenv_pid_action": (_i, [_vp, _dptr, _vp]),
     "qenv_pid_reset": (_i, [_vp, _vp]),
+    "qenv_pidpos_action": (_i, [_vp, _dptr, _vp]),
     "qenv_window_push": (_i, [_vp, _vp, _vp, _i]),
     "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
@@ -59,6 +60,7 @@ SYMBOLS = {
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adv_normalize": (_i, [_i, _i64, _vp, _vp, _i, _vp]),
     "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 13),
+    "qenv_ppo_loss": (_i, [_i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "qenv_debug_copy_rows": (_i, [_i, _vp, _vp, _i, _i64, _vp]),
 }
 

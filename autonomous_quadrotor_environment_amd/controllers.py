@@ -55,3 +55,11 @@ class pid_control(PidController):
     def __init__(self, drone_env):
         super().__init__(drone_env)
         self.att_target = []
+
+
+class PidPosController(PidController):
+    """Position-tracking PD of environment/controller/PID_control.py:29-106 (trajectory targets)."""
+
+    def control(self, xd=(0, 0, 0), dxd=(0, 0, 0), psd=0, dpsd=0, out=None):
+        a = self._b.pidpos_action([xd[0], xd[1], xd[2], dxd[0], dxd[1], dxd[2], psd], out)
+        return a[:, 0].double().cpu().numpy() if isinstance(self.env, quad) else a

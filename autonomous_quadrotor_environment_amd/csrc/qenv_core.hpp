@@ -610,4 +610,46 @@ __device__ __forceinline__ void pid_law(const T y[13], const Book<T>& bk, const 
     act[3] = U4;
 }
 
+// ---- position-tracking PD, environment/controller/PID_control.py:24-106,205-216 ---------------
+// tgt = {xd, yd, zd, dxd, dyd, dzd, psi_d}; the passed derivatives (state velocity, env.ang_vel) are
+// used, arctan instead of arctan2.  Only ix[] and ang_d_ant[] of the PID state are touched.
+template <typename T>
+__device__ __forceinline__ void pidpos_law(const T y[13], const Book<T>& bk, PidState<T>& s, const T tgt[7], T t_step,
+                                           T act[4]) {
+    using m = Mth<T>;
+    const T P[6] = {T(6), T(6), T(6), T(22), T(22), T(1)}, D[6] = {T(3), T(3), T(3), T(12), T(12), T(0.1)};
+    const T ts = T(0.01);
+    T u[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T x = y[2 * k], dx = y[2 * k + 1];
+        s.ix[k] = s.ix[k] + (tgt[k] - x) * ts;
+        u[k] = P[k] * (tgt[k] - x) + D[k] * (tgt[3 + k] - dx);  // I = 0 (PID_control.py:24-27)
+    }
+    const T theta_d = m::atan2(u[0] / (u[2] + T(phys::G)), T(1));  // arctan
+    const T ctd = m::cos(theta_d);
+    const T phi_d = m::atan2(-u[1] / (u[2] + T(phys::G)) * ctd, T(1));
+    act[0] = T(phys::M) * (u[2] + T(phys::G)) / (ctd * m::cos(phi_d));
+    const T ang_d[3] = {phi_d, theta_d, tgt[6]};
+    T u567[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T v_ang_d = (ang_d[k] - s.ang_d_ant[k]) / t_step;
+        s.ix[3 + k] = s.ix[3 + k] + (ang_d[k] - bk.ang[k]) * ts;
+        u567[k] = P[3 + k] * (ang_d[k] - bk.ang[k]) + D[3 + k] * (v_ang_d - bk.ang_vel[k]);
+        s.ang_d_ant[k] = ang_d[k];
+    }
+    const T phi = bk.ang[0], theta = bk.ang[1];
+    const T sp = m::sin(phi), cp = m::cos(phi), ct = m::cos(theta), tt = m::tan(theta);
+    const T b1 = T(1.0 / phys::JX), b2 = tt * sp * T(1.0 / phys::JY), b3 = tt * cp * T(1.0 / phys::JZ);
+    const T b4 = cp * T(1.0 / phys::JY), b5 = -sp * T(1.0 / phys::JZ);
+    const T b6 = sp / ct * T(1.0 / phys::JY), b7 = cp / ct * T(1.0 / phys::JZ);
+    const T det = b4 * b7 - b5 * b6;
+    const T U3 = (b7 * u567[1] - b5 * u567[2]) / det;
+    const T U4 = (-b6 * u567[1] + b4 * u567[2]) / det;
+    act[1] = (u567[0] - b2 * U3 - b3 * U4) / b1;
+    act[2] = U3;
+    act[3] = U4;
+}
+
 }  // namespace qenv

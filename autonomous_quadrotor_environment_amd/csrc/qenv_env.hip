@@ -38,7 +38,7 @@ template <typename T> struct RolloutArgs {
     int32_t pid_first;
     int32_t ang_ok;
     T const_action[4];
-    T pid_target[4];
+    T pid_target[7];
     LqrGains<T> lqr;
     PidGains<T> pid;
 };
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         for (int k = 0; k < 3; ++k) bk.ang_vel[k] = ld(a.ws, ROW_ANG_VEL + k, N, e);
     }
     PidState<T> ps;
-    if (CTRL == QENV_CTRL_PID) {
+    if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { ps.ix[k] = ld(a.ws, ROW_PID + k, N, e); ps.x_old[k] = ld(a.ws, ROW_PID + 6 + k, N, e); }
 #pragma unroll
@@ -188,6 +188,9 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             } else {
                 pid_law(y, bk, a.pid, ps, a.pid_target, cfg.t_step, raw);
             }
+            prepare_action(raw, cfg, w, effort, cl, act, u);
+        } else if (CTRL == QENV_CTRL_PIDPOS) {
+            pidpos_law(y, bk, ps, a.pid_target, cfg.t_step, raw);
             prepare_action(raw, cfg, w, effort, cl, act, u);
         }
         const T q_old[4] = {y[6], y[7], y[8], y[9]};
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) st(a.ws, ROW_ACCEL + k, N, e, kq[1 + 2 * k]);
-    if (CTRL == QENV_CTRL_PID) {
+    if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { st(a.ws, ROW_PID + k, N, e, ps.ix[k]); st(a.ws, ROW_PID + 6 + k, N, e, ps.x_old[k]); }
 #pragma unroll
@@ -304,6 +307,35 @@ __global__ __launch_bounds__(256) void k_pid_action(T* ws, int64_t N, PidGains<T
     pid_law(y, bk, g, ps, tgt, t_step, act);
 #pragma unroll
     for (int k = 0; k < 6; ++k) { st(ws, ROW_PID + k, N, e, ps.ix[k]); st(ws, ROW_PID + 6 + k, N, e, ps.x_old[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st(ws, ROW_PID + 12 + k, N, e, ps.ang_d_ant[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
+}
+
+template <typename T> struct Tgt7 { T v[7]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pidpos_action(T* ws, int64_t N, Tgt7<T> tg, T t_step, T* out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    T y[13];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y[k] = ld(ws, ROW_STATE + k, N, e);
+#pragma unroll
+    for (int k = 6; k < 13; ++k) y[k] = T(0);
+    Book<T> bk;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { bk.ang[k] = ld(ws, ROW_ANG + k, N, e); bk.ang_vel[k] = ld(ws, ROW_ANG_VEL + k, N, e); }
+    PidState<T> ps;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ps.ix[k] = ld(ws, ROW_PID + k, N, e); ps.x_old[k] = T(0); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(ws, ROW_PID + 12 + k, N, e);
+    T act[4];
+    pidpos_law(y, bk, ps, tg.v, t_step, act);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st(ws, ROW_PID + k, N, e, ps.ix[k]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) st(ws, ROW_PID + 12 + k, N, e, ps.ang_d_ant[k]);
 #pragma unroll
@@ -414,6 +446,7 @@ template <typename T, int INTEG> static void launch_rollout(qenv_s* q, int contr
     switch (controller) {
         case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_CONST>), g, b, 0, q->stream, a); break;
         case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_LQR>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_PIDPOS>), g, b, 0, q->stream, a); break;
         default: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_PID>), g, b, 0, q->stream, a); break;
     }
 }
@@ -425,11 +458,11 @@ template <typename T> static int do_rollout(qenv_s* q, int controller, int n_ste
     a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
     a.ang_ok = q->ang_ok;
     q->ang_ok = flags == QENV_STEP_DYNAMICS_ONLY ? 0 : 1;
-    for (int k = 0; k < 4; ++k) {
-        a.const_action[k] = const_action ? (T)const_action[k]
-                                         : ((q->cfg.direct_control || k == 0) ? a.cfg.zero_control0 : (T)0);
-        a.pid_target[k] = (T)0;
-    }
+    for (int k = 0; k < 7; ++k) a.pid_target[k] = (controller == QENV_CTRL_PIDPOS && const_action) ? (T)const_action[k] : (T)0;
+    for (int k = 0; k < 4; ++k)
+        a.const_action[k] = (const_action && controller == QENV_CTRL_CONST)
+                                ? (T)const_action[k]
+                                : ((q->cfg.direct_control || k == 0) ? a.cfg.zero_control0 : (T)0);
     a.lqr = make_lqr<T>(q->cfg.clipped != 0);
     a.pid = make_pid<T>(q->cfg.clipped != 0);
     switch (q->cfg.integrator) {
@@ -563,7 +596,7 @@ int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, ui
 
 int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_action, int pid_first_action, int flags) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_rollout: null handle");
-    if (controller < QENV_CTRL_CONST || controller > QENV_CTRL_PID) return fail(QENV_ERR_ARG, "qenv_rollout: bad controller");
+    if (controller < QENV_CTRL_CONST || controller > QENV_CTRL_PIDPOS) return fail(QENV_ERR_ARG, "qenv_rollout: bad controller");
     if (n_steps < 0) return fail(QENV_ERR_ARG, "qenv_rollout: negative n_steps");
     if (flags < QENV_STEP_FULL || flags > QENV_STEP_NO_AUX) return fail(QENV_ERR_ARG, "qenv_rollout: bad flags");
     if (flags == QENV_STEP_DYNAMICS_ONLY && controller != QENV_CTRL_CONST)
@@ -600,6 +633,21 @@ int qenv_pid_action(qenv_t q, const double* targets, void* out_actions) {
                            make_pid<float>(q->cfg.clipped != 0), (float)t[0], (float)t[1], (float)t[2], (float)t[3],
                            (float)q->cfg.t_step, (float*)out_actions);
     return check_launch("k_pid_action");
+}
+
+int qenv_pidpos_action(qenv_t q, const double* targets, void* out_actions) {
+    if (!q || !out_actions) return fail(QENV_ERR_ARG, "qenv_pidpos_action: null argument");
+    const dim3 g = grid_for(q->N), b(256);
+    if (q->cfg.dtype == QENV_F64) {
+        Tgt7<double> tg;
+        for (int k = 0; k < 7; ++k) tg.v[k] = targets ? targets[k] : 0.0;
+        hipLaunchKernelGGL((k_pidpos_action<double>), g, b, 0, q->stream, (double*)q->ws, q->N, tg, q->cfg.t_step, (double*)out_actions);
+    } else {
+        Tgt7<float> tg;
+        for (int k = 0; k < 7; ++k) tg.v[k] = targets ? (float)targets[k] : 0.f;
+        hipLaunchKernelGGL((k_pidpos_action<float>), g, b, 0, q->stream, (float*)q->ws, q->N, tg, (float)q->cfg.t_step, (float*)out_actions);
+    }
+    return check_launch("k_pidpos_action");
 }
 
 int qenv_pid_reset(qenv_t q, const uint8_t* mask) {

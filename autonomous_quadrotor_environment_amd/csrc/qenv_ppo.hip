@@ -373,6 +373,54 @@ __global__ __launch_bounds__(256) void k_adv_normalize(int64_t n, T* adv, const 
         adv[i] = (T)(((double)adv[i] - mean) * inv);
 }
 
+// ---- PPO clipped-surrogate loss (ppo.py:185-203) ------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_ppo_loss(int64_t B, const T* mean, const T* value, const T* actions,
+                                                  const T* old_logprob, const T* adv, const T* returns, T inv_var, T log_norm,
+                                                  T eps, T c_value, T entropy4, double* sums, T* grad_mean, T* grad_value) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s_actor = 0.0, s_sq = 0.0;
+    if (b < B) {
+        T lp = T(0), lp_old = T(0), d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d[k] = actions[(int64_t)k * B + b] - mean[(int64_t)k * B + b];
+            lp += T(-0.5) * d[k] * d[k] * inv_var + log_norm;
+            lp_old += old_logprob[(int64_t)k * B + b];
+        }
+        const T ratio = (T)exp((double)(lp - lp_old));
+        const T A = adv[b];
+        const T clipped = Mth<T>::min(Mth<T>::max(ratio, T(1) - eps), T(1) + eps);
+        const T s1 = ratio * A, s2 = clipped * A;
+        const bool use1 = s1 <= s2;  // torch.min picks surr1 on ties
+        s_actor = -(double)(use1 ? s1 : s2);
+        const T err = value[b] - returns[b];
+        s_sq = (double)err * (double)err;
+        const T invB = T(1) / (T)B;
+        if (grad_value) grad_value[b] = T(2) * c_value * err * invB;
+        if (grad_mean) {
+            // d(-min)/d mean_k: -A * ratio * (a_k - mean_k)/var when the un-clipped branch is active
+            // (or the clamp is not saturated), else 0
+            const bool live = use1 || (ratio > T(1) - eps && ratio < T(1) + eps);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) grad_mean[(int64_t)k * B + b] = live ? -A * ratio * d[k] * inv_var * invB : T(0);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s_actor += __shfl_xor(s_actor, off);
+        s_sq += __shfl_xor(s_sq, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[1], s_actor);
+        atomicAdd(&sums[2], s_sq);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&sums[0], (double)B);
+        atomicAdd(&sums[3], (double)entropy4 * (double)B);
+    }
+}
+
 // ---- visual_reward -----------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_visual_reward(int64_t N, int total_steps, const T* marker, const T* pos,
@@ -516,6 +564,28 @@ int qenv_adv_normalize(int dtype, int64_t n, void* adv, const double* stats, int
         hipLaunchKernelGGL((k_adv_normalize<float>), g, b, 0, (hipStream_t)stream, n, (float*)adv, stats, ddof);
     else return fail(QENV_ERR_ARG, "qenv_adv_normalize: bad dtype");
     return check_launch("k_adv_normalize");
+}
+
+int qenv_ppo_loss(int dtype, int64_t batch, const void* mean, const void* value, const void* actions,
+                  const void* old_logprob, const void* adv, const void* returns, double std, double eps_clip,
+                  double c_value, double* sums, void* grad_mean, void* grad_value, void* stream) {
+    if (!mean || !value || !actions || !old_logprob || !adv || !returns || !sums)
+        return fail(QENV_ERR_ARG, "qenv_ppo_loss: null argument");
+    if (batch <= 0 || !(std > 0)) return fail(QENV_ERR_ARG, "qenv_ppo_loss: batch and std must be positive");
+    const dim3 g((unsigned)((batch + 255) / 256)), b(256);
+    const double inv_var = 1.0 / (std * std), log_norm = -std::log(std) - 0.9189385332046727;
+    const double entropy4 = 4.0 * (0.5 + 0.9189385332046727 + std::log(std));
+    if (dtype == QENV_F64)
+        hipLaunchKernelGGL((k_ppo_loss<double>), g, b, 0, (hipStream_t)stream, batch, (const double*)mean, (const double*)value,
+                           (const double*)actions, (const double*)old_logprob, (const double*)adv, (const double*)returns,
+                           inv_var, log_norm, eps_clip, c_value, entropy4, sums, (double*)grad_mean, (double*)grad_value);
+    else if (dtype == QENV_F32)
+        hipLaunchKernelGGL((k_ppo_loss<float>), g, b, 0, (hipStream_t)stream, batch, (const float*)mean, (const float*)value,
+                           (const float*)actions, (const float*)old_logprob, (const float*)adv, (const float*)returns,
+                           (float)inv_var, (float)log_norm, (float)eps_clip, (float)c_value, (float)entropy4, sums,
+                           (float*)grad_mean, (float*)grad_value);
+    else return fail(QENV_ERR_ARG, "qenv_ppo_loss: bad dtype");
+    return check_launch("k_ppo_loss");
 }
 
 int qenv_visual_reward(int dtype, int64_t n_envs, int total_steps, const void* marker, const void* pos, const void* vel,

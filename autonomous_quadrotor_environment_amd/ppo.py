@@ -127,6 +127,31 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True):
     return ret, adv
 
 
+def ppo_loss(mean, value, actions, old_logprob, adv, returns, std, eps_clip=0.2, c_value=0.5, c_entropy=0.006,
+             with_grads=False):
+    """Loss of PPO.update (ppo.py:185-203) for a batch: mean/actions/old_logprob [4, B], value/adv/returns [B].
+    Returns a dict of device scalars {loss, actor, critic, entropy} (loss = loss.mean() of the reference) and,
+    with_grads, d loss / d mean [4, B] and d loss / d value [B]."""
+    B = adv.numel()
+    dt = L.F64 if mean.dtype == torch.float64 else L.F32
+    c = lambda t: t.to(mean.dtype).contiguous()
+    mean, value, actions, old_logprob, adv, returns = map(c, (mean, value, actions, old_logprob, adv, returns))
+    sums = torch.zeros(4, dtype=torch.float64, device=mean.device)
+    gm = torch.empty_like(mean) if with_grads else None
+    gv = torch.empty_like(value) if with_grads else None
+    stream = C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream)
+    L.check(L.lib.qenv_ppo_loss(dt, B, L.ptr(mean), L.ptr(value), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
+                                L.ptr(returns), float(std), float(eps_clip), float(c_value), L.ptr(sums), L.ptr(gm),
+                                L.ptr(gv), stream), "qenv_ppo_loss")
+    actor = sums[1] / sums[0]
+    critic = c_value * sums[2] / sums[0]
+    entropy = -c_entropy * sums[3] / sums[0]
+    out = {"loss": actor + critic + entropy, "actor": actor, "critic": critic, "entropy": entropy}
+    if with_grads:
+        out["grad_mean"], out["grad_value"] = gm, gv
+    return out
+
+
 def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, ang, v_ang):
     """Batched visual_landing/rl_reward_fuction.py:3-102.  [3, N] tensors (marker, pos, vel,
     control, ang, v_ang), last_shaping [N] (0 = none), step int32 [N].

@@ -262,10 +262,11 @@ class BatchedQuad:
     def rollout(self, controller="const", n_steps=1, action=None, pid_first_action=False, flags=L.STEP_FULL):
         """n_steps fused env steps in one launch with an on-device controller
         ('const' | 'lqr' | 'pid'); state stays in registers between steps."""
-        ctrl = {"const": L.CTRL_CONST, "lqr": L.CTRL_LQR, "pid": L.CTRL_PID}[controller]
+        ctrl = {"const": L.CTRL_CONST, "lqr": L.CTRL_LQR, "pid": L.CTRL_PID, "pidpos": L.CTRL_PIDPOS}[controller]
         ca = None
-        if action is not None:
-            ca = (C.c_double * 4)(*[float(a) for a in np.asarray(action).ravel()])
+        if action is not None:  # CONST: the 4-vector action; PIDPOS: the 7-vector target
+            vals = [float(a) for a in np.asarray(action).ravel()]
+            ca = (C.c_double * len(vals))(*vals)
         self._bind()
         L.check(L.lib.qenv_rollout(self._h, ctrl, int(n_steps), ca, int(bool(pid_first_action)), flags), "qenv_rollout")
 
@@ -280,6 +281,14 @@ class BatchedQuad:
         tg = None if targets is None else (C.c_double * 4)(*[float(a) for a in targets])
         self._bind()
         L.check(L.lib.qenv_pid_action(self._h, tg, L.ptr(out)), "qenv_pid_action")
+        return out
+
+    def pidpos_action(self, targets=None, out=None):
+        """PID_control.py position PD: targets = [xd, yd, zd, dxd, dyd, dzd, psi_d]."""
+        out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        tg = None if targets is None else (C.c_double * 7)(*[float(a) for a in targets])
+        self._bind()
+        L.check(L.lib.qenv_pidpos_action(self._h, tg, L.ptr(out)), "qenv_pidpos_action")
         return out
 
     def pid_reset(self, mask=None):

@@ -60,7 +60,8 @@ typedef enum { QENV_RK45 = 0, QENV_DP5 = 1, QENV_RK4 = 2 } qenv_integrator;
 typedef enum {
     QENV_CTRL_CONST = 0, /* one constant action for every env and step              */
     QENV_CTRL_LQR = 1,   /* environment/controller/lqr_quad.py:128-154              */
-    QENV_CTRL_PID = 2    /* environment/controller/pid_vel_control.py:29-127        */
+    QENV_CTRL_PID = 2,   /* environment/controller/pid_vel_control.py:29-127        */
+    QENV_CTRL_PIDPOS = 3 /* environment/controller/PID_control.py:29-106 (position PD) */
 } qenv_controller;
 
 /* Rows of the per-env workspace exposed through qenv_field (the attributes callers of
@@ -167,7 +168,8 @@ int qenv_step(qenv_t q, const void *actions, void *out_obs, void *out_reward, ui
  * pid_vel_control.py:141-164 (both ignore `done` and keep stepping), or a constant
  * action.  const_action: HOST pointer to 4 doubles (CONST only, nullable =
  * zero_control).  pid_first_action: PID only, nonzero = the first step uses
- * [M*G,0,0,0] like pid_vel_control.py:146.  Rewards are summed into EP_RETURN.
+ * [M*G,0,0,0] like pid_vel_control.py:146.  PIDPOS holds one target (const_action then
+ * points to its 7 doubles {xd,yd,zd,dxd,dyd,dzd,psi_d}).  Rewards are summed into EP_RETURN.
  * flags: QENV_STEP_* (DYNAMICS_ONLY skips Euler/done/reward, CONST only). */
 int qenv_rollout(qenv_t q, int controller, int n_steps, const double *const_action,
                  int pid_first_action, int flags);
@@ -180,6 +182,11 @@ int qenv_rollout(qenv_t q, int controller, int n_steps, const double *const_acti
 int qenv_lqr_action(qenv_t q, void *out_actions);
 int qenv_pid_action(qenv_t q, const double *targets, void *out_actions);
 int qenv_pid_reset(qenv_t q, const uint8_t *mask); /* new pid_control(), :144 */
+/* Position-tracking PD of PID_control.py:98-110, pid_control.control(xd, dxd, psi_d, 0):
+ * targets: HOST pointer to 7 doubles {xd, yd, zd, dxd, dyd, dzd, psi_d} (nullable = zeros) --
+ * one trajectory point shared by all envs, as mission_control.get_error(t) supplies per step
+ * (PID_control.py:250-263).  Uses and updates the same PID workspace rows. */
+int qenv_pidpos_action(qenv_t q, const double *targets, void *out_actions);
 
 /* ---- PPO inner loop ------------------------------------------------------------------ */
 
@@ -226,6 +233,19 @@ int qenv_gae(int dtype, int64_t n_envs, int n_steps, const void *values, const v
              const void *rewards, void *returns, void *adv, double *stats, void *stream);
 int qenv_adv_normalize(int dtype, int64_t n_elems, void *adv, const double *stats, int ddof,
                        void *stream);
+
+/* Replaces the loss of PPO.update (environment/controller/ppo.py:185-203): per sample
+ *   logp_k = Normal(mean_k, std).log_prob(action_k); ratio = exp(sum_k logp_k - sum_k old_logprob_k)
+ *   actor = -min(ratio*adv, clamp(ratio, 1-eps, 1+eps)*adv); entropy_k = 0.5 + 0.5 log(2 pi) + log std
+ *   loss.mean() = mean(actor) + c_value * MSE(value, returns) - c_entropy * mean(sum_k entropy_k)
+ * (ppo.py: c_value 0.5, c_entropy 0.006, eps 0.2; ppo_trainer.py:112-122 uses the same terms).
+ * Inputs [4][B] / [B] in `dtype`.  sums: device double[4] accumulated (caller zeroes):
+ * {B, sum actor, sum (value-returns)^2, sum_k entropy_k * B}.  grad_mean [4][B] / grad_value [B]
+ * (nullable): d loss.mean() / d mean, d value -- the seed of the backward pass. */
+int qenv_ppo_loss(int dtype, int64_t batch, const void *mean, const void *value, const void *actions,
+                  const void *old_logprob, const void *adv, const void *returns, double std,
+                  double eps_clip, double c_value, double *sums, void *grad_mean, void *grad_value,
+                  void *stream);
 
 /* Replaces visual_reward (visual_landing/rl_reward_fuction.py:3-102), batched.
  * marker,pos,vel,control,ang,v_ang [3][N]; last_shaping [N] (0 = none, like the

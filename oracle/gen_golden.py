@@ -270,6 +270,38 @@ def load_pid_classes(clipped=True):
     return ns
 
 
+def load_pidpos_classes():
+    tree = ast.parse(_src("environment/controller/PID_control.py"))
+    keep = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("pid_control", "pid")]
+    gains = [n for n in tree.body if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Tuple)
+             and getattr(n.targets[0].elts[0], "id", "") in ("P", "P_z", "P_a", "P_ps")]
+    ns = {"np": np}
+    exec(compile(ast.Module(gains + keep, []), "PID_control(ast)", "exec"), ns)
+    return ns
+
+
+def g14():
+    """PID_control.py:230-275 loop body on step / ramp targets from rest (trajectory tracking)."""
+    ns = load_pidpos_classes()
+    drone = make_env(t_step=0.01, n=5000, training=5, euler=0, direct_control=0)  # quad(0.01, 5000, 5, direct_control=0)
+    ns["drone"] = drone
+    ns["psi_d"] = 0
+    x0 = np.zeros(13); x0[6] = 1
+    with quiet:
+        drone.reset(x0)
+        controller = ns["pid_control"](drone)
+        rows, acts, tg = [], [], []
+        for j in range(600):
+            t = drone.i * drone.t_step
+            xd = np.array([1.0, -0.5, 0.8]) if j < 300 else np.array([1.0 + 0.5 * (t - 3), -0.5, 0.8])
+            dxd = np.zeros(3) if j < 300 else np.array([0.5, 0, 0])
+            action = controller.control(xd, dxd, 0, 0)
+            drone.step(action)
+            acts.append(np.array(action, dtype=float)); tg.append(np.concatenate([xd, dxd]))
+            rows.append(traj_record(drone))
+    save("g14_pidpos", x0=x0, traj=np.array(rows), actions=np.array(acts), targets=np.array(tg), cols=np.array(TRAJ_COLS))
+
+
 def load_lqr():
     tree = ast.parse(_src("environment/controller/lqr_quad.py"))
     design, body = [], None
@@ -510,6 +542,37 @@ def g10():
     save("g10_gae", **rec)
 
 
+def g15():
+    """PPO loss on a 512-sample batch: logprobs / values / entropy from the reference's own
+    ActorCritic.evaluate (model.py:74-85, N=16 weights, fp64), combined as ppo.py:185-203 does; the
+    gradients w.r.t. the policy mean and the value come from torch autograd on that same loss."""
+    pol, sd = load_policy(16, "nn_old_solved_16_32000_f6e38de2303f410f8e905d0f1c12add4.pth")
+    pol = ActorCritic(16, 75, 4, 0.1, True).double()
+    pol.load_state_dict({k: v for k, v in sd.items() if k != "std"}, strict=False)
+    rng = np.random.RandomState(115)
+    B = 512
+    obs = torch.from_numpy(rng.normal(0, 1, (B, 1, 75)))
+    mean = pol.actor(obs).detach().clone().requires_grad_(True)
+    value = pol.critic(obs).squeeze(-1).detach().clone().requires_grad_(True)   # [B,1]
+    std = float(pol.std)
+    actions = (mean + std * torch.from_numpy(rng.normal(0, 1, (B, 1, 4)))).detach()
+    old_mean = mean.detach() + 0.05 * torch.from_numpy(rng.normal(0, 1, (B, 1, 4)))
+    old_logprobs = torch.distributions.Normal(old_mean, torch.ones(4) * std).log_prob(actions)
+    adv = torch.from_numpy(rng.normal(0, 1, B)); rets = torch.from_numpy(rng.normal(0, 2, B))
+    dist = torch.distributions.Normal(mean, torch.ones(4) * std)   # as evaluate() builds it (model.py:79)
+    logprobs, ent = dist.log_prob(actions), dist.entropy()
+    ratios = torch.exp(logprobs.sum(axis=2).flatten() - old_logprobs.sum(axis=2).flatten())
+    a_loss = -torch.min(ratios * adv, torch.clamp(ratios, 0.8, 1.2) * adv)
+    c_loss = 0.5 * torch.nn.MSELoss()(value.flatten(), rets)
+    e_loss = -0.006 * ent.sum(axis=2).flatten()
+    total = (a_loss + c_loss + e_loss).mean()
+    total.backward()
+    save("g15_ppo_loss", mean=mean.detach().numpy()[:, 0], value=value.detach().numpy().ravel(), actions=actions.numpy()[:, 0],
+         old_logprob=old_logprobs.numpy()[:, 0], adv=adv.numpy(), returns=rets.numpy(), std=np.array(std),
+         loss=np.array(float(total)), actor=np.array(float(a_loss.mean())), critic=np.array(float(c_loss)),
+         entropy=np.array(float(e_loss.mean())), grad_mean=mean.grad.numpy()[:, 0], grad_value=value.grad.numpy().ravel())
+
+
 def g11():
     rng = np.random.RandomState(111)
     rows = []
@@ -538,6 +601,6 @@ def g11():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15"]
     for name in todo:
         globals()[name]()

@@ -145,6 +145,16 @@ def gae(values, masks, rewards, ddof):
     return ret, adv
 
 
+def ppo_loss(mean, value, actions, old_logprob, adv, returns, std, eps=0.2):
+    """[B,4] / [B] arrays -> (loss.mean(), mean actor, critic_loss, mean entropy term)."""
+    mean, actions, old_logprob = _a(mean), _a(actions), _a(old_logprob)
+    value, adv, returns = _a(value), _a(adv), _a(returns)
+    out = np.zeros(4)
+    lib().qo_ppo_loss(int(adv.size), _p(mean), _p(value), _p(actions), _p(old_logprob), _p(adv), _p(returns),
+                      C.c_double(float(std)), C.c_double(float(eps)), _p(out))
+    return out
+
+
 def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, ang, v_ang):
     out = np.zeros(4)
     ls = 0.0 if last_shaping is None else float(last_shaping)
@@ -297,6 +307,21 @@ class OraclePid:
     def control(self, xd, dxd, psd, dpsd):
         a = np.zeros(4)
         lib().qo_pid_action(C.byref(self._c), C.byref(self.env._e), _p(_a(xd, 3)), C.c_double(float(psd)), _p(a))
+        return a
+
+
+class OraclePidPos:
+    """pid_control of environment/controller/PID_control.py:29-106 (position tracking)."""
+
+    def __init__(self, env):
+        self.env = env
+        self._c = _Pid()
+        lib().qo_pidpos_init(C.byref(self._c))
+
+    def control(self, xd, dxd, psd, dpsd):
+        a = np.zeros(4)
+        lib().qo_pidpos_action(C.byref(self._c), C.byref(self.env._e), _p(_a(xd, 3)), _p(_a(dxd, 3)),
+                               C.c_double(float(psd)), _p(a))
         return a
 
 

@@ -365,3 +365,29 @@ def test_full_size_lqr_config3_statistics(aq, oracle):
     tame = np.isfinite(ref).all(1) & (np.abs(ref[:, 10:13]).max(1) < 1.0)
     assert tame.mean() > 0.6
     assert scaled_err(_np(env.state[:, :sub]).T[tame], ref[tame]) < 2e-2
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-9), ("f32", 5e-3)])
+def test_pidpos_tracking_golden(aq, dt, tol):
+    """G14: PID_control.py position PD tracking a step then a ramp target, 600 steps."""
+    g = golden("g14_pidpos")
+    env = aq.BatchedQuad(2, 0.01, 5000, training=True, direct_control=0, T=1, dtype=DT[dt])
+    env.reset(_dev(np.repeat(g["x0"][:, None], 2, 1), dt))
+    ctl = aq.PidPosController(env)
+    rows = []
+    for j in range(600):
+        a = ctl.control(g["targets"][j, :3], g["targets"][j, 3:], 0, 0)
+        assert rel_err(_np(a)[:, 0], g["actions"][j], 1e-2) < tol * 10, j
+        env.step(a)
+        rows.append(_np(env.state)[:, 1])
+    assert scaled_err(np.array(rows), g["traj"][:, :13]) < tol
+    # constant-target fused rollout == step-by-step with the same target
+    e1 = aq.BatchedQuad(2, 0.01, 5000, training=True, direct_control=0, T=1, dtype=DT[dt])
+    e2 = aq.BatchedQuad(2, 0.01, 5000, training=True, direct_control=0, T=1, dtype=DT[dt])
+    for e_ in (e1, e2):
+        e_.reset(_dev(np.repeat(g["x0"][:, None], 2, 1), dt)); e_.pid_reset()
+    tgt = [1.0, -0.5, 0.8, 0, 0, 0, 0]
+    for j in range(50):
+        e1.step(e1.pidpos_action(tgt))
+    e2.rollout("pidpos", 50, action=tgt)
+    assert torch.equal(e1.state, e2.state)

@@ -184,3 +184,19 @@ def test_auto_reset_keeps_rings_in_phase_and_banks_returns(aq):
     assert int((env.episodes - ep_before).min()) >= 2  # n_max=12 (+T): every env timed out at least twice
     assert bool(torch.isfinite(env.state).all())
     assert float(ro.masks.min()) == 0.0 and float(ro.masks.max()) == 1.0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_ppo_loss_and_seed_gradients_golden(aq, dt):
+    """G15: loss of PPO.update (ppo.py:185-203) and d loss / d mean, d loss / d value against the reference's
+    evaluate() + torch autograd."""
+    g = golden("g15_ppo_loss")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    out = aq.ppo_loss(dev(g["mean"].T), dev(g["value"]), dev(g["actions"].T), dev(g["old_logprob"].T), dev(g["adv"]),
+                      dev(g["returns"]), float(g["std"]), with_grads=True)
+    tol = 2e-6 if dt == torch.float64 else 2e-5  # the reference itself mixes an fp32 scale tensor in (model.py:79)
+    for k in ("loss", "actor", "critic", "entropy"):
+        assert abs(float(out[k]) - float(g[k])) < tol * max(1.0, abs(float(g[k]))), k
+    assert np.max(np.abs(_np(out["grad_mean"]).T - g["grad_mean"])) < tol * 10
+    assert np.max(np.abs(_np(out["grad_value"]) - g["grad_value"])) < tol
+    assert float((out["grad_mean"] == 0).float().mean()) > 0.02  # some samples sit on the saturated clamp

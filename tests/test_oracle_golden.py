@@ -257,3 +257,27 @@ def test_g12_lqr_gains(oracle):
     for a in range(3):
         off[a, 2 * a:2 * a + 2] = 0
     assert np.max(np.abs(off)) < 1e-9
+
+
+def test_g14_pidpos_tracking(oracle):
+    """PID_control.py position PD (step then ramp target) against the reference's own classes."""
+    g = golden("g14_pidpos")
+    env = oracle.OracleQuad(0.01, 5000, training=True, direct_control=0, T=1)
+    env.reset(g["x0"])
+    ctl = oracle.OraclePidPos(env)
+    rows = []
+    for j in range(600):
+        a = ctl.control(g["targets"][j, :3], g["targets"][j, 3:], 0, 0)
+        assert rel_err(a, g["actions"][j], 1e-2) < 1e-7, j
+        env.step(a)
+        rows.append(_rec(env))
+    _cmp_traj(rows, g, 1e-9, 1e-7)
+
+
+def test_g15_ppo_loss(oracle):
+    g = golden("g15_ppo_loss")
+    out = oracle.ppo_loss(g["mean"], g["value"], g["actions"], g["old_logprob"], g["adv"], g["returns"], float(g["std"]))
+    # model.py:79 builds Normal(mean_fp64, torch.ones(4) * std) with a FLOAT32 scale tensor, so torch forms
+    # scale**2 and log(scale) in fp32: the reference's own numbers carry ~1e-7 of that; the oracle is fp64
+    assert abs(out[0] - g["loss"]) < 2e-6 and abs(out[1] - g["actor"]) < 2e-6
+    assert abs(out[2] - g["critic"]) < 1e-12 and abs(out[3] - g["entropy"]) < 1e-8
