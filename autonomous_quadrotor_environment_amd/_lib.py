@@ -55,6 +55,7 @@ SYMBOLS = {
     "qenv_pidpos_action": (_i, [_vp, _dptr, _vp]),
     "qenv_window_push": (_i, [_vp, _vp, _vp, _i]),
     "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

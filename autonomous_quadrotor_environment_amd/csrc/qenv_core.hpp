@@ -59,6 +59,20 @@ template <> struct Mth<double> {
     static __device__ __forceinline__ double ulp_up(double t) { return nextafter(t, (double)INFINITY) - t; }
 };
 
+// Two envs per lane: every add/mul/fma of the integrator becomes ONE packed instruction
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) working on both.  Measured on MI355X: a wave64 fp32
+// VALU instruction issues every ~4 cycles per SIMD whatever the occupancy (profiles/), so the only way
+// to the chip's fp32 vector peak is two floats per lane per instruction.
+using F2 = float __attribute__((ext_vector_type(2)));
+template <> struct Mth<F2> {
+    static __device__ __forceinline__ F2 sqrt(F2 x) { return F2{__fsqrt_rn(x.x), __fsqrt_rn(x.y)}; }
+    static __device__ __forceinline__ F2 rsqrt(F2 x) { return F2{rsqrtf(x.x), rsqrtf(x.y)}; }
+    static __device__ __forceinline__ F2 rcp(F2 x) { return F2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+    static __device__ __forceinline__ F2 abs(F2 x) { return __builtin_elementwise_abs(x); }
+    static __device__ __forceinline__ F2 max(F2 a, F2 b) { return __builtin_elementwise_max(a, b); }
+    static __device__ __forceinline__ F2 min(F2 a, F2 b) { return __builtin_elementwise_min(a, b); }
+};
+
 // ---- physical constants (quadrotor_env.py:30-81), folded at compile time ----------------
 namespace phys {
 constexpr double M = 1.03, G = 9.82, RHO = 1.2041, C_D = 1.1;
@@ -319,6 +333,104 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
     for (int i = 0; i < 13; ++i) kq[i] = k1[i];
 }
 
+// The same solve_ivp restatement for the two envs of a lane: the heavy part (RHS evaluations, stage
+// combinations, error norm) is packed; the step-size control is scalar per env and drives per-env
+// selects.  Each env follows exactly the instruction sequence of the scalar version (an env that has
+// reached t_bound idles with h = 0 while its partner finishes), so results are bit-identical to it.
+__device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, F2 cm_xy, F2 cm_z, float tb, F2 kq[13],
+                                                  F2 dy[13]) {
+    using m = Mth<float>;
+    using m2 = Mth<F2>;
+    constexpr int MAX_ATTEMPTS = 96;
+    F2 k1[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) dy[i] = F2{0.f, 0.f};
+    rhs(y, u, cm_xy, cm_z, k1);
+    float h_abs[2];
+    {
+        F2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+        F2 isc[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            isc[i] = m2::rcp(F2(1e-6f) + m2::abs(y[i]) * F2(1e-3f));
+            const F2 a = y[i] * isc[i], b = k1[i] * isc[i];
+            d0 += a * a;
+            d1 += b * b;
+        }
+        d0 = m2::sqrt(d0 * F2((float)(1.0 / 13))); d1 = m2::sqrt(d1 * F2((float)(1.0 / 13)));
+        float h0[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            h0[c] = (d0[c] < 1e-5f || d1[c] < 1e-5f) ? 1e-6f : m::div_ctl(0.01f * d0[c], d1[c]);
+            h0[c] = m::min(h0[c], tb);
+        }
+        const F2 h0v = {h0[0], h0[1]};
+        F2 y1[13], f1[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h0v * k1[i];
+        rhs(y1, u, cm_xy, cm_z, f1);
+        F2 d2 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const F2 a = (f1[i] - k1[i]) * isc[i];
+            d2 += a * a;
+        }
+        d2 = m2::sqrt(d2 * F2((float)(1.0 / 13)));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float d2c = m::div_ctl(d2[c], h0[c]);
+            float h1;
+            if (d1[c] <= 1e-15f && d2c <= 1e-15f) h1 = m::max(1e-6f, h0[c] * 1e-3f);
+            else h1 = m::pow_ctl(m::div_ctl(0.01f, m::max(d1[c], d2c)), 0.2f);
+            h_abs[c] = m::min(m::min(100.f * h0[c], h1), tb);
+        }
+    }
+    float t[2] = {0.f, 0.f};
+    bool rejected[2] = {false, false}, failed[2] = {false, false};
+    for (int it = 0; it < MAX_ATTEMPTS && ((t[0] < tb && !failed[0]) || (t[1] < tb && !failed[1])); ++it) {
+        float h[2], t_new[2];
+        bool act[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            act[c] = t[c] < tb && !failed[c];
+            const float min_step = 10.f * m::ulp_up(t[c]);
+            if (act[c] && !rejected[c] && h_abs[c] < min_step) h_abs[c] = min_step;
+            if (act[c] && h_abs[c] < min_step) { failed[c] = true; act[c] = false; }  // TOO_SMALL_STEP
+            t_new[c] = t[c] + h_abs[c];
+            if (t_new[c] > tb) t_new[c] = tb;
+            h[c] = act[c] ? t_new[c] - t[c] : 0.f;
+            if (act[c]) h_abs[c] = h[c];
+        }
+        if (!act[0] && !act[1]) break;
+        F2 yn[13], k7[13], inc[13];
+        const F2 err2 = dp5_step<F2, true>(y, k1, u, cm_xy, cm_z, F2{h[0], h[1]}, yn, k7, inc);
+        bool accept[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float err = m::sqrt(err2[c] * (float)(1.0 / 13));
+            accept[c] = act[c] && err < 1.f;
+            if (accept[c]) {
+                float factor = (err == 0.f) ? 10.f : m::min(10.f, 0.9f * m::pow_ctl(err, -0.2f));
+                if (rejected[c]) factor = m::min(1.f, factor);
+                h_abs[c] *= factor;
+                t[c] = t_new[c];
+                rejected[c] = false;
+            } else if (act[c]) {
+                h_abs[c] *= m::max(0.2f, 0.9f * m::pow_ctl(err, -0.2f));
+                rejected[c] = true;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            y[i] = F2{accept[0] ? yn[i].x : y[i].x, accept[1] ? yn[i].y : y[i].y};
+            k1[i] = F2{accept[0] ? k7[i].x : k1[i].x, accept[1] ? k7[i].y : k1[i].y};
+            dy[i] = F2{accept[0] ? dy[i].x + inc[i].x : dy[i].x, accept[1] ? dy[i].y + inc[i].y : dy[i].y};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) kq[i] = k1[i];
+}
+
 template <typename T>
 __device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13]) {
     T k1[13], yn[13];
@@ -360,6 +472,13 @@ __device__ __forceinline__ void integrate(T y[13], const Act<T>& u, T cm_xy, T c
     if (INTEG == INT_RK45) integrate_rk45(y, u, cm_xy, cm_z, tb, kq, dy);
     else if (INTEG == INT_DP5) integrate_dp5(y, u, cm_xy, cm_z, tb, kq, dy);
     else integrate_rk4(y, u, cm_xy, cm_z, tb, kq, dy);
+}
+
+template <int INTEG>
+__device__ __forceinline__ void integrate2(F2 y[13], const Act<F2>& u, F2 cm_xy, F2 cm_z, float tb, F2 kq[13], F2 dy[13]) {
+    if constexpr (INTEG == INT_RK45) integrate_rk45_x2(y, u, cm_xy, cm_z, tb, kq, dy);
+    else if constexpr (INTEG == INT_DP5) integrate_dp5<F2>(y, u, cm_xy, cm_z, F2{tb, tb}, kq, dy);
+    else integrate_rk4<F2>(y, u, cm_xy, cm_z, F2{tb, tb}, kq, dy);
 }
 
 // ---- per-env bookkeeping carried between steps (registers in fused rollouts) -------------

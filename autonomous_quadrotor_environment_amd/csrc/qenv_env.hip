@@ -223,6 +223,110 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
     }
 }
 
+// ---- two envs per lane (fp32, even N): the integrator runs on packed float2 math -----------------
+// Lane g owns envs 2g and 2g+1 (adjacent in every row: one 8-byte load/store per row per lane, 512 B
+// per wave).  Mixing, Euler angles, done/reward and the controllers are evaluated per env with the
+// scalar code; only the integrator -- >90% of the instructions -- is packed.
+template <int INTEG, int CTRL>
+__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutArgs<float> a) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t N = a.N;
+    if (2 * g >= N) return;
+    const Cfg<float>& cfg = a.cfg;
+    const float2* ws2 = reinterpret_cast<const float2*>(a.ws);
+    const int64_t N2 = N / 2;
+    F2 y[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) { const float2 v = ws2[(int64_t)(ROW_STATE + k) * N2 + g]; y[k] = F2{v.x, v.y}; }
+    const bool dyn_only = a.mode == QENV_STEP_DYNAMICS_ONLY;
+    Book<float> bk[2];
+    PidState<float> ps[2];
+    if (!dyn_only) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            load_book(a.ws, a.wsi, N, 2 * g + c, true, bk[c]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bk[c].ang_vel[k] = ld(a.ws, ROW_ANG_VEL + k, N, 2 * g + c);
+            if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { ps[c].ix[k] = ld(a.ws, ROW_PID + k, N, 2 * g + c); ps[c].x_old[k] = ld(a.ws, ROW_PID + 6 + k, N, 2 * g + c); }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ps[c].ang_d_ant[k] = ld(a.ws, ROW_PID + 12 + k, N, 2 * g + c);
+            }
+        }
+    }
+    float w[2][4], effort[2][4], cl[2][4], act[2][4], raw[4];
+    Act<float> us[2];
+    Act<F2> u;
+    if (CTRL == QENV_CTRL_CONST) {
+        prepare_action(a.const_action, cfg, w[0], effort[0], cl[0], act[0], us[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w[1][k] = w[0][k]; effort[1][k] = effort[0][k]; cl[1][k] = cl[0][k]; act[1][k] = act[0][k]; }
+        u.F = F2{us[0].F, us[0].F}; u.Mx = F2{us[0].Mx, us[0].Mx}; u.My = F2{us[0].My, us[0].My};
+        u.Mz = F2{us[0].Mz, us[0].Mz}; u.omr = F2{us[0].omr, us[0].omr};
+    }
+    const F2 cm_xy = {cfg.cm_xy, cfg.cm_xy}, cm_z = {cfg.cm_z, cfg.cm_z};
+    bool ang_ok = a.ang_ok != 0;
+    F2 kq[13], dy[13];
+    for (int s = 0; s < a.n_steps; ++s) {
+        if (CTRL != QENV_CTRL_CONST) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float yc[13];
+#pragma unroll
+                for (int k = 0; k < 13; ++k) yc[k] = y[k][c];
+                if (CTRL == QENV_CTRL_LQR) lqr_law(yc, bk[c], a.lqr, raw);
+                else if (CTRL == QENV_CTRL_PID) {
+                    if (s == 0 && a.pid_first) { raw[0] = float(phys::M * phys::G); raw[1] = raw[2] = raw[3] = 0.f; }
+                    else pid_law(yc, bk[c], a.pid, ps[c], a.pid_target, cfg.t_step, raw);
+                } else pidpos_law(yc, bk[c], ps[c], a.pid_target, cfg.t_step, raw);
+                prepare_action(raw, cfg, w[c], effort[c], cl[c], act[c], us[c]);
+            }
+            u.F = F2{us[0].F, us[1].F}; u.Mx = F2{us[0].Mx, us[1].Mx}; u.My = F2{us[0].My, us[1].My};
+            u.Mz = F2{us[0].Mz, us[1].Mz}; u.omr = F2{us[0].omr, us[1].omr};
+        }
+        const F2 q_old[4] = {y[6], y[7], y[8], y[9]};
+        integrate2<INTEG>(y, u, cm_xy, cm_z, cfg.t_step, kq, dy);
+        if (!dyn_only) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float yc[13], dyc[13];
+#pragma unroll
+                for (int k = 0; k < 13; ++k) { yc[k] = y[k][c]; dyc[k] = dy[k][c]; }
+                const float qo[4] = {q_old[0][c], q_old[1][c], q_old[2][c], q_old[3][c]};
+                bk[c].i += 1;
+                euler_update(qo, yc, dyc, ang_ok && (bk[c].flags & FLAG_ANG_OK), cfg, bk[c]);
+                done_reward(yc, act[c], effort[c], cfg, bk[c]);
+            }
+            ang_ok = true;
+        }
+    }
+    float2* wso = reinterpret_cast<float2*>(a.ws);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) wso[(int64_t)(ROW_STATE + k) * N2 + g] = make_float2(y[k].x, y[k].y);
+    if (dyn_only) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int64_t e = 2 * g + c;
+        store_book(a.ws, a.wsi, N, e, bk[c], true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st(a.ws, ROW_VQ + k, N, e, kq[6 + k][c]);
+            st(a.ws, ROW_W + k, N, e, w[c][k]);
+            st(a.ws, ROW_EFFORT + k, N, e, effort[c][k]);
+            st(a.ws, ROW_CLIPPED + k, N, e, cl[c][k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st(a.ws, ROW_ACCEL + k, N, e, kq[1 + 2 * k][c]);
+        if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { st(a.ws, ROW_PID + k, N, e, ps[c].ix[k]); st(a.ws, ROW_PID + 6 + k, N, e, ps[c].x_old[k]); }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) st(a.ws, ROW_PID + 12 + k, N, e, ps[c].ang_d_ant[k]);
+        }
+    }
+}
+
 // quad.reset front half (quadrotor_env.py:428-445): load initial states, clear counters.
 template <typename T>
 __global__ __launch_bounds__(256) void k_reset(T* ws, int32_t* wsi, int64_t N, const T* init, const uint8_t* mask) {
@@ -442,6 +546,18 @@ template <typename T> static int do_step(qenv_s* q, const void* actions, const u
 }
 
 template <typename T, int INTEG> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T>& a) {
+    if constexpr (sizeof(T) == 4) {
+        if (q->packed && (q->N % 2) == 0) {  // two envs per lane, packed fp32 integrator
+            const dim3 g2 = grid_for(q->N / 2), b2(256);
+            switch (controller) {
+                case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_CONST>), g2, b2, 0, q->stream, a); break;
+                case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_LQR>), g2, b2, 0, q->stream, a); break;
+                case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_PIDPOS>), g2, b2, 0, q->stream, a); break;
+                default: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_PID>), g2, b2, 0, q->stream, a); break;
+            }
+            return;
+        }
+    }
     const dim3 g = grid_for(q->N), b(256);
     switch (controller) {
         case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_CONST>), g, b, 0, q->stream, a); break;
@@ -528,6 +644,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->window = (float*)((char*)workspace + L.win_off);
     q->win_head = 0;
     q->ang_ok = 0;
+    q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : 0;  // developer A/B switch
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
     if (e != hipSuccess) { delete q; return fail_hip(e, "hipMemsetAsync(workspace)"); }
     *out = q;

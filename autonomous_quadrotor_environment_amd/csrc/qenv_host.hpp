@@ -60,6 +60,7 @@ struct qenv_s {
     int32_t* wsi;
     float* window;
     int32_t win_head;  // ring slot the next push writes
+    int32_t packed;    // 1: fused rollouts use the two-envs-per-lane packed-fp32 kernels
     int32_t ang_ok;    // 1: no dynamics-only step since the last unmasked full step (see euler_update)
     hipStream_t stream;
 };

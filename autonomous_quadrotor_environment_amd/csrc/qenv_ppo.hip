@@ -238,6 +238,118 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     return check_launch("k_mlp");
 }
 
+// ---- dense tail of rl_nn_model.py: K -> H -> H -> n_out with K too large for LDS-resident W1 ------
+// Same operand orientation as k_mlp.  W1 is streamed through LDS in chunks of KC input features (rows
+// padded by one word so the transposing staging writes are conflict-free); the four waves of a workgroup
+// march over the chunks together, each accumulating its own 32-env tile.
+struct DenseArgs {
+    const float* x;  // [K][N]
+    int64_t N;
+    int32_t K, n_out, final_tanh;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    float* out;
+};
+
+template <int H>
+__global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
+    constexpr int NT = H / 32, KC = 64, LDW = H + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* W1c = lds;                   // [KC][H+1]
+    float* W2t = W1c + KC * LDW;        // [H][H]  k-major
+    float* W3t = W2t + H * H;           // [H][4]
+    float* b1s = W3t + 4 * H;
+    float* b2s = b1s + H;
+    float* b3s = b2s + H;
+    for (int idx = threadIdx.x; idx < H * H; idx += 256) { const int k = idx / H, h = idx % H; W2t[idx] = a.W2[(size_t)h * H + k]; }
+    for (int idx = threadIdx.x; idx < 4 * H; idx += 256) { const int h = idx / 4, o = idx % 4; W3t[idx] = o < a.n_out ? a.W3[(size_t)o * H + h] : 0.f; }
+    for (int h = threadIdx.x; h < H; h += 256) { b1s[h] = a.b1[h]; b2s[h] = a.b2[h]; }
+    if (threadIdx.x < 4) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (a.N + 31) / 32;
+    const int64_t rounds = (n_tiles + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4);
+    const uint32_t N32 = (uint32_t)a.N;
+    for (int64_t r = 0; r < rounds; ++r) {
+        const int64_t tile = (r * gridDim.x + blockIdx.x) * 4 + wave;
+        const int64_t e = tile * 32 + col;
+        const bool valid = tile < n_tiles && e < a.N;
+        const uint32_t e32 = (uint32_t)(valid ? e : a.N - 1);
+        f32x16 acc1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = 0.f;
+        for (int kc = 0; kc < a.K; kc += KC) {
+            __syncthreads();  // every wave is done with the previous chunk (and with the one-off staging above)
+            for (int idx = threadIdx.x; idx < KC * H; idx += 256) {
+                const int h = idx / KC, k = idx % KC;  // global reads run along k (coalesced), LDS writes stride H+1 words
+                W1c[k * LDW + h] = (kc + k) < a.K ? a.W1[(size_t)h * a.K + kc + k] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s0 = 0; s0 < KC / 2; s0 += 8) {
+                float xs[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {  // 8 k-steps of activations in flight before the first MFMA needs one
+                    const int k = kc + 2 * (s0 + s) + half;
+                    const uint32_t kk = (uint32_t)(k < a.K ? k : a.K - 1);
+                    const float v = a.x[kk * N32 + e32];
+                    xs[s] = k < a.K ? v : 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1c[(2 * (s0 + s) + half) * LDW + 32 * t + col], xs[s], acc1[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j] + b1s[32 * t + acc_row(j, half)]);
+        float o3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2t[(32 * ti + acc_row(j, half)) * H + 32 * t + col], acc1[ti][j], acc2, 0, 0, 0);
+                    if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float hv = fast_tanh(acc2[j]);
+                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * (32 * t + acc_row(j, half))]);
+                o3[0] = fmaf(w3.x, hv, o3[0]); o3[1] = fmaf(w3.y, hv, o3[1]);
+                o3[2] = fmaf(w3.z, hv, o3[2]); o3[3] = fmaf(w3.w, hv, o3[3]);
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = o3[o] + __shfl_xor(o3[o], 32);
+            v += b3s[o];
+            if (a.final_tanh) v = tanhf(v);
+            if (valid && half == 0 && o < a.n_out) a.out[(int64_t)o * a.N + e] = v;
+        }
+    }
+}
+
+template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (64 * (H + 1) + H * H + 4 * H + 2 * H + 4);
+    hipError_t e = hipFuncSetAttribute((const void*)k_dense_tail<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_dense_tail)");
+    const int64_t n_tiles = (a.N + 31) / 32;
+    int64_t blocks = (n_tiles + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((k_dense_tail<H>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return check_launch("k_dense_tail");
+}
+
 // ---- counter-based RNG: Philox4x32-10 (Salmon et al. 2011) --------------------------------------
 // One call = 4 x 32 random bits as a pure function of (key, counter): any env/step can be drawn
 // independently, so streams are identical whatever the sharding or launch order.
@@ -507,6 +619,23 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
         case 128: return t5 ? launch_mlp<128, 5, 512, true>(a, 5, q->stream) : launch_mlp<128, 0, 512, true>(a, q->cfg.T, q->stream);
         case 256: return launch_mlp<256, 0, 256, false>(a, q->cfg.T, q->stream);
         default: return fail(QENV_ERR_ARG, "qenv_mlp_forward: hidden must be one of 16, 32, 64, 128, 256");
+    }
+}
+
+int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float* x, const float* W1,
+                    const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* out,
+                    void* stream) {
+    if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_dense_tail: null argument");
+    if (n <= 0 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_dense_tail: bad sizes");
+    if ((int64_t)k_in * n >= ((int64_t)1 << 31)) return fail(QENV_ERR_ARG, "qenv_dense_tail: K*n must stay below 2^31");
+    DenseArgs a;
+    a.x = x; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
+    switch (hidden) {
+        case 32: return launch_dense<32>(a, (hipStream_t)stream);
+        case 64: return launch_dense<64>(a, (hipStream_t)stream);
+        case 128: return launch_dense<128>(a, (hipStream_t)stream);
+        default: return fail(QENV_ERR_ARG, "qenv_dense_tail: hidden must be 32, 64 or 128");
     }
 }
 

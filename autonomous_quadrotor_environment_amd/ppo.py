@@ -127,6 +127,21 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True):
     return ret, adv
 
 
+def dense_tail(x, weights, final_tanh=True, out=None):
+    """Dense tail of visual_landing/rl_nn_model.py (:58-66): Linear(K,H) tanh Linear(H,H) tanh Linear(H,n_out)
+    [tanh] on feature-major float32 x [K, N]; weights = [W1, b1, W2, b2, W3, b3] float32 device tensors in
+    torch layout.  Returns [n_out, N]."""
+    W1, b1, W2, b2, W3, b3 = [w.to(device=x.device, dtype=torch.float32).contiguous() for w in weights]
+    K, N = x.shape
+    assert W1.shape[1] == K and x.dtype == torch.float32
+    x = x.contiguous()
+    out = torch.empty(W3.shape[0], N, device=x.device, dtype=torch.float32) if out is None else out
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    L.check(L.lib.qenv_dense_tail(N, K, W1.shape[0], W3.shape[0], int(bool(final_tanh)), L.ptr(x), L.ptr(W1), L.ptr(b1),
+                                  L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), stream), "qenv_dense_tail")
+    return out
+
+
 def ppo_loss(mean, value, actions, old_logprob, adv, returns, std, eps_clip=0.2, c_value=0.5, c_entropy=0.006,
              with_grads=False):
     """Loss of PPO.update (ppo.py:185-203) for a batch: mean/actions/old_logprob [4, B], value/adv/returns [B].

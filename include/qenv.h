@@ -206,6 +206,15 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
                      const float *b1, const float *W2, const float *b2, const float *W3,
                      const float *b3, void *out, float *obs_store);
 
+/* Dense tail of the legacy landing policy (visual_landing/rl_nn_model.py:58-66 actor, :77-84 critic):
+ * Linear(K,H) tanh Linear(H,H) tanh Linear(H,n_out) [tanh] on flattened conv features (K = 800, H = 64,
+ * n_out = 3 / 1) -- the GEMM-shaped part of that model; its conv front-end needs rendered camera images
+ * and is out of scope.  x float32 [K][N] (feature-major), weights float32 torch layout, H in {32, 64, 128},
+ * n_out <= 4, out float32 [n_out][N].  fp32 MFMA, W1 streamed through LDS in K-chunks. */
+int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float *x,
+                    const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                    const float *b3, float *out, void *stream);
+
 /* Replaces ActorCritic.act's sampling (model.py:62-68): action = mean + std * eps,
  * logprob = Normal(mean, std).log_prob(action) per dimension.
  *   mean [4][N]; noise nullable [4][N] standard normal in the handle's dtype (injected, so a

@@ -200,3 +200,22 @@ def test_ppo_loss_and_seed_gradients_golden(aq, dt):
     assert np.max(np.abs(_np(out["grad_mean"]).T - g["grad_mean"])) < tol * 10
     assert np.max(np.abs(_np(out["grad_value"]) - g["grad_value"])) < tol
     assert float((out["grad_mean"] == 0).float().mean()) > 0.02  # some samples sit on the saturated clamp
+
+
+def test_dense_tail_rl_nn_model_shape(aq, oracle):
+    """rl_nn_model.py dense tail 800 -> 64 -> 64 -> 3 (tanh x3) and its critic twin (-> 1, no final tanh) on
+    synthetic U(-1,1) features, against the fp64 oracle MLP; ragged N."""
+    rng = np.random.RandomState(9)
+    for K, H, n_out, ft, N in ((800, 64, 3, True, 1000), (800, 64, 1, False, 37), (130, 32, 4, True, 4096), (75, 128, 4, True, 333)):
+        def lin(o, i):
+            b = 1.0 / np.sqrt(i)
+            return rng.uniform(-b, b, (o, i)), rng.uniform(-b, b, o)
+        W1, b1 = lin(H, K); W2, b2 = lin(H, H); W3, b3 = lin(n_out, H)
+        x = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+        w = [torch.from_numpy(v).float().cuda() for v in (W1, b1, W2, b2, W3, b3)]
+        got = _np(aq.dense_tail(torch.from_numpy(x).cuda(), w, final_tanh=ft)).T
+        ref = oracle.mlp_forward(x.T.astype(np.float64), W1.astype(np.float32).astype(np.float64), b1.astype(np.float32).astype(np.float64),
+                                 W2.astype(np.float32).astype(np.float64), b2.astype(np.float32).astype(np.float64),
+                                 W3.astype(np.float32).astype(np.float64), b3.astype(np.float32).astype(np.float64), ft)
+        assert got.shape == (N, n_out)
+        assert np.max(np.abs(got - ref)) < 5e-6, (K, H, n_out, np.max(np.abs(got - ref)))

@@ -1,0 +1,39 @@
+"""Developer A/B (GPU box): packed two-envs-per-lane rollout kernels vs the scalar ones:
+bit-equality of results and env-steps/s."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from autonomous_quadrotor_environment_amd import BatchedQuad
+from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+
+def make(n, integ, packed, direct=1, init="config2"):
+    os.environ["QENV_PACKED"] = "1" if packed else "0"
+    env = BatchedQuad(n, 0.01, 10**9, training=False, direct_control=direct, T=1, integrator=integ)
+    env.reset(torch.from_numpy(np.ascontiguousarray(bench.make_init(init, n, 0, n).T)))
+    return env
+
+for integ in ("rk45", "dp5", "rk4"):
+    for ctrl, direct, flags, init in (("const", 1, 1, "config2"), ("const", 1, 0, "config3"), ("lqr", 0, 0, "config3"), ("pid", 0, 0, "config3")):
+        a, b = make(4096, integ, False, direct, init), make(4096, integ, True, direct, init)
+        for e in (a, b):
+            if ctrl == "pid": e.pid_reset()
+            e.rollout(ctrl, 60, flags=flags)
+        same = torch.equal(a.state, b.state) and (flags == 1 or (torch.equal(a.flags, b.flags) and torch.equal(a.episode_return, b.episode_return) and torch.equal(a.ang_vel, b.ang_vel)))
+        md = float((a.state - b.state).abs().max())
+        print(integ, ctrl, "flags", flags, "bit-identical" if same else f"DIFFERENT maxdiff {md:.3e}", flush=True)
+for n in (65536, 1048576):
+    for integ in ("rk45", "dp5", "rk4"):
+        for packed in (False, True):
+            env = make(n, integ, packed)
+            run_, pc = bench.make_runner(env, "const", 1, "fused", 100, False)
+            bench.time_region(run_, pc, 100, 1, env.device)
+            s = bench.time_region(run_, pc, 400, 1, env.device)
+            print(json.dumps(dict(n=n, integ=integ, packed=packed, us_per_step=round(s / 400 * 1e6, 2), Gsteps=round(n * 400 / s / 1e9, 2))), flush=True)
+    for integ in ("rk45", "dp5"):
+        for packed in (False, True):
+            env = make(n, integ, packed, 0, "config3")
+            run_, pc = bench.make_runner(env, "lqr", 2, "fused", 100, False)
+            bench.time_region(run_, pc, 100, 1, env.device)
+            s = bench.time_region(run_, pc, 200, 1, env.device)
+            print(json.dumps(dict(n=n, workload="lqr", integ=integ, packed=packed, us_per_step=round(s / 200 * 1e6, 2), Gsteps=round(n * 200 / s / 1e9, 2))), flush=True)
