@@ -28,11 +28,13 @@ def init_process_group_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())  # rehearsals with more ranks than GPUs (gloo only)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("QENV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
