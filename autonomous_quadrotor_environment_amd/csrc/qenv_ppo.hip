@@ -7,6 +7,7 @@
 //   environment/controller/ppo.py:125-141, visual_landing/ppo_trainer.py:133-148   GAE
 //   visual_landing/rl_reward_fuction.py:3-102      visual_reward
 #include "qenv_host.hpp"
+#include "qenv_mlp_common.hpp"
 
 namespace qenv {
 
@@ -36,7 +37,6 @@ __global__ __launch_bounds__(256) void k_window_push(float* win, int64_t N, int 
 // across the lane halves as one k-step, reading the matching two weight columns.  No LDS
 // round trip, no shuffles between layers.  Weights are staged once per workgroup into LDS,
 // transposed to [k][h] so the 32 lanes of a half read 32 consecutive floats (conflict-free).
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct MlpArgs {
     const float* win;   // [15*T][N] ring
@@ -47,19 +47,6 @@ struct MlpArgs {
     int32_t out_f64;
     float* obs_store;   // null or [15*T][N]: the window in time order
 };
-
-__device__ __forceinline__ int acc_row(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }
-
-// tanh with ~1e-7 absolute error in ~12 VALU instructions (ocml's tanhf is ~3x that and the two
-// hidden layers need 256 of them per env): odd Taylor polynomial below 0.3 (next term < 2e-8),
-// 1 - 2/(exp(2|x|)+1) on v_exp_f32 / v_rcp_f32 above; saturates cleanly for large |x|.
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float ax = fabsf(x), x2 = x * x;
-    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
-    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    const float small = ax * (1.0f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f))));
-    return copysignf(ax < 0.3f ? small : big, x);
-}
 
 // K1 = 15*T window elements; TW > 0: compile-time window length (the whole observation of a tile
 // is prefetched into registers with back-to-back global loads before the first MFMA, and every
@@ -252,17 +239,17 @@ struct DenseArgs {
 
 template <int H>
 __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
-    constexpr int NT = H / 32, KC = 64, LDW = H + 1;
+    constexpr int HP = H < 32 ? 32 : H, NT = HP / 32, KC = 64, LDW = HP + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* W1c = lds;                   // [KC][H+1]
     float* W2t = W1c + KC * LDW;        // [H][H]  k-major
-    float* W3t = W2t + H * H;           // [H][4]
-    float* b1s = W3t + 4 * H;
-    float* b2s = b1s + H;
-    float* b3s = b2s + H;
-    for (int idx = threadIdx.x; idx < H * H; idx += 256) { const int k = idx / H, h = idx % H; W2t[idx] = a.W2[(size_t)h * H + k]; }
-    for (int idx = threadIdx.x; idx < 4 * H; idx += 256) { const int h = idx / 4, o = idx % 4; W3t[idx] = o < a.n_out ? a.W3[(size_t)o * H + h] : 0.f; }
-    for (int h = threadIdx.x; h < H; h += 256) { b1s[h] = a.b1[h]; b2s[h] = a.b2[h]; }
+    float* W3t = W2t + HP * HP;         // [HP][4]
+    float* b1s = W3t + 4 * HP;
+    float* b2s = b1s + HP;
+    float* b3s = b2s + HP;
+    for (int idx = threadIdx.x; idx < HP * HP; idx += 256) { const int k = idx / HP, h = idx % HP; W2t[idx] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f; }
+    for (int idx = threadIdx.x; idx < 4 * HP; idx += 256) { const int h = idx / 4, o = idx % 4; W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f; }
+    for (int h = threadIdx.x; h < HP; h += 256) { b1s[h] = h < H ? a.b1[h] : 0.f; b2s[h] = h < H ? a.b2[h] : 0.f; }
     if (threadIdx.x < 4) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
@@ -281,9 +268,9 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
             for (int j = 0; j < 16; ++j) acc1[t][j] = 0.f;
         for (int kc = 0; kc < a.K; kc += KC) {
             __syncthreads();  // every wave is done with the previous chunk (and with the one-off staging above)
-            for (int idx = threadIdx.x; idx < KC * H; idx += 256) {
-                const int h = idx / KC, k = idx % KC;  // global reads run along k (coalesced), LDS writes stride H+1 words
-                W1c[k * LDW + h] = (kc + k) < a.K ? a.W1[(size_t)h * a.K + kc + k] : 0.f;
+            for (int idx = threadIdx.x; idx < KC * HP; idx += 256) {
+                const int h = idx / KC, k = idx % KC;  // global reads run along k (coalesced), LDS writes stride HP+1 words
+                W1c[k * LDW + h] = ((kc + k) < a.K && h < H) ? a.W1[(size_t)h * a.K + kc + k] : 0.f;
             }
             __syncthreads();
 #pragma unroll
@@ -317,7 +304,7 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2t[(32 * ti + acc_row(j, half)) * H + 32 * t + col], acc1[ti][j], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2t[(32 * ti + acc_row(j, half)) * HP + 32 * t + col], acc1[ti][j], acc2, 0, 0, 0);
                     if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -340,7 +327,8 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
 }
 
 template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (64 * (H + 1) + H * H + 4 * H + 2 * H + 4);
+    constexpr int HP = H < 32 ? 32 : H;
+    const size_t lds = sizeof(float) * (64 * (HP + 1) + HP * HP + 4 * HP + 2 * HP + 4);
     hipError_t e = hipFuncSetAttribute((const void*)k_dense_tail<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_dense_tail)");
     const int64_t n_tiles = (a.N + 31) / 32;
@@ -632,10 +620,11 @@ int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, 
     a.x = x; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     switch (hidden) {
+        case 16: return launch_dense<16>(a, (hipStream_t)stream);
         case 32: return launch_dense<32>(a, (hipStream_t)stream);
         case 64: return launch_dense<64>(a, (hipStream_t)stream);
         case 128: return launch_dense<128>(a, (hipStream_t)stream);
-        default: return fail(QENV_ERR_ARG, "qenv_dense_tail: hidden must be 32, 64 or 128");
+        default: return fail(QENV_ERR_ARG, "qenv_dense_tail: hidden must be 16, 32, 64 or 128");
     }
 }
 

@@ -1,0 +1,331 @@
+// qenv_train.hip -- the optimiser half of PPO.update (environment/controller/ppo.py:172-203,
+// visual_landing/ppo_trainer.py:96-131) for the 75-N-N-4 / 75-N-N-1 MLPs of model.py: backward pass of the
+// tanh MLP on the fp32 MFMA pipe, weight/bias gradients as split-K GEMMs over the samples, Adam.
+//
+// Sample layout = the rollout's time-major chunked SoA: sample (c, e) of a matrix with R rows lives at
+// base + (c*R + r)*N + e (chunk c = one rollout step, N envs).  Every kernel works on 32- or 64-sample
+// tiles that never straddle a chunk.
+#include "qenv_host.hpp"
+#include "qenv_mlp_common.hpp"
+
+namespace qenv {
+
+struct BwdArgs {
+    int64_t N;          // envs per chunk
+    int32_t n_chunks, K, n_out, final_tanh;
+    const float* obs;   // [c][K][N]
+    const float* seed;  // [c][n_out][N]  d loss / d output
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    float *h1, *h2, *dz2, *dz1;  // [c][H][N] each
+    float* dz3;                  // [c][4][N]
+};
+
+// Forward (recomputed) + backward through the activations for one 32-sample tile per wave:
+//   H1 = tanh(W1 x + b1), H2 = tanh(W2 H1 + b2), out = [tanh](W3 H2 + b3)
+//   dz3 = seed * (1 - out^2 | 1), dZ2 = (W3^T dz3) * (1 - H2^2), dZ1 = (W2^T dZ2) * (1 - H1^2)
+// Same operand orientation as k_mlp (accumulator tile = next B operand); W2 is kept ONCE in LDS as
+// [k = input][h = output] with rows padded by one word so both the forward read (32 consecutive h) and the
+// transposed backward read (stride H+1) are bank-conflict free.
+// H = 128 keeps 2 x 64 activation registers + the gradient tile live: 256-thread workgroups (one wave per
+// SIMD, 512 registers) instead of spilling 1.6 KB/lane under the 256-register cap of 512 threads.
+template <int H>
+__global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs a) {
+    constexpr int HP = H < 32 ? 32 : H, NT = HP / 32, LD2 = HP + 1;
+    constexpr int BLOCK = H >= 128 ? 256 : 512, WPB = BLOCK / 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K1 = a.K, K1P = (K1 + 1) & ~1;
+    float* W1t = lds;                        // [K1P][HP]
+    float* W2t = W1t + (size_t)K1P * HP;     // [HP][HP+1]: W2t[k*LD2 + h] = W2[h][k]
+    float* W3t = W2t + (size_t)HP * LD2;     // [HP][4]
+    float* b1s = W3t + 4 * HP;
+    float* b2s = b1s + HP;
+    float* b3s = b2s + HP;
+    for (int idx = threadIdx.x; idx < K1P * HP; idx += BLOCK) {
+        const int k = idx / HP, h = idx % HP;
+        W1t[idx] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < HP * HP; idx += BLOCK) {
+        const int k = idx / HP, h = idx % HP;
+        W2t[k * LD2 + h] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < 4 * HP; idx += BLOCK) {
+        const int h = idx / 4, o = idx % 4;
+        W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
+    }
+    for (int h = threadIdx.x; h < HP; h += BLOCK) { b1s[h] = h < H ? a.b1[h] : 0.f; b2s[h] = h < H ? a.b2[h] : 0.f; }
+    if (threadIdx.x < 4) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles_per_chunk = (a.N + 31) / 32, n_tiles = tiles_per_chunk * a.n_chunks;
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
+        asm volatile("" ::: "memory");  // keep the (tile-invariant) LDS reads inside the loop (see k_mlp)
+        const int64_t c = tile / tiles_per_chunk, e = (tile % tiles_per_chunk) * 32 + col;
+        const bool valid = e < a.N;
+        const int64_t ec = valid ? e : a.N - 1;
+        const float* x = a.obs + (size_t)c * K1 * a.N + ec;
+        f32x16 h1[NT], h2[NT];
+        // ---- layer 1
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) h1[t][j] = b1s[32 * t + acc_row(j, half)];
+        for (int s0 = 0; s0 < K1P / 2; s0 += 8) {
+            float xs[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int k = 2 * (s0 + s) + half;
+                const float v = x[(size_t)(k < K1 ? k : K1 - 1) * a.N];
+                xs[s] = (k < K1 && 2 * (s0 + s) < K1P) ? v : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int kk = 2 * (s0 + s) + half;
+                if (2 * (s0 + s) < K1P) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[kk * HP + 32 * t + col], xs[s], h1[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) h1[t][j] = fast_tanh(h1[t][j]);
+        // ---- layer 2 (+ layer-3 partial sums)
+        float o3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) h2[t][j] = b2s[32 * t + acc_row(j, half)];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    h2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W2t[(32 * ti + acc_row(j, half)) * LD2 + 32 * t + col], h1[ti][j], h2[t], 0, 0, 0);
+                    if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                h2[t][j] = fast_tanh(h2[t][j]);
+                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * (32 * t + acc_row(j, half))]);
+                o3[0] = fmaf(w3.x, h2[t][j], o3[0]); o3[1] = fmaf(w3.y, h2[t][j], o3[1]);
+                o3[2] = fmaf(w3.z, h2[t][j], o3[2]); o3[3] = fmaf(w3.w, h2[t][j], o3[3]);
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- output and its pre-activation gradient (both lane halves hold the same 4 numbers)
+        float dz3[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = o3[o] + __shfl_xor(o3[o], 32) + b3s[o];
+            if (a.final_tanh) v = tanhf(v);
+            const float sd = o < a.n_out ? a.seed[((size_t)c * a.n_out + o) * a.N + ec] : 0.f;
+            dz3[o] = a.final_tanh ? sd * (1.f - v * v) : sd;
+            if (valid && half == 0) a.dz3[((size_t)c * 4 + o) * a.N + e] = dz3[o];
+        }
+        // ---- store H1, H2; dZ2 = (W3^T dz3) (1 - H2^2) in place of H2
+        const size_t rowbase = (size_t)c * H * a.N + ec;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int h = 32 * t + acc_row(j, half);
+                if (valid && h < H) {
+                    a.h1[rowbase + (size_t)h * a.N] = h1[t][j];
+                    a.h2[rowbase + (size_t)h * a.N] = h2[t][j];
+                }
+                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * h]);
+                const float g = w3.x * dz3[0] + w3.y * dz3[1] + w3.z * dz3[2] + w3.w * dz3[3];
+                h2[t][j] = g * (1.f - h2[t][j] * h2[t][j]);
+                if (valid && h < H) a.dz2[rowbase + (size_t)h * a.N] = h2[t][j];
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- dH1 = W2^T dZ2 on the MFMA pipe, one output tile at a time; dZ1 = dH1 (1 - H1^2)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 d;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d[j] = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    // A[i = h1 row][k = h2] = W2[h2][h1] = W2t[h1 * LD2 + h2]
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(W2t[(32 * t + col) * LD2 + 32 * ti + acc_row(j, half)], h2[ti][j], d, 0, 0, 0);
+                    if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int h = 32 * t + acc_row(j, half);
+                const float g = d[j] * (1.f - h1[t][j] * h1[t][j]);
+                if (valid && h < H) a.dz1[rowbase + (size_t)h * a.N] = g;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- weight gradients: C[M][Nn] += sum over samples A[m][s] * B[n][s]  (+ row sums of A = bias gradients)
+struct WgradArgs {
+    int64_t N;
+    int32_t n_chunks, M, Nn;
+    const float *A, *B;  // chunked [c][M][N], [c][Nn][N]
+    float* C;            // [M][Nn] row-major, accumulated with atomics
+    float* rowsum;       // [M] or null
+};
+
+// One workgroup walks a strided set of 64-sample tiles: both operand tiles are staged in LDS ([row][65]: the
+// 64-sample rows are written coalesced, the MFMA operands -- 32 rows at a fixed sample -- read stride 65,
+// conflict free); each of the 4 waves owns up to MT*NT/4 of the 32x32 output tiles in registers for the
+// whole walk and adds them to C once at the end.
+template <int MT, int NTN>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
+    constexpr int LD = 65, TPW = (MT * NTN + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                 // [MT*32][65]
+    float* Bs = As + MT * 32 * LD;   // [NTN*32][65]
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles_per_chunk = (a.N + 63) / 64, n_tiles = tiles_per_chunk * a.n_chunks;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
+    float rs = 0.f;  // thread r < M accumulates row r's sum
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t c = tile / tiles_per_chunk, e0 = (tile % tiles_per_chunk) * 64;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < MT * 32 * 64; idx += 256) {
+            const int r = idx >> 6, sidx = idx & 63;
+            As[r * LD + sidx] = (r < a.M && e0 + sidx < a.N) ? a.A[((size_t)c * a.M + r) * a.N + e0 + sidx] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < NTN * 32 * 64; idx += 256) {
+            const int r = idx >> 6, sidx = idx & 63;
+            Bs[r * LD + sidx] = (r < a.Nn && e0 + sidx < a.N) ? a.B[((size_t)c * a.Nn + r) * a.N + e0 + sidx] : 0.f;
+        }
+        __syncthreads();
+        if (a.rowsum && (int)threadIdx.x < a.M) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int sidx = 0; sidx < 64; ++sidx) sacc += As[threadIdx.x * LD + sidx];
+            rs += sacc;
+        }
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int tid = wave * TPW + q;
+            if (tid < MT * NTN) {
+                const int tm = tid / NTN, tn = tid % NTN;
+#pragma unroll 8
+                for (int ks = 0; ks < 32; ++ks) {
+                    const int sidx = 2 * ks + half;
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(32 * tm + col) * LD + sidx], Bs[(32 * tn + col) * LD + sidx], acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int tid = wave * TPW + q;
+        if (tid < MT * NTN) {
+            const int tm = tid / NTN, tn = tid % NTN;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = 32 * tm + acc_row(j, half), n = 32 * tn + col;
+                if (m < a.M && n < a.Nn) atomicAdd(&a.C[(size_t)m * a.Nn + n], acc[q][j]);
+            }
+        }
+    }
+    if (a.rowsum && (int)threadIdx.x < a.M) atomicAdd(&a.rowsum[threadIdx.x], rs);
+}
+
+template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+    const size_t lds = sizeof(float) * (size_t)(MT + NTN) * 32 * 65;
+    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<MT, NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_wgrad)");
+    const int64_t n_tiles = ((a.N + 63) / 64) * a.n_chunks;
+    const int64_t blocks = n_tiles < 512 ? n_tiles : 512;
+    hipLaunchKernelGGL((k_wgrad<MT, NTN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return check_launch("k_wgrad");
+}
+
+// torch.optim.Adam (ppo.py:105: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay)
+__global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1,
+                                              float b2, float eps, float bc1, float bc2) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    }
+}
+
+}  // namespace qenv
+
+using namespace qenv;
+
+extern "C" {
+
+int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_out, int final_tanh, const float* obs,
+                      const float* seed, const float* W1, const float* b1, const float* W2, const float* b2,
+                      const float* W3, const float* b3, float* h1, float* h2, float* dz2, float* dz1, float* dz3,
+                      void* stream) {
+    if (!obs || !seed || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !h1 || !h2 || !dz2 || !dz1 || !dz3)
+        return fail(QENV_ERR_ARG, "qenv_mlp_backward: null argument");
+    if (n_envs <= 0 || n_chunks <= 0 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_backward: bad sizes");
+    BwdArgs a;
+    a.N = n_envs; a.n_chunks = n_chunks; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh;
+    a.obs = obs; a.seed = seed; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+    a.h1 = h1; a.h2 = h2; a.dz2 = dz2; a.dz1 = dz1; a.dz3 = dz3;
+    const int HP = hidden < 32 ? 32 : hidden, K1P = (k_in + 1) & ~1;
+    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)HP * (HP + 1) + 4 * HP + 2 * HP + 4);
+    if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_backward: weights do not fit the 160 KiB LDS");
+    const int64_t n_tiles = ((n_envs + 31) / 32) * n_chunks;
+    const int wpb = hidden >= 128 ? 4 : 8;
+    int64_t blocks = (n_tiles + wpb - 1) / wpb;
+    if (blocks > 256) blocks = 256;
+    hipError_t e;
+#define QENV_BWD_CASE(HH)                                                                                                   \
+    case HH:                                                                                                                 \
+        e = hipFuncSetAttribute((const void*)k_mlp_bwd<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd)");                                           \
+        hipLaunchKernelGGL((k_mlp_bwd<HH>), dim3((unsigned)blocks), dim3(HH >= 128 ? 256 : 512), lds, (hipStream_t)stream, a);                 \
+        break;
+    switch (hidden) {
+        QENV_BWD_CASE(16) QENV_BWD_CASE(32) QENV_BWD_CASE(64) QENV_BWD_CASE(128)
+        default: return fail(QENV_ERR_ARG, "qenv_mlp_backward: hidden must be 16, 32, 64 or 128");
+    }
+#undef QENV_BWD_CASE
+    return check_launch("k_mlp_bwd");
+}
+
+int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float* A, const float* B, float* C,
+                     float* rowsum, void* stream) {
+    if (!A || !B || !C) return fail(QENV_ERR_ARG, "qenv_weight_grad: null argument");
+    if (n_envs <= 0 || n_chunks <= 0 || m_rows < 1 || m_rows > 128 || n_rows < 1 || n_rows > 128)
+        return fail(QENV_ERR_ARG, "qenv_weight_grad: rows must be 1..128");
+    WgradArgs a;
+    a.N = n_envs; a.n_chunks = n_chunks; a.M = m_rows; a.Nn = n_rows; a.A = A; a.B = B; a.C = C; a.rowsum = rowsum;
+    const int mt = (m_rows + 31) / 32, nt = (n_rows + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+#define QENV_WG(MT_, NT_) if (mt == MT_ && nt == NT_) return launch_wgrad<MT_, NT_>(a, s);
+    QENV_WG(1, 1) QENV_WG(1, 2) QENV_WG(1, 3) QENV_WG(1, 4) QENV_WG(2, 1) QENV_WG(2, 2) QENV_WG(2, 3) QENV_WG(2, 4)
+    QENV_WG(3, 1) QENV_WG(3, 2) QENV_WG(3, 3) QENV_WG(3, 4) QENV_WG(4, 1) QENV_WG(4, 2) QENV_WG(4, 3) QENV_WG(4, 4)
+#undef QENV_WG
+    return fail(QENV_ERR_ARG, "qenv_weight_grad: unsupported tile shape");
+}
+
+int qenv_adam_step(int64_t n, float* param, const float* grad, float* m, float* v, double lr, double beta1, double beta2,
+                   double eps, int step, void* stream) {
+    if (!param || !grad || !m || !v) return fail(QENV_ERR_ARG, "qenv_adam_step: null argument");
+    if (n <= 0 || step < 1) return fail(QENV_ERR_ARG, "qenv_adam_step: n must be positive and step >= 1");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, param, grad, m, v, (float)lr,
+                       (float)beta1, (float)beta2, (float)eps, (float)bc1, (float)bc2);
+    return check_launch("k_adam");
+}
+
+}  // extern "C"

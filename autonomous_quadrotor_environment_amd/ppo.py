@@ -167,6 +167,90 @@ def ppo_loss(mean, value, actions, old_logprob, adv, returns, std, eps_clip=0.2,
     return out
 
 
+class PpoLearner:
+    """PPO.update of environment/controller/ppo.py:143-209 on the device for the 75-N-N-4 actor / 75-N-N-1
+    critic of model.py: K_epochs full-batch passes of { forward, clipped-surrogate loss, backward (fp32 MFMA),
+    Adam } over a `PolicyRollout` collected with store_obs=True.  FIXED_STD as in the reference (:301).
+
+    Gradients of the weights are fp32-atomic sums over the batch (order not deterministic to the last bit)."""
+
+    def __init__(self, weights: ActorCriticWeights, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, eps_clip=0.2, c_value=0.5,
+                 c_entropy=0.006, K_epochs=10):
+        assert weights.critic is not None
+        self.w, self.lr, self.betas, self.eps = weights, lr, betas, eps
+        self.eps_clip, self.c_value, self.c_entropy, self.K_epochs = eps_clip, c_value, c_entropy, K_epochs
+        self.step = 0
+        self._state = {}
+        for head in ("actor", "critic"):
+            for k, p in enumerate(weights.head(head)):
+                self._state[(head, k)] = (torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p))  # grad, m, v
+        self._buf = None
+
+    def _buffers(self, H, n, N, dev):
+        key = (H, n, N)
+        if self._buf is None or self._buf[0] != key:
+            mk = lambda r: torch.empty(n, r, N, device=dev, dtype=torch.float32)
+            self._buf = (key, dict(h1=mk(H), h2=mk(H), dz2=mk(H), dz1=mk(H), dz3=mk(4), mean=mk(4), value=mk(1)))
+        return self._buf[1]
+
+    def gradients(self, obs, actions, old_logprob, adv, returns):
+        """One forward + loss + backward over the batch; fills the .grad buffers.  obs [n, 75, N] float32,
+        actions / old_logprob [n, 4, N], adv / returns [n, N].  Returns the loss dict of `ppo_loss`."""
+        n, K, N = obs.shape
+        dev, w = obs.device, self.w
+        H = w.hidden
+        b = self._buffers(H, n, N, dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        f32 = lambda t: t.to(torch.float32).contiguous()
+        obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
+        # forward of both heads on the stored observations (the dense kernel takes feature-major chunks)
+        for head, out, ft in (("actor", b["mean"], True), ("critic", b["value"], False)):
+            W = w.head(head)
+            for c in range(n):
+                L.check(L.lib.qenv_dense_tail(N, K, H, W[4].shape[0], int(ft), L.ptr(obs[c]), *[L.ptr(x) for x in W],
+                                              L.ptr(out[c]), stream), "qenv_dense_tail")
+        # loss + seed gradients over the whole batch: view [n, r, N] as r rows of n*N samples
+        flat = lambda t, r: t.permute(1, 0, 2).reshape(r, n * N).contiguous()
+        loss = ppo_loss(flat(b["mean"], 4), b["value"].reshape(n * N), flat(actions, 4), flat(old_logprob, 4),
+                        adv.reshape(n * N), returns.reshape(n * N), w.std, self.eps_clip, self.c_value, self.c_entropy,
+                        with_grads=True)
+        seed_a = loss["grad_mean"].reshape(4, n, N).permute(1, 0, 2).contiguous()
+        seed_c = loss["grad_value"].reshape(n, 1, N).contiguous()
+        for head, seed, ft in (("actor", seed_a, True), ("critic", seed_c, False)):
+            W = w.head(head)
+            n_out = W[4].shape[0]
+            L.check(L.lib.qenv_mlp_backward(N, n, K, H, n_out, int(ft), L.ptr(obs), L.ptr(seed), *[L.ptr(x) for x in W],
+                                            L.ptr(b["h1"]), L.ptr(b["h2"]), L.ptr(b["dz2"]), L.ptr(b["dz1"]), L.ptr(b["dz3"]),
+                                            stream), "qenv_mlp_backward")
+            g = [self._state[(head, k)][0] for k in range(6)]
+            for t in g:
+                t.zero_()
+            dz3 = b["dz3"] if n_out == 4 else b["dz3"][:, :n_out].contiguous()
+            for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
+                                                 (b["dz1"], H, obs, K, g[0], g[1])):
+                L.check(L.lib.qenv_weight_grad(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb), stream),
+                        "qenv_weight_grad")
+        return loss
+
+    def adam_step(self):
+        self.step += 1
+        for (head, k), (g, m, v) in self._state.items():
+            p = self.w.head(head)[k]
+            stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+            L.check(L.lib.qenv_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), self.lr, self.betas[0],
+                                         self.betas[1], self.eps, self.step, stream), "qenv_adam_step")
+
+    def update(self, rollout, returns, adv):
+        """K_epochs full-batch epochs (ppo.py:172-203; the reference's randperm of a full batch does not change
+        loss.mean()).  Returns the list of loss dicts."""
+        n = rollout.t
+        out = []
+        for _ in range(self.K_epochs):
+            out.append(self.gradients(rollout.obs[:n], rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n]))
+            self.adam_step()
+        return out
+
+
 def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, ang, v_ang):
     """Batched visual_landing/rl_reward_fuction.py:3-102.  [3, N] tensors (marker, pos, vel,
     control, ang, v_ang), last_shaping [N] (0 = none), step int32 [N].

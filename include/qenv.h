@@ -209,7 +209,7 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
 /* Dense tail of the legacy landing policy (visual_landing/rl_nn_model.py:58-66 actor, :77-84 critic):
  * Linear(K,H) tanh Linear(H,H) tanh Linear(H,n_out) [tanh] on flattened conv features (K = 800, H = 64,
  * n_out = 3 / 1) -- the GEMM-shaped part of that model; its conv front-end needs rendered camera images
- * and is out of scope.  x float32 [K][N] (feature-major), weights float32 torch layout, H in {32, 64, 128},
+ * and is out of scope.  x float32 [K][N] (feature-major), weights float32 torch layout, H in {16, 32, 64, 128},
  * n_out <= 4, out float32 [n_out][N].  fp32 MFMA, W1 streamed through LDS in K-chunks. */
 int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float *x,
                     const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
@@ -255,6 +255,26 @@ int qenv_ppo_loss(int dtype, int64_t batch, const void *mean, const void *value,
                   const void *old_logprob, const void *adv, const void *returns, double std,
                   double eps_clip, double c_value, double *sums, void *grad_mean, void *grad_value,
                   void *stream);
+
+/* ---- optimiser half of PPO.update (ppo.py:199-203: loss.mean().backward(); optimizer.step()) -------------
+ * All matrices are float32 in the rollout's time-major chunked SoA: sample (c, e) of an R-row matrix at
+ * base + (c*R + r)*n_envs + e, c < n_chunks (one chunk per rollout step).
+ *
+ * qenv_mlp_backward: recomputes the forward of the tanh MLP (model.py:27-42) on obs [c][K][N] and backpropagates
+ * seed = d loss / d output [c][n_out][N] (from qenv_ppo_loss) through the activations:
+ *   h1, h2 [c][H][N] (post-tanh), dz2, dz1 [c][H][N] (gradients w.r.t. the pre-activations), dz3 [c][4][N].
+ * qenv_weight_grad: C[m][n] += sum_samples A[m][s] B[n][s] (C row-major [M][Nn] = torch's weight layout) and, if
+ *   rowsum != NULL, rowsum[m] += sum_samples A[m][s] (bias gradient): dW3 = dz3 x h2, dW2 = dz2 x h1, dW1 = dz1 x obs.
+ *   The caller zeroes C / rowsum; accumulation order is not deterministic (fp32 atomics).
+ * qenv_adam_step: torch.optim.Adam update (ppo.py:105) of n parameters, step counted from 1. */
+int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_out, int final_tanh,
+                      const float *obs, const float *seed, const float *W1, const float *b1,
+                      const float *W2, const float *b2, const float *W3, const float *b3, float *h1,
+                      float *h2, float *dz2, float *dz1, float *dz3, void *stream);
+int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float *A, const float *B,
+                     float *C, float *rowsum, void *stream);
+int qenv_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, double lr, double beta1,
+                   double beta2, double eps, int step, void *stream);
 
 /* Replaces visual_reward (visual_landing/rl_reward_fuction.py:3-102), batched.
  * marker,pos,vel,control,ang,v_ang [3][N]; last_shaping [N] (0 = none, like the

@@ -219,3 +219,70 @@ def test_dense_tail_rl_nn_model_shape(aq, oracle):
                                  W3.astype(np.float32).astype(np.float64), b3.astype(np.float32).astype(np.float64), ft)
         assert got.shape == (N, n_out)
         assert np.max(np.abs(got - ref)) < 5e-6, (K, H, n_out, np.max(np.abs(got - ref)))
+
+
+def _torch_nets(w, dtype=torch.float64):
+    import torch.nn as nn
+    def net(ws, final_tanh):
+        W1, b1, W2, b2, W3, b3 = ws
+        l = [nn.Linear(W1.shape[1], W1.shape[0]), nn.Tanh(), nn.Linear(W2.shape[1], W2.shape[0]), nn.Tanh(),
+             nn.Linear(W3.shape[1], W3.shape[0])] + ([nn.Tanh()] if final_tanh else [])
+        m = nn.Sequential(*l).to("cuda", dtype)
+        with torch.no_grad():
+            for lin, (W, b) in zip([m[0], m[2], m[4]], ((W1, b1), (W2, b2), (W3, b3))):
+                lin.weight.copy_(W.to(dtype)); lin.bias.copy_(b.to(dtype))
+        return m
+    return net(w.actor, True), net(w.critic, False)
+
+
+@pytest.mark.parametrize("hidden", [16, 128])
+def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden):
+    """Backward pass (MFMA), weight/bias gradients (split-K GEMM) and the Adam step of PpoLearner against torch
+    autograd + torch.optim.Adam on the reference's loss (ppo.py:185-203), fp64 torch as the yardstick."""
+    torch.manual_seed(0)
+    n, N, K = 3, 200, 75
+    w = aq.ActorCriticWeights.random(hidden, K, 4, seed=3)
+    w.std = 0.1
+    obs = torch.randn(n, K, N, device="cuda")
+    act_net, cri_net = _torch_nets(w)
+    with torch.no_grad():
+        mean0 = act_net(obs.permute(0, 2, 1).double())  # [n, N, 4]
+    actions = (mean0 + 0.1 * torch.randn_like(mean0)).permute(0, 2, 1).float().contiguous()      # [n, 4, N]
+    old_lp = torch.distributions.Normal(mean0 + 0.03 * torch.randn_like(mean0), 0.1).log_prob(actions.permute(0, 2, 1).double())
+    old_lp = old_lp.permute(0, 2, 1).float().contiguous()
+    adv = torch.randn(n, N, device="cuda"); rets = 2 * torch.randn(n, N, device="cuda")
+    learner = aq.PpoLearner(w, K_epochs=1)
+    loss = learner.gradients(obs, actions, old_lp, adv, rets)
+    # torch reference of the same loss
+    x = obs.permute(0, 2, 1).double()
+    mean = act_net(x); value = cri_net(x).squeeze(-1)
+    dist = torch.distributions.Normal(mean, 0.1)
+    lp = dist.log_prob(actions.permute(0, 2, 1).double()).sum(-1)
+    ratio = torch.exp(lp - old_lp.permute(0, 2, 1).double().sum(-1))
+    a_ = adv.double()
+    total = (-torch.min(ratio * a_, torch.clamp(ratio, 0.8, 1.2) * a_)).mean() + 0.5 * ((value - rets.double()) ** 2).mean() \
+        - 0.006 * dist.entropy().sum(-1).mean()
+    total.backward()
+    assert abs(float(loss["loss"]) - float(total)) < 1e-4 * max(1.0, abs(float(total)))
+    ref_grads = {"actor": [act_net[0].weight.grad, act_net[0].bias.grad, act_net[2].weight.grad, act_net[2].bias.grad,
+                           act_net[4].weight.grad, act_net[4].bias.grad],
+                 "critic": [cri_net[0].weight.grad, cri_net[0].bias.grad, cri_net[2].weight.grad, cri_net[2].bias.grad,
+                            cri_net[4].weight.grad, cri_net[4].bias.grad]}
+    for head in ("actor", "critic"):
+        for k in range(6):
+            g = learner._state[(head, k)][0].double()
+            r = ref_grads[head][k]
+            scale = float(r.abs().max()) + 1e-12
+            assert float((g - r).abs().max()) / scale < 2e-4, (head, k, float((g - r).abs().max()), scale)
+    # one Adam step vs torch.optim.Adam (fp32 parameters)
+    act32, cri32 = _torch_nets(w, torch.float32)
+    opt = torch.optim.Adam(list(act32.parameters()) + list(cri32.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    for net, head in ((act32, "actor"), (cri32, "critic")):
+        for lin, (kw, kb) in zip([net[0], net[2], net[4]], ((0, 1), (2, 3), (4, 5))):
+            lin.weight.grad = learner._state[(head, kw)][0].clone(); lin.bias.grad = learner._state[(head, kb)][0].clone()
+    opt.step()
+    learner.adam_step()
+    for net, head in ((act32, "actor"), (cri32, "critic")):
+        for lin, (kw, kb) in zip([net[0], net[2], net[4]], ((0, 1), (2, 3), (4, 5))):
+            assert torch.allclose(w.head(head)[kw], lin.weight, rtol=0, atol=2e-7)
+            assert torch.allclose(w.head(head)[kb], lin.bias, rtol=0, atol=2e-7)
