@@ -10,8 +10,9 @@ from . import _lib  # noqa: F401  (raises if libqenv.so is missing: no CPU fallb
 from .quadrotor_env import BatchedQuad, quad, random_init_states, euler_quat, quat_euler  # noqa: F401
 from .controllers import LqrController, PidController, PidPosController, pid_control  # noqa: F401
 from .ppo import ActorCriticWeights, dense_tail, dl_in_gen, gae, ppo_loss, visual_reward, PolicyRollout, PpoLearner  # noqa: F401
+from .mission import mission  # noqa: F401
 from .distributed import shard_range, ShardedQuad, all_gather_returns  # noqa: F401
 
 __all__ = ["BatchedQuad", "quad", "random_init_states", "LqrController", "PidController", "PidPosController", "pid_control",
-           "ActorCriticWeights", "dl_in_gen", "gae", "dense_tail", "ppo_loss", "visual_reward", "PolicyRollout", "PpoLearner", "shard_range",
+           "ActorCriticWeights", "dl_in_gen", "gae", "dense_tail", "ppo_loss", "visual_reward", "PolicyRollout", "PpoLearner", "mission", "shard_range",
            "ShardedQuad", "all_gather_returns"]

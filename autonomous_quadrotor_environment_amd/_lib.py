@@ -49,6 +49,7 @@ SYMBOLS = {
     "qenv_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "qenv_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "qenv_rollout": (_i, [_vp, _i, _i, _dptr, _i, _i]),
+    "qenv_rollout_track": (_i, [_vp, _i, _vp, _i]),
     "qenv_lqr_action": (_i, [_vp, _vp]),
     "qenv_pid_action": (_i, [_vp, _dptr, _vp]),
     "qenv_pid_reset": (_i, [_vp, _vp]),

@@ -39,6 +39,7 @@ template <typename T> struct RolloutArgs {
     int32_t ang_ok;
     T const_action[4];
     T pid_target[7];
+    const T* target_table;  // null, or [n_steps][7]: PIDPOS target of each step
     LqrGains<T> lqr;
     PidGains<T> pid;
 };
@@ -190,7 +191,14 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             }
             prepare_action(raw, cfg, w, effort, cl, act, u);
         } else if (CTRL == QENV_CTRL_PIDPOS) {
-            pidpos_law(y, bk, ps, a.pid_target, cfg.t_step, raw);
+            if (a.target_table) {
+                T tg[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) tg[k] = a.target_table[s * 7 + k];  // wave-uniform address: scalar loads
+                pidpos_law(y, bk, ps, tg, cfg.t_step, raw);
+            } else {
+                pidpos_law(y, bk, ps, a.pid_target, cfg.t_step, raw);
+            }
             prepare_action(raw, cfg, w, effort, cl, act, u);
         }
         const T q_old[4] = {y[6], y[7], y[8], y[9]};
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
                 else if (CTRL == QENV_CTRL_PID) {
                     if (s == 0 && a.pid_first) { raw[0] = float(phys::M * phys::G); raw[1] = raw[2] = raw[3] = 0.f; }
                     else pid_law(yc, bk[c], a.pid, ps[c], a.pid_target, cfg.t_step, raw);
-                } else pidpos_law(yc, bk[c], ps[c], a.pid_target, cfg.t_step, raw);
+                } else pidpos_law(yc, bk[c], ps[c], a.target_table ? a.target_table + s * 7 : a.pid_target, cfg.t_step, raw);
                 prepare_action(raw, cfg, w[c], effort[c], cl[c], act[c], us[c]);
             }
             u.F = F2{us[0].F, us[1].F}; u.Mx = F2{us[0].Mx, us[1].Mx}; u.My = F2{us[0].My, us[1].My};
@@ -568,8 +576,9 @@ template <typename T, int INTEG> static void launch_rollout(qenv_s* q, int contr
 }
 
 template <typename T> static int do_rollout(qenv_s* q, int controller, int n_steps, const double* const_action,
-                                            int pid_first, int flags) {
+                                            int pid_first, int flags, const void* target_table = nullptr) {
     RolloutArgs<T> a;
+    a.target_table = (const T*)target_table;
     a.cfg = make_cfg<T>(q);
     a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
     a.ang_ok = q->ang_ok;
@@ -723,6 +732,16 @@ int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_acti
     if (n_steps == 0) return QENV_OK;
     return q->cfg.dtype == QENV_F64 ? do_rollout<double>(q, controller, n_steps, const_action, pid_first_action, flags)
                                     : do_rollout<float>(q, controller, n_steps, const_action, pid_first_action, flags);
+}
+
+int qenv_rollout_track(qenv_t q, int n_steps, const void* targets, int flags) {
+    if (!q || !targets) return fail(QENV_ERR_ARG, "qenv_rollout_track: null argument");
+    if (n_steps < 0) return fail(QENV_ERR_ARG, "qenv_rollout_track: negative n_steps");
+    if (flags != QENV_STEP_FULL && flags != QENV_STEP_NO_AUX) return fail(QENV_ERR_ARG, "qenv_rollout_track: bad flags");
+    if (q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_rollout_track: the PD commands [F,Mx,My,Mz]; direct_control=0");
+    if (n_steps == 0) return QENV_OK;
+    return q->cfg.dtype == QENV_F64 ? do_rollout<double>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets)
+                                    : do_rollout<float>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets);
 }
 
 int qenv_lqr_action(qenv_t q, void* out_actions) {

@@ -60,10 +60,12 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
     const int64_t tiles_per_chunk = (a.N + 31) / 32, n_tiles = tiles_per_chunk * a.n_chunks;
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         asm volatile("" ::: "memory");  // keep the (tile-invariant) LDS reads inside the loop (see k_mlp)
-        const int64_t c = tile / tiles_per_chunk, e = (tile % tiles_per_chunk) * 32 + col;
+        // chunk index and chunk bases are wave-uniform (SGPRs); everything per lane is a 32-bit element offset
+        const int64_t c = __builtin_amdgcn_readfirstlane((int)(tile / tiles_per_chunk));
+        const int64_t e = (tile % tiles_per_chunk) * 32 + col;
         const bool valid = e < a.N;
-        const int64_t ec = valid ? e : a.N - 1;
-        const float* x = a.obs + (size_t)c * K1 * a.N + ec;
+        const uint32_t N32 = (uint32_t)a.N, ec = (uint32_t)(valid ? e : a.N - 1);
+        const float* x = a.obs + (size_t)c * K1 * a.N;
         f32x16 h1[NT], h2[NT];
         // ---- layer 1
 #pragma unroll
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int k = 2 * (s0 + s) + half;
-                const float v = x[(size_t)(k < K1 ? k : K1 - 1) * a.N];
+                const float v = x[(uint32_t)(k < K1 ? k : K1 - 1) * N32 + ec];
                 xs[s] = (k < K1 && 2 * (s0 + s) < K1P) ? v : 0.f;
             }
 #pragma unroll
@@ -120,25 +122,28 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
         for (int o = 0; o < 4; ++o) {
             float v = o3[o] + __shfl_xor(o3[o], 32) + b3s[o];
             if (a.final_tanh) v = tanhf(v);
-            const float sd = o < a.n_out ? a.seed[((size_t)c * a.n_out + o) * a.N + ec] : 0.f;
+            const float sd = o < a.n_out ? (a.seed + (size_t)c * a.n_out * a.N)[(uint32_t)o * N32 + ec] : 0.f;
             dz3[o] = a.final_tanh ? sd * (1.f - v * v) : sd;
-            if (valid && half == 0) a.dz3[((size_t)c * 4 + o) * a.N + e] = dz3[o];
+            if (valid && half == 0) (a.dz3 + (size_t)c * 4 * a.N)[(uint32_t)o * N32 + ec] = dz3[o];
         }
         // ---- store H1, H2; dZ2 = (W3^T dz3) (1 - H2^2) in place of H2
-        const size_t rowbase = (size_t)c * H * a.N + ec;
+        float* const h1c = a.h1 + (size_t)c * H * a.N;
+        float* const h2c = a.h2 + (size_t)c * H * a.N;
+        float* const dz2c = a.dz2 + (size_t)c * H * a.N;
+        float* const dz1c = a.dz1 + (size_t)c * H * a.N;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int h = 32 * t + acc_row(j, half);
                 if (valid && h < H) {
-                    a.h1[rowbase + (size_t)h * a.N] = h1[t][j];
-                    a.h2[rowbase + (size_t)h * a.N] = h2[t][j];
+                    h1c[(uint32_t)h * N32 + ec] = h1[t][j];
+                    h2c[(uint32_t)h * N32 + ec] = h2[t][j];
                 }
                 const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * h]);
                 const float g = w3.x * dz3[0] + w3.y * dz3[1] + w3.z * dz3[2] + w3.w * dz3[3];
                 h2[t][j] = g * (1.f - h2[t][j] * h2[t][j]);
-                if (valid && h < H) a.dz2[rowbase + (size_t)h * a.N] = h2[t][j];
+                if (valid && h < H) dz2c[(uint32_t)h * N32 + ec] = h2[t][j];
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         // ---- dH1 = W2^T dZ2 on the MFMA pipe, one output tile at a time; dZ1 = dH1 (1 - H1^2)
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
             for (int j = 0; j < 16; ++j) {
                 const int h = 32 * t + acc_row(j, half);
                 const float g = d[j] * (1.f - h1[t][j] * h1[t][j]);
-                if (valid && h < H) a.dz1[rowbase + (size_t)h * a.N] = g;
+                if (valid && h < H) dz1c[(uint32_t)h * N32 + ec] = g;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -274,6 +279,8 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
     if (!obs || !seed || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !h1 || !h2 || !dz2 || !dz1 || !dz3)
         return fail(QENV_ERR_ARG, "qenv_mlp_backward: null argument");
     if (n_envs <= 0 || n_chunks <= 0 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_backward: bad sizes");
+    if ((int64_t)(hidden > k_in ? hidden : k_in) * n_envs >= ((int64_t)1 << 31))
+        return fail(QENV_ERR_ARG, "qenv_mlp_backward: rows*n_envs per chunk must stay below 2^31 (32-bit offsets)");
     BwdArgs a;
     a.N = n_envs; a.n_chunks = n_chunks; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh;
     a.obs = obs; a.seed = seed; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;

@@ -270,6 +270,16 @@ class BatchedQuad:
         self._bind()
         L.check(L.lib.qenv_rollout(self._h, ctrl, int(n_steps), ca, int(bool(pid_first_action)), flags), "qenv_rollout")
 
+    def track(self, targets, flags=L.STEP_FULL):
+        """Position-PD trajectory tracking in one launch (PID_control.py:245-263): targets [n_steps, 7] =
+        {xd, yd, zd, dxd, dyd, dzd, psi_d} per step, e.g. mission.table(n)."""
+        if isinstance(targets, np.ndarray):
+            targets = torch.from_numpy(np.ascontiguousarray(targets))
+        tg = targets.to(device=self.device, dtype=self.dtype).contiguous()
+        assert tg.dim() == 2 and tg.shape[1] == 7
+        self._bind()
+        L.check(L.lib.qenv_rollout_track(self._h, tg.shape[0], L.ptr(tg), flags), "qenv_rollout_track")
+
     def lqr_action(self, out=None):
         out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
         self._bind()

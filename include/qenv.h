@@ -174,6 +174,11 @@ int qenv_step(qenv_t q, const void *actions, void *out_obs, void *out_reward, ui
 int qenv_rollout(qenv_t q, int controller, int n_steps, const double *const_action,
                  int pid_first_action, int flags);
 
+/* Trajectory tracking in one launch: the position PD of PID_control.py with a new target every step, as the
+ * loop PID_control.py:245-263 feeds it from mission_control.get_error().  targets: DEVICE [n_steps][7] in the
+ * handle's dtype, row s = {xd, yd, zd, dxd, dyd, dzd, psi_d} used at step s (shared by all envs). */
+int qenv_rollout_track(qenv_t q, int n_steps, const void *targets, int flags);
+
 /* Stand-alone controller laws writing actions [4][N] from the workspace rows
  * (state, ang, ang_vel) -- for callers that interleave them with qenv_step.
  * LQR: lqr_quad.py:128-154.  PID: pid_control.control(xd, 0, psd, 0),

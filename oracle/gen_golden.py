@@ -573,6 +573,20 @@ def g15():
          entropy=np.array(float(e_loss.mean())), grad_mean=mean.grad.numpy()[:, 0], grad_value=value.grad.numpy().ravel())
 
 
+def g16():
+    """mission_control.mission trajectories as handed out by get_error() call after call."""
+    from mission_control.mission_control import mission as Ref
+    out = {}
+    for name, f, n in (("step", lambda q: q.gen_trajectory(700, 300, np.array([1.0, -0.5, 0.8])), 750),
+                       ("ramp_vel", lambda q: q.gen_trajectory(200, 200, np.zeros(3), velocity=np.array([0.5, 0.2, -0.1])), 300),
+                       ("sin", lambda q: q.sin_trajectory(600, 1.5, 0.1, np.array([0.5, 0, 0]), np.array([1.0, 0.5, 0])), 650),
+                       ("spiral", lambda q: q.spiral_trajectory(300, 600, 0.3, 1.2, 0.8, np.array([0, 0, 0.0])), 620)):
+        q = Ref(0.01)
+        f(q)
+        out[name] = np.array([q.get_error(0) for _ in range(n)])
+    save("g16_mission", **out)
+
+
 def g11():
     rng = np.random.RandomState(111)
     rows = []
@@ -601,6 +615,6 @@ def g11():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16"]
     for name in todo:
         globals()[name]()

@@ -391,3 +391,27 @@ def test_pidpos_tracking_golden(aq, dt, tol):
         e1.step(e1.pidpos_action(tgt))
     e2.rollout("pidpos", 50, action=tgt)
     assert torch.equal(e1.state, e2.state)
+
+
+def test_track_mission_in_one_launch(aq, oracle):
+    """PID_control.py:245-263: spiral mission tracked by the position PD, whole trajectory in ONE launch, against
+    the oracle driven step by step with the same table; and against the per-step HIP path bit for bit."""
+    m = aq.mission(0.01)
+    m.spiral_trajectory(300, 600, 0.3, 1.2, 0.8, np.array([0, 0, 0.0]))
+    tab = m.table(600)
+    x0 = np.zeros(13); x0[6] = 1
+    env = aq.BatchedQuad(64, 0.01, 5000, training=True, direct_control=0, T=1, dtype=torch.float64)
+    env.reset(_dev(np.repeat(x0[:, None], 64, 1), "f64")); env.pid_reset()
+    env.track(tab)
+    ref = oracle.OracleQuad(0.01, 5000, training=True, direct_control=0, T=1)
+    ref.reset(x0)
+    ctl = oracle.OraclePidPos(ref)
+    for j in range(600):
+        ref.step(ctl.control(tab[j, :3], tab[j, 3:6], tab[j, 6], 0))
+    assert scaled_err(_np(env.state[:, 5]), ref.state) < 1e-9
+    assert np.linalg.norm(ref.state[0:5:2] - tab[-1, :3]) < 0.2  # it does track
+    e2 = aq.BatchedQuad(64, 0.01, 5000, training=True, direct_control=0, T=1, dtype=torch.float64)
+    e2.reset(_dev(np.repeat(x0[:, None], 64, 1), "f64")); e2.pid_reset()
+    for j in range(600):
+        e2.step(e2.pidpos_action(tab[j]))
+    assert torch.equal(e2.state, env.state)

@@ -263,7 +263,7 @@ def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden):
     total = (-torch.min(ratio * a_, torch.clamp(ratio, 0.8, 1.2) * a_)).mean() + 0.5 * ((value - rets.double()) ** 2).mean() \
         - 0.006 * dist.entropy().sum(-1).mean()
     total.backward()
-    assert abs(float(loss["loss"]) - float(total)) < 1e-4 * max(1.0, abs(float(total)))
+    assert abs(float(loss["loss"]) - float(total.detach())) < 1e-4 * max(1.0, abs(float(total.detach())))
     ref_grads = {"actor": [act_net[0].weight.grad, act_net[0].bias.grad, act_net[2].weight.grad, act_net[2].bias.grad,
                            act_net[4].weight.grad, act_net[4].bias.grad],
                  "critic": [cri_net[0].weight.grad, cri_net[0].bias.grad, cri_net[2].weight.grad, cri_net[2].bias.grad,

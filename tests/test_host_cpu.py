@@ -96,3 +96,23 @@ def test_gpu_only_classes_refuse_cpu(built):
     import torch
     with pytest.raises(RuntimeError):
         built.BatchedQuad(4, 0.01, 100, device="cpu")
+
+
+def test_mission_trajectories_match_reference(built):
+    """G16: mission_control.mission (step, velocity ramp, sine, spiral incl. the end-of-trajectory drift)."""
+    import numpy as _np
+    g = golden("g16_mission")
+    M = built.mission
+    cases = {"step": (lambda q: q.gen_trajectory(700, 300, _np.array([1.0, -0.5, 0.8])), 750),
+             "ramp_vel": (lambda q: q.gen_trajectory(200, 200, _np.zeros(3), velocity=_np.array([0.5, 0.2, -0.1])), 300),
+             "sin": (lambda q: q.sin_trajectory(600, 1.5, 0.1, _np.array([0.5, 0, 0]), _np.array([1.0, 0.5, 0])), 650),
+             "spiral": (lambda q: q.spiral_trajectory(300, 600, 0.3, 1.2, 0.8, _np.array([0, 0, 0.0])), 620)}
+    for name, (f, n) in cases.items():
+        q = M(0.01)
+        f(q)
+        got = _np.array([q.get_error(0) for _ in range(n)])
+        assert _np.allclose(got, g[name], rtol=0, atol=1e-12), name
+        q2 = M(0.01)
+        f(q2)
+        tab = q2.table(n)
+        assert _np.allclose(tab[:, 0:3], g[name][:, 0:5:2], atol=1e-12) and _np.allclose(tab[:, 3:6], g[name][:, 1:6:2], atol=1e-12)
