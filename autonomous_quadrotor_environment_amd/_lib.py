@@ -28,7 +28,7 @@ FLAG_DONE, FLAG_SOLVED, FLAG_HAS_SHAPING = 1, 2, 4
 class QenvConfig(C.Structure):
     _fields_ = [("n_envs", C.c_int64), ("t_step", C.c_double), ("n_max", C.c_int32), ("T", C.c_int32),
                 ("training", C.c_int32), ("direct_control", C.c_int32), ("clipped", C.c_int32),
-                ("variant", C.c_int32), ("integrator", C.c_int32), ("dtype", C.c_int32)]
+                ("variant", C.c_int32), ("integrator", C.c_int32), ("dtype", C.c_int32), ("compute", C.c_int32)]
 
 
 class QenvError(RuntimeError):

@@ -7,30 +7,34 @@
 // coalesced wave-wide transaction.  One lane = one quadrotor; 256-thread workgroups
 // (4 waves); the state never leaves VGPRs inside a step (or inside a fused rollout).
 #include "qenv_host.hpp"
+#include <type_traits>
 
 namespace qenv {
 
 // ---- kernel argument blocks (live in SGPRs) ------------------------------------------------
-template <typename T> struct StepArgs {
+// T = arithmetic type, S = storage type of the workspace and of the caller's arrays.  S == T for the fp32 and
+// fp64 handles; the mixed handle (fp64 rows, fp32 arithmetic) uses T = float, S = double: the state rows are
+// advanced by state += (double)increment, so no per-step rounding of the state enters the closed loop.
+template <typename T, typename S = T> struct StepArgs {
     Cfg<T> cfg;
-    T* ws;                 // workspace rows of type T
+    S* ws;                 // workspace rows of type S
     int32_t* wsi;          // int rows (I, FLAGS)
     int64_t N;
-    const T* actions;      // [4][N] or null (zero_control)
+    const S* actions;      // [4][N] or null (zero_control)
     const uint8_t* mask;   // null or [N]: only envs with mask != 0 are stepped
-    T* out_obs;            // [14][N] or null
-    T* out_reward;         // [N] or null
+    S* out_obs;            // [14][N] or null
+    S* out_reward;         // [N] or null
     uint8_t* out_done;     // [N] or null
-    T* out_mask;           // [N] or null: 1 - done
+    S* out_mask;           // [N] or null: 1 - done
     float* win;            // observation ring or null
     int32_t win_slot;      // ring slot this step's slice goes to
     int32_t mode;          // QENV_STEP_* (mode bits only)
     int32_t ang_ok;        // every env's prev_ang row is the angle of its state row (see euler_update)
 };
 
-template <typename T> struct RolloutArgs {
+template <typename T, typename S = T> struct RolloutArgs {
     Cfg<T> cfg;
-    T* ws;
+    S* ws;
     int32_t* wsi;
     int64_t N;
     int32_t n_steps;
@@ -39,36 +43,36 @@ template <typename T> struct RolloutArgs {
     int32_t ang_ok;
     T const_action[4];
     T pid_target[7];
-    const T* target_table;  // null, or [n_steps][7]: PIDPOS target of each step
+    const S* target_table;  // null, or [n_steps][7]: PIDPOS target of each step
     LqrGains<T> lqr;
     PidGains<T> pid;
 };
 
-template <typename T> __device__ __forceinline__ T ld(const T* base, int row, int64_t N, int64_t e) {
+template <typename S> __device__ __forceinline__ S ld(const S* base, int row, int64_t N, int64_t e) {
     return base[(int64_t)row * N + e];
 }
-template <typename T> __device__ __forceinline__ void st(T* base, int row, int64_t N, int64_t e, T v) {
-    base[(int64_t)row * N + e] = v;
+template <typename S, typename V> __device__ __forceinline__ void st(S* base, int row, int64_t N, int64_t e, V v) {
+    base[(int64_t)row * N + e] = (S)v;
 }
 
-template <typename T>
-__device__ __forceinline__ void load_book(const T* ws, const int32_t* wsi, int64_t N, int64_t e, bool opt, Book<T>& bk) {
+template <typename T, typename S>
+__device__ __forceinline__ void load_book(const S* ws, const int32_t* wsi, int64_t N, int64_t e, bool opt, Book<T>& bk) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        bk.prev_ang[k] = ld(ws, ROW_PREV_ANG + k, N, e);
-        bk.ang[k] = opt ? ld(ws, ROW_ANG + k, N, e) : T(0);  // only the opt variant reads the old ang
+        bk.prev_ang[k] = (T)ld(ws, ROW_PREV_ANG + k, N, e);
+        bk.ang[k] = opt ? (T)ld(ws, ROW_ANG + k, N, e) : T(0);  // only the opt variant reads the old ang
         bk.ang_vel[k] = T(0);
     }
-    bk.prev_shaping = ld(ws, ROW_PREV_SHAPING, N, e);
-    bk.abs_sum = ld(ws, ROW_ABS_SUM, N, e);
-    bk.ep_return = ld(ws, ROW_EP_RETURN, N, e);
+    bk.prev_shaping = (T)ld(ws, ROW_PREV_SHAPING, N, e);
+    bk.abs_sum = (T)ld(ws, ROW_ABS_SUM, N, e);
+    bk.ep_return = (T)ld(ws, ROW_EP_RETURN, N, e);
     bk.reward = T(0);
     bk.i = wsi[IROW_I * N + e];
     bk.flags = wsi[IROW_FLAGS * N + e];
 }
 
-template <typename T>
-__device__ __forceinline__ void store_book(T* ws, int32_t* wsi, int64_t N, int64_t e, const Book<T>& bk, bool aux) {
+template <typename T, typename S>
+__device__ __forceinline__ void store_book(S* ws, int32_t* wsi, int64_t N, int64_t e, const Book<T>& bk, bool aux) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         st(ws, ROW_PREV_ANG + k, N, e, bk.prev_ang[k]);
@@ -88,27 +92,32 @@ __device__ __forceinline__ void store_book(T* ws, int32_t* wsi, int64_t N, int64
 #endif
 
 // quad.step for N envs: one launch, one lane per env.
-template <typename T, int INTEG>
-__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T> a) {
+template <typename T, typename S, int INTEG>
+__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
     if (a.mask && a.mask[e] == 0) return;
     const int64_t N = a.N;
     const Cfg<T>& cfg = a.cfg;
+    constexpr bool MIXED = !std::is_same<T, S>::value;
     T y[13];
+    S ys[13];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) y[k] = ld(a.ws, ROW_STATE + k, N, e);
+    for (int k = 0; k < 13; ++k) { ys[k] = ld(a.ws, ROW_STATE + k, N, e); y[k] = (T)ys[k]; }
     T raw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        raw[k] = a.actions ? a.actions[(int64_t)k * N + e] : ((cfg.direct || k == 0) ? cfg.zero_control0 : T(0));
+        raw[k] = a.actions ? (T)a.actions[(int64_t)k * N + e] : ((cfg.direct || k == 0) ? cfg.zero_control0 : T(0));
     T w[4], effort[4], cl[4], act[4], kq[13], dy[13];
     const T q_old[4] = {y[6], y[7], y[8], y[9]};
     Act<T> u;
     prepare_action(raw, cfg, w, effort, cl, act, u);
     integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy);
 #pragma unroll
-    for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, y[k]);
+    for (int k = 0; k < 13; ++k) {
+        if (MIXED) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; st(a.ws, ROW_STATE + k, N, e, ys[k]); }
+        else st(a.ws, ROW_STATE + k, N, e, y[k]);
+    }
     if (a.mode == QENV_STEP_DYNAMICS_ONLY) return;
 
     Book<T> bk;
@@ -132,13 +141,13 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T> 
     }
     if (a.out_obs) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) a.out_obs[(int64_t)k * N + e] = y[k];
+        for (int k = 0; k < 10; ++k) a.out_obs[(int64_t)k * N + e] = MIXED ? ys[k] : (S)y[k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a.out_obs[(int64_t)(10 + k) * N + e] = kq[6 + k];
+        for (int k = 0; k < 4; ++k) a.out_obs[(int64_t)(10 + k) * N + e] = (S)kq[6 + k];
     }
-    if (a.out_reward) a.out_reward[e] = bk.reward;
+    if (a.out_reward) a.out_reward[e] = (S)bk.reward;
     if (a.out_done) a.out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
-    if (a.out_mask) a.out_mask[e] = (bk.flags & FLAG_DONE) ? T(0) : T(1);
+    if (a.out_mask) a.out_mask[e] = (bk.flags & FLAG_DONE) ? S(0) : S(1);
     if (a.win) {  // dl_in_gen.dl_input: [raw action(4), vel(3), q(4), q_dot(4)] (dl_auxiliary.py:27-31)
         float* wv = a.win + (int64_t)a.win_slot * 15 * N + e;
 #pragma unroll
@@ -150,28 +159,30 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T> 
 }
 
 // n_steps env steps in one launch, controller on device, state in VGPRs throughout.
-template <typename T, int INTEG, int CTRL>
-__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T> a) {
+template <typename T, typename S, int INTEG, int CTRL>
+__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T, S> a) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
     const int64_t N = a.N;
     const Cfg<T>& cfg = a.cfg;
+    constexpr bool MIXED = !std::is_same<T, S>::value;
     T y[13];
+    S ys[13];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) y[k] = ld(a.ws, ROW_STATE + k, N, e);
+    for (int k = 0; k < 13; ++k) { ys[k] = ld(a.ws, ROW_STATE + k, N, e); y[k] = (T)ys[k]; }
     const bool dyn_only = a.mode == QENV_STEP_DYNAMICS_ONLY;
     Book<T> bk;
     if (!dyn_only) {
         load_book(a.ws, a.wsi, N, e, true, bk);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bk.ang_vel[k] = ld(a.ws, ROW_ANG_VEL + k, N, e);
+        for (int k = 0; k < 3; ++k) bk.ang_vel[k] = (T)ld(a.ws, ROW_ANG_VEL + k, N, e);
     }
     PidState<T> ps;
     if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { ps.ix[k] = ld(a.ws, ROW_PID + k, N, e); ps.x_old[k] = ld(a.ws, ROW_PID + 6 + k, N, e); }
+        for (int k = 0; k < 6; ++k) { ps.ix[k] = (T)ld(a.ws, ROW_PID + k, N, e); ps.x_old[k] = (T)ld(a.ws, ROW_PID + 6 + k, N, e); }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(a.ws, ROW_PID + 12 + k, N, e);
+        for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = (T)ld(a.ws, ROW_PID + 12 + k, N, e);
     }
     T w[4], effort[4], cl[4], act[4], kq[13], raw[4], dy[13];
     Act<T> u;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             if (a.target_table) {
                 T tg[7];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) tg[k] = a.target_table[s * 7 + k];  // wave-uniform address: scalar loads
+                for (int k = 0; k < 7; ++k) tg[k] = (T)a.target_table[s * 7 + k];  // wave-uniform address: scalar loads
                 pidpos_law(y, bk, ps, tg, cfg.t_step, raw);
             } else {
                 pidpos_law(y, bk, ps, a.pid_target, cfg.t_step, raw);
@@ -203,6 +214,10 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         }
         const T q_old[4] = {y[6], y[7], y[8], y[9]};
         integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy);
+        if (MIXED) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; }
+        }
         if (!dyn_only) {
             bk.i += 1;
             euler_update(q_old, y, dy, ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
@@ -211,7 +226,10 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         }
     }
 #pragma unroll
-    for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, y[k]);
+    for (int k = 0; k < 13; ++k) {
+        if (MIXED) st(a.ws, ROW_STATE + k, N, e, ys[k]);
+        else st(a.ws, ROW_STATE + k, N, e, y[k]);
+    }
     if (dyn_only) return;
     store_book(a.ws, a.wsi, N, e, bk, true);
 #pragma unroll
@@ -527,16 +545,16 @@ template <typename T> static PidGains<T> make_pid(bool clipped) {
 
 static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 255) / 256)); }
 
-template <typename T> static int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
-                                         void* out_reward, uint8_t* out_done, void* out_mask, int flags_in,
-                                         int win_slot) {
+template <typename T, typename S> static int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
+                                                     void* out_reward, uint8_t* out_done, void* out_mask, int flags_in,
+                                                     int win_slot) {
     const int flags = flags_in & QENV_STEP_MODE_MASK;
-    StepArgs<T> a;
+    StepArgs<T, S> a;
     a.cfg = make_cfg<T>(q);
-    a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N;
-    a.actions = (const T*)actions; a.mask = mask;
-    a.out_obs = (T*)out_obs; a.out_reward = (T*)out_reward; a.out_done = out_done; a.mode = flags;
-    a.out_mask = (T*)out_mask;
+    a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N;
+    a.actions = (const S*)actions; a.mask = mask;
+    a.out_obs = (S*)out_obs; a.out_reward = (S*)out_reward; a.out_done = out_done; a.mode = flags;
+    a.out_mask = (S*)out_mask;
     a.win = win_slot >= 0 ? q->window : nullptr;
     a.win_slot = win_slot;
     a.ang_ok = q->ang_ok;
@@ -546,15 +564,15 @@ template <typename T> static int do_step(qenv_s* q, const void* actions, const u
     else if (!mask) q->ang_ok = 1;
     const dim3 g = grid_for(q->N), b(256);
     switch (q->cfg.integrator) {
-        case QENV_RK45: hipLaunchKernelGGL((k_step<T, INT_RK45>), g, b, 0, q->stream, a); break;
-        case QENV_DP5: hipLaunchKernelGGL((k_step<T, INT_DP5>), g, b, 0, q->stream, a); break;
-        default: hipLaunchKernelGGL((k_step<T, INT_RK4>), g, b, 0, q->stream, a); break;
+        case QENV_RK45: hipLaunchKernelGGL((k_step<T, S, INT_RK45>), g, b, 0, q->stream, a); break;
+        case QENV_DP5: hipLaunchKernelGGL((k_step<T, S, INT_DP5>), g, b, 0, q->stream, a); break;
+        default: hipLaunchKernelGGL((k_step<T, S, INT_RK4>), g, b, 0, q->stream, a); break;
     }
     return check_launch("k_step");
 }
 
-template <typename T, int INTEG> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T>& a) {
-    if constexpr (sizeof(T) == 4) {
+template <typename T, typename S, int INTEG> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T, S>& a) {
+    if constexpr (sizeof(T) == 4 && sizeof(S) == 4) {
         if (q->packed && (q->N % 2) == 0) {  // two envs per lane, packed fp32 integrator
             const dim3 g2 = grid_for(q->N / 2), b2(256);
             switch (controller) {
@@ -568,19 +586,19 @@ template <typename T, int INTEG> static void launch_rollout(qenv_s* q, int contr
     }
     const dim3 g = grid_for(q->N), b(256);
     switch (controller) {
-        case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_CONST>), g, b, 0, q->stream, a); break;
-        case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_LQR>), g, b, 0, q->stream, a); break;
-        case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_PIDPOS>), g, b, 0, q->stream, a); break;
-        default: hipLaunchKernelGGL((k_rollout<T, INTEG, QENV_CTRL_PID>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_LQR>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PIDPOS>), g, b, 0, q->stream, a); break;
+        default: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PID>), g, b, 0, q->stream, a); break;
     }
 }
 
-template <typename T> static int do_rollout(qenv_s* q, int controller, int n_steps, const double* const_action,
-                                            int pid_first, int flags, const void* target_table = nullptr) {
-    RolloutArgs<T> a;
-    a.target_table = (const T*)target_table;
+template <typename T, typename S> static int do_rollout(qenv_s* q, int controller, int n_steps, const double* const_action,
+                                                        int pid_first, int flags, const void* target_table = nullptr) {
+    RolloutArgs<T, S> a;
+    a.target_table = (const S*)target_table;
     a.cfg = make_cfg<T>(q);
-    a.ws = (T*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
+    a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
     a.ang_ok = q->ang_ok;
     q->ang_ok = flags == QENV_STEP_DYNAMICS_ONLY ? 0 : 1;
     for (int k = 0; k < 7; ++k) a.pid_target[k] = (controller == QENV_CTRL_PIDPOS && const_action) ? (T)const_action[k] : (T)0;
@@ -591,30 +609,30 @@ template <typename T> static int do_rollout(qenv_s* q, int controller, int n_ste
     a.lqr = make_lqr<T>(q->cfg.clipped != 0);
     a.pid = make_pid<T>(q->cfg.clipped != 0);
     switch (q->cfg.integrator) {
-        case QENV_RK45: launch_rollout<T, INT_RK45>(q, controller, a); break;
-        case QENV_DP5: launch_rollout<T, INT_DP5>(q, controller, a); break;
-        default: launch_rollout<T, INT_RK4>(q, controller, a); break;
+        case QENV_RK45: launch_rollout<T, S, INT_RK45>(q, controller, a); break;
+        case QENV_DP5: launch_rollout<T, S, INT_DP5>(q, controller, a); break;
+        default: launch_rollout<T, S, INT_RK4>(q, controller, a); break;
     }
     return check_launch("k_rollout");
 }
 
-template <typename T> static int do_reset(qenv_s* q, const void* init, const uint8_t* mask, void* out_states,
-                                          void* out_actions, int push_window) {
+template <typename T, typename S> static int do_reset(qenv_s* q, const void* init, const uint8_t* mask, void* out_states,
+                                                      void* out_actions, int push_window) {
     const dim3 g = grid_for(q->N), b(256);
-    hipLaunchKernelGGL((k_reset<T>), g, b, 0, q->stream, (T*)q->ws, q->wsi, q->N, (const T*)init, mask);
+    hipLaunchKernelGGL((k_reset<S>), g, b, 0, q->stream, (S*)q->ws, q->wsi, q->N, (const S*)init, mask);
     int rc = check_launch("k_reset");
-    const Cfg<T> c = make_cfg<T>(q);
+    const Cfg<S> c = make_cfg<S>(q);
     for (int t = 0; t < q->cfg.T && rc == 0; ++t) {
-        T* obs = out_states ? (T*)out_states + (int64_t)t * 14 * q->N : nullptr;
+        S* obs = out_states ? (S*)out_states + (int64_t)t * 14 * q->N : nullptr;
         // warm-up slice t goes to ring slot head+t: after T of them the reset env's ring is full and in
         // phase with the (unmoved) head, whatever the other envs did meanwhile
-        rc = do_step<T>(q, nullptr, mask, obs, nullptr, nullptr, nullptr, QENV_STEP_FULL,
+        rc = do_step<T, S>(q, nullptr, mask, obs, nullptr, nullptr, nullptr, QENV_STEP_FULL,
                         push_window ? (q->win_head + t) % q->cfg.T : -1);
         if (rc == 0 && out_actions) {
-            T* oa = (T*)out_actions + (int64_t)t * 4 * q->N;
-            const T z = c.zero_control0;
-            hipLaunchKernelGGL((k_fill_actions<T>), g, b, 0, q->stream, oa, q->N, z, c.direct ? z : (T)0,
-                               c.direct ? z : (T)0, c.direct ? z : (T)0, mask);
+            S* oa = (S*)out_actions + (int64_t)t * 4 * q->N;
+            const S z = c.zero_control0;
+            hipLaunchKernelGGL((k_fill_actions<S>), g, b, 0, q->stream, oa, q->N, z, c.direct ? z : (S)0,
+                               c.direct ? z : (S)0, c.direct ? z : (S)0, mask);
             rc = check_launch("k_fill_actions");
         }
     }
@@ -641,6 +659,8 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     if (cfg->n_envs <= 0 || cfg->T < 1 || cfg->T > 64 || cfg->t_step <= 0)
         return fail(QENV_ERR_ARG, "qenv_create: n_envs, T (1..64) and t_step must be positive");
     if (cfg->dtype != QENV_F32 && cfg->dtype != QENV_F64) return fail(QENV_ERR_ARG, "qenv_create: bad dtype");
+    if (cfg->compute != QENV_COMPUTE_NATIVE && !(cfg->compute == QENV_COMPUTE_F32 && cfg->dtype == QENV_F64))
+        return fail(QENV_ERR_ARG, "qenv_create: compute must be NATIVE, or F32 on a QENV_F64 handle");
     if (cfg->integrator < QENV_RK45 || cfg->integrator > QENV_RK4) return fail(QENV_ERR_ARG, "qenv_create: bad integrator");
     if (cfg->variant != QENV_MAIN && cfg->variant != QENV_OPT) return fail(QENV_ERR_ARG, "qenv_create: bad variant");
     const WsLayout L = ws_layout(*cfg);
@@ -699,8 +719,10 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
 int qenv_reset(qenv_t q, const void* init_states, const uint8_t* mask, void* out_states, void* out_actions,
                int push_window) {
     if (!q || !init_states) return fail(QENV_ERR_ARG, "qenv_reset: null argument");
-    return q->cfg.dtype == QENV_F64 ? do_reset<double>(q, init_states, mask, out_states, out_actions, push_window)
-                                    : do_reset<float>(q, init_states, mask, out_states, out_actions, push_window);
+    if (q->cfg.dtype == QENV_F64)
+        return q->cfg.compute == QENV_COMPUTE_F32 ? do_reset<float, double>(q, init_states, mask, out_states, out_actions, push_window)
+                                                  : do_reset<double, double>(q, init_states, mask, out_states, out_actions, push_window);
+    return do_reset<float, float>(q, init_states, mask, out_states, out_actions, push_window);
 }
 
 int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, uint8_t* out_done, void* out_mask,
@@ -714,8 +736,10 @@ int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, ui
         return fail(QENV_ERR_STATE, "qenv_step: PUSH_WINDOW needs a full step (the slice holds q_dot)");
     const int slot = push ? q->win_head : -1;
     const int rc = q->cfg.dtype == QENV_F64
-                       ? do_step<double>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot)
-                       : do_step<float>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot);
+                       ? (q->cfg.compute == QENV_COMPUTE_F32
+                              ? do_step<float, double>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot)
+                              : do_step<double, double>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot))
+                       : do_step<float, float>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot);
     if (push && rc == 0) q->win_head = (q->win_head + 1) % q->cfg.T;
     return rc;
 }
@@ -730,8 +754,10 @@ int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_acti
     if (controller != QENV_CTRL_CONST && q->cfg.direct_control)
         return fail(QENV_ERR_STATE, "qenv_rollout: LQR/PID command [F,Mx,My,Mz]; create the handle with direct_control=0");
     if (n_steps == 0) return QENV_OK;
-    return q->cfg.dtype == QENV_F64 ? do_rollout<double>(q, controller, n_steps, const_action, pid_first_action, flags)
-                                    : do_rollout<float>(q, controller, n_steps, const_action, pid_first_action, flags);
+    if (q->cfg.dtype == QENV_F64)
+        return q->cfg.compute == QENV_COMPUTE_F32 ? do_rollout<float, double>(q, controller, n_steps, const_action, pid_first_action, flags)
+                                                  : do_rollout<double, double>(q, controller, n_steps, const_action, pid_first_action, flags);
+    return do_rollout<float, float>(q, controller, n_steps, const_action, pid_first_action, flags);
 }
 
 int qenv_rollout_track(qenv_t q, int n_steps, const void* targets, int flags) {
@@ -740,8 +766,10 @@ int qenv_rollout_track(qenv_t q, int n_steps, const void* targets, int flags) {
     if (flags != QENV_STEP_FULL && flags != QENV_STEP_NO_AUX) return fail(QENV_ERR_ARG, "qenv_rollout_track: bad flags");
     if (q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_rollout_track: the PD commands [F,Mx,My,Mz]; direct_control=0");
     if (n_steps == 0) return QENV_OK;
-    return q->cfg.dtype == QENV_F64 ? do_rollout<double>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets)
-                                    : do_rollout<float>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets);
+    if (q->cfg.dtype == QENV_F64)
+        return q->cfg.compute == QENV_COMPUTE_F32 ? do_rollout<float, double>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets)
+                                                  : do_rollout<double, double>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets);
+    return do_rollout<float, float>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets);
 }
 
 int qenv_lqr_action(qenv_t q, void* out_actions) {

@@ -103,9 +103,12 @@ class BatchedQuad:
     """
 
     def __init__(self, n_envs, t_step, n, training=True, euler=0, direct_control=1, T=1, clipped=True,
-                 variant="main", integrator="rk45", device="cuda", dtype=torch.float32):
+                 variant="main", integrator="rk45", device="cuda", dtype=torch.float32, compute=None):
+        """compute="f32" on dtype=torch.float64 selects the mixed handle: fp64 rows, fp32 arithmetic."""
         if dtype not in (torch.float32, torch.float64):
             raise ValueError("dtype must be torch.float32 or torch.float64")
+        if compute not in (None, "native", "f32") or (compute == "f32" and dtype != torch.float64):
+            raise ValueError("compute must be None/'native', or 'f32' together with dtype=torch.float64")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BatchedQuad runs on the GPU only (device='cuda[:i]'); there is no CPU path")
@@ -124,7 +127,8 @@ class BatchedQuad:
         self.J_mat = J
         self._cfg = L.QenvConfig(self.n_envs, float(t_step), int(n), self.T, int(bool(training)),
                                  int(bool(direct_control)), int(bool(clipped)), L.VARIANTS[variant],
-                                 L.INTEGRATORS[integrator], L.F64 if dtype == torch.float64 else L.F32)
+                                 L.INTEGRATORS[integrator], L.F64 if dtype == torch.float64 else L.F32,
+                                 1 if compute == "f32" else 0)
         nbytes = L.lib.qenv_workspace_bytes(C.byref(self._cfg))
         if nbytes == 0:
             raise L.QenvError("qenv_workspace_bytes rejected the configuration")

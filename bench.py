@@ -57,7 +57,8 @@ def parse():
     p.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     p.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the workload's own size)")
     p.add_argument("--integrator", default="rk45", choices=["rk45", "dp5", "rk4"])
-    p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    p.add_argument("--dtype", default="f32", choices=["f32", "f64", "mix"],
+                   help="mix = fp64 rows + fp32 arithmetic (QENV_COMPUTE_F32)")
     p.add_argument("--launch", default="fused", choices=["step", "fused"],
                    help="step: one kernel launch per env step (quad.step API); fused: the whole K-step "
                         "region in ONE launch with the state held in registers (qenv_rollout)")
@@ -252,18 +253,19 @@ def main():
     n_global = envs_per_gpu * world
     lo, hi = shard_range(n_global, rank, world)
     dt = torch.float32 if args.dtype == "f32" else torch.float64
+    compute = "f32" if args.dtype == "mix" else None
 
     ppo = controller.startswith("ppo")
 
     def build_env(integrator):
         if ppo:  # config 5 trains (solved/broken/timeout end episodes, 500-step episodes as ppo.py:301)
             env = BatchedQuad(hi - lo, 0.01, 500, training=(controller == "ppo_rollout"), direct_control=1, T=5,
-                              integrator=integrator, device=dev, dtype=dt)
+                              integrator=integrator, device=dev, dtype=dt, compute=compute)
             env.reset(torch.from_numpy(np.ascontiguousarray(make_init(args.workload, n_global, lo, hi).T)),
                       return_history=False, push_window=True)
             return env
         env = BatchedQuad(hi - lo, 0.01, 10 ** 9, training=False, direct_control=direct, T=1,
-                          integrator=integrator, device=dev, dtype=dt)
+                          integrator=integrator, device=dev, dtype=dt, compute=compute)
         env.reset(torch.from_numpy(np.ascontiguousarray(make_init(args.workload, n_global, lo, hi).T)))
         if controller == "pid":
             env.pid_reset()
@@ -305,7 +307,7 @@ def main():
         except Exception:
             traffic = None
     kname = ("k_rollout" if (args.launch == "fused" or controller != "const") else "k_step") + \
-            f"<{'float' if args.dtype == 'f32' else 'double'},{args.integrator}>"
+            f"<{'double' if args.dtype == 'f64' else 'float'},{args.integrator}>"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kname,
                 "kernel_us": k_us, "algorithmic_bytes_per_launch": algo_bytes,
@@ -329,7 +331,7 @@ def main():
         "metric": "quadrotor env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else "f64", "data": "synthetic",
+        "dtype": {"f32": "f32", "f64": "f64", "mix": "f32 arithmetic on f64 state rows"}[args.dtype], "data": "synthetic",
         "config": {"workload": desc, "envs_per_gpu": hi - lo, "global_envs": n_global,
                    "integrator": args.integrator, "launch": args.launch, "controller": controller,
                    "steps_per_graph_replay_or_launch": chunk, "hip_graph": (args.launch == "step" and not args.no_graph),

@@ -47,6 +47,11 @@ typedef enum {
 
 typedef enum { QENV_F32 = 0, QENV_F64 = 1 } qenv_dtype;
 
+/* QENV_COMPUTE_F32 on a QENV_F64 handle = "mixed": fp64 rows, fp32 arithmetic; the state rows advance by
+ * state += (double)increment, so the per-step rounding of an fp32 state never enters the closed loop
+ * (DESIGN.md section 5).  Same HBM bytes as fp64, ALU cost of fp32. */
+typedef enum { QENV_COMPUTE_NATIVE = 0, QENV_COMPUTE_F32 = 1 } qenv_compute;
+
 /* quadrotor_env.py (MAIN) vs quadrotor_env_opt.py (OPT) dynamics/reward variant */
 typedef enum { QENV_MAIN = 0, QENV_OPT = 1 } qenv_variant;
 
@@ -118,7 +123,8 @@ typedef struct {
     int32_t clipped;        /* f2w clipping (:218)                                     */
     int32_t variant;        /* qenv_variant                                            */
     int32_t integrator;     /* qenv_integrator                                         */
-    int32_t dtype;          /* qenv_dtype                                              */
+    int32_t dtype;          /* qenv_dtype: element type of the workspace and all arrays */
+    int32_t compute;        /* qenv_compute: arithmetic precision of step / rollout     */
 } qenv_config;
 
 /* ---- lifetime ------------------------------------------------------------------- */

@@ -415,3 +415,29 @@ def test_track_mission_in_one_launch(aq, oracle):
     for j in range(600):
         e2.step(e2.pidpos_action(tab[j]))
     assert torch.equal(e2.state, env.state)
+
+
+def test_mixed_handle_fp64_rows_fp32_arithmetic(aq):
+    """compute='f32' on a float64 handle: the state rows advance by state += (double)increment.  One step is as
+    accurate as the fp32 handle (the arithmetic is fp32), but nothing is rounded to fp32 between steps: the
+    1000-step open-loop run of config 2's slice stays within 5e-6 (fp32 handle: 7.5e-5; fp64: 5e-15)."""
+    g = golden("g4_step_direct")
+    n = len(g["x0"])
+    env = aq.BatchedQuad(n, 0.01, 1000, T=1, direct_control=1, dtype=torch.float64, compute="f32")
+    env.reset(_dev(g["x0"].T, "f64"))
+    obs, rew, done = env.step(_dev(g["action"].T, "f64"))
+    assert obs.dtype == torch.float64
+    assert scaled_err(_np(env.state).T, g["s_state"]) < 1e-5
+    assert np.max(np.abs(_np(rew) - g["s_reward"])) < 2e-3
+    h = golden("g6_hover_perturbed")
+    e2 = aq.BatchedQuad(64, 0.01, 2000, training=False, direct_control=1, T=1, dtype=torch.float64, compute="f32")
+    e2.reset(_dev(np.repeat(h["x0"][:, None], 64, 1), "f64"))
+    e2.rollout("const", 1000, flags=1)
+    assert rel_err(_np(e2.state)[:, 0], h["traj"][-1, :13]) < 5e-6
+    e3 = aq.BatchedQuad(64, 0.01, 2000, training=False, direct_control=1, T=1, dtype=torch.float64, compute="f32")
+    e3.reset(_dev(np.repeat(h["x0"][:, None], 64, 1), "f64"))
+    for _ in range(1000):
+        e3.step(None, flags=1)
+    assert torch.equal(e3.state, e2.state)
+    with pytest.raises(ValueError):
+        aq.BatchedQuad(4, 0.01, 10, dtype=torch.float32, compute="f32")
