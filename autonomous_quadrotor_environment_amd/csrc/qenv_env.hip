@@ -22,6 +22,8 @@ template <typename T, typename S = T> struct StepArgs {
     int64_t N;
     const S* actions;      // [4][N] or null (zero_control)
     const uint8_t* mask;   // null or [N]: only envs with mask != 0 are stepped
+    const int32_t* idx;    // null, or a compacted list of env indices (k_compact_mask) ...
+    const int32_t* count;  // ... and its length on the device: lane g steps env idx[g] if g < *count
     S* out_obs;            // [14][N] or null
     S* out_reward;         // [N] or null
     uint8_t* out_done;     // [N] or null
@@ -44,6 +46,10 @@ template <typename T, typename S = T> struct RolloutArgs {
     T const_action[4];
     T pid_target[7];
     const S* target_table;  // null, or [n_steps][7]: PIDPOS target of each step
+    const int32_t* idx;     // null, or compacted env list + its device-side length (masked reset warm-up)
+    const int32_t* count;
+    float* win;             // null, or the observation ring: step s also writes its slice to slot (win_head+s)%win_T
+    int32_t win_head, win_T;
     LqrGains<T> lqr;
     PidGains<T> pid;
 };
@@ -94,9 +100,12 @@ __device__ __forceinline__ void store_book(S* ws, int32_t* wsi, int64_t N, int64
 // quad.step for N envs: one launch, one lane per env.
 template <typename T, typename S, int INTEG>
 __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
-    if (a.mask && a.mask[e] == 0) return;
+    if (a.idx) {  // masked steps (reset warm-ups) run on the compacted list: only ceil(count/64) waves do any work
+        if (e >= *a.count) return;
+        e = a.idx[e];
+    } else if (a.mask && a.mask[e] == 0) return;
     const int64_t N = a.N;
     const Cfg<T>& cfg = a.cfg;
     constexpr bool MIXED = !std::is_same<T, S>::value;
@@ -161,8 +170,12 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, 
 // n_steps env steps in one launch, controller on device, state in VGPRs throughout.
 template <typename T, typename S, int INTEG, int CTRL>
 __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T, S> a) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
+    if (a.idx) {
+        if (e >= *a.count) return;
+        e = a.idx[e];
+    }
     const int64_t N = a.N;
     const Cfg<T>& cfg = a.cfg;
     constexpr bool MIXED = !std::is_same<T, S>::value;
@@ -223,6 +236,16 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             euler_update(q_old, y, dy, ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
             done_reward(y, act, effort, cfg, bk);
             ang_ok = true;  // from here on every env's prev_ang belongs to the state in its registers
+            if (a.win) {  // dl_in_gen.dl_input of this step (reset warm-up: raw action = the constant action)
+                int slot = a.win_head + s;
+                while (slot >= a.win_T) slot -= a.win_T;
+                float* wv = a.win + (int64_t)slot * 15 * N + e;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wv[(int64_t)k * N] = (float)(CTRL == QENV_CTRL_CONST ? a.const_action[k] : raw[k]);
+                wv[4 * N] = (float)y[1]; wv[5 * N] = (float)y[3]; wv[6 * N] = (float)y[5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
+            }
         }
     }
 #pragma unroll
@@ -351,6 +374,19 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
             for (int k = 0; k < 3; ++k) st(a.ws, ROW_PID + 12 + k, N, e, ps[c].ang_d_ant[k]);
         }
     }
+}
+
+// Compaction of a reset mask: idx[0..count) = the envs with mask != 0 (order across waves is arbitrary, which is
+// harmless: envs are independent).  One ballot + one atomic per wave.
+__global__ __launch_bounds__(256) void k_compact_mask(const uint8_t* mask, int64_t N, int32_t* idx, int32_t* count) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = e < N && mask[e] != 0;
+    const unsigned long long b = __ballot(on);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && b) base = atomicAdd(count, __popcll(b));
+    base = __shfl(base, 0);
+    if (on) idx[base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)e;
 }
 
 // quad.reset front half (quadrotor_env.py:428-445): load initial states, clear counters.
@@ -553,6 +589,8 @@ template <typename T, typename S> static int do_step(qenv_s* q, const void* acti
     a.cfg = make_cfg<T>(q);
     a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N;
     a.actions = (const S*)actions; a.mask = mask;
+    a.idx = nullptr; a.count = nullptr;
+    if (mask && q->compact_valid) { a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N; }
     a.out_obs = (S*)out_obs; a.out_reward = (S*)out_reward; a.out_done = out_done; a.mode = flags;
     a.out_mask = (S*)out_mask;
     a.win = win_slot >= 0 ? q->window : nullptr;
@@ -597,10 +635,15 @@ template <typename T, typename S> static int do_rollout(qenv_s* q, int controlle
                                                         int pid_first, int flags, const void* target_table = nullptr) {
     RolloutArgs<T, S> a;
     a.target_table = (const S*)target_table;
+    a.idx = nullptr; a.count = nullptr; a.win = nullptr; a.win_head = 0; a.win_T = q->cfg.T;
+    if (q->compact_valid) {  // called from a masked qenv_reset: warm-up of the reset envs only
+        a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N;
+        if (q->warmup_push) { a.win = q->window; a.win_head = q->win_head; }
+    }
     a.cfg = make_cfg<T>(q);
     a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
     a.ang_ok = q->ang_ok;
-    q->ang_ok = flags == QENV_STEP_DYNAMICS_ONLY ? 0 : 1;
+    if (!a.idx) q->ang_ok = flags == QENV_STEP_DYNAMICS_ONLY ? 0 : 1;  // a masked warm-up leaves the global flag alone
     for (int k = 0; k < 7; ++k) a.pid_target[k] = (controller == QENV_CTRL_PIDPOS && const_action) ? (T)const_action[k] : (T)0;
     for (int k = 0; k < 4; ++k)
         a.const_action[k] = (const_action && controller == QENV_CTRL_CONST)
@@ -621,7 +664,27 @@ template <typename T, typename S> static int do_reset(qenv_s* q, const void* ini
     const dim3 g = grid_for(q->N), b(256);
     hipLaunchKernelGGL((k_reset<S>), g, b, 0, q->stream, (S*)q->ws, q->wsi, q->N, (const S*)init, mask);
     int rc = check_launch("k_reset");
+    q->compact_valid = 0;
+    if (mask && rc == 0) {  // the T warm-up steps touch only the reset envs: run them on a compacted index list
+        hipError_t he = hipMemsetAsync(q->wsi + IROW_COUNT * q->N, 0, sizeof(int32_t), q->stream);
+        if (he != hipSuccess) return fail_hip(he, "hipMemsetAsync(count)");
+        hipLaunchKernelGGL(k_compact_mask, g, b, 0, q->stream, mask, q->N, q->wsi + IROW_IDX * q->N, q->wsi + IROW_COUNT * q->N);
+        rc = check_launch("k_compact_mask");
+        q->compact_valid = 1;
+    }
     const Cfg<S> c = make_cfg<S>(q);
+    if (mask && rc == 0 && !out_states && !out_actions) {
+        // masked reset inside a rollout: all T warm-up steps of the (few) reset envs in ONE launch -- their wall time
+        // is the latency of a single wave's step, so T launches cost T times that; state stays in registers
+        q->warmup_push = push_window;
+        const int keep = q->packed;
+        q->packed = 0;
+        rc = do_rollout<T, S>(q, QENV_CTRL_CONST, q->cfg.T, nullptr, 0, QENV_STEP_FULL);
+        q->packed = keep;
+        q->warmup_push = 0;
+        q->compact_valid = 0;
+        return rc;
+    }
     for (int t = 0; t < q->cfg.T && rc == 0; ++t) {
         S* obs = out_states ? (S*)out_states + (int64_t)t * 14 * q->N : nullptr;
         // warm-up slice t goes to ring slot head+t: after T of them the reset env's ring is full and in
@@ -636,6 +699,7 @@ template <typename T, typename S> static int do_reset(qenv_s* q, const void* ini
             rc = check_launch("k_fill_actions");
         }
     }
+    q->compact_valid = 0;
     return rc;
 }
 
@@ -673,6 +737,8 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->window = (float*)((char*)workspace + L.win_off);
     q->win_head = 0;
     q->ang_ok = 0;
+    q->compact_valid = 0;
+    q->warmup_push = 0;
     q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : 0;  // developer A/B switch
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
     if (e != hipSuccess) { delete q; return fail_hip(e, "hipMemsetAsync(workspace)"); }

@@ -32,7 +32,7 @@ enum {
     ROW_LAST_RETURN = 60,   // 1
     ROWS_T = 61
 };
-enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROWS = 3 };
+enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_COUNT = 4, IROWS = 5 };  // IDX/COUNT: compacted reset list
 
 struct WsLayout {
     size_t int_off, win_off, total;
@@ -60,6 +60,8 @@ struct qenv_s {
     int32_t* wsi;
     float* window;
     int32_t win_head;  // ring slot the next push writes
+    int32_t warmup_push;    // the masked warm-up in progress also refills the observation ring
+    int32_t compact_valid;  // the IDX/COUNT rows hold the compaction of the mask of the reset in progress
     int32_t packed;    // 1: fused rollouts use the two-envs-per-lane packed-fp32 kernels
     int32_t ang_ok;    // 1: no dynamics-only step since the last unmasked full step (see euler_update)
     hipStream_t stream;
