@@ -217,6 +217,22 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
                      const float *b1, const float *W2, const float *b2, const float *W3,
                      const float *b3, void *out, float *obs_store);
 
+/* ---- onboard sensor model: class sensor, environment/quadrotor_env.py:579-724 -------
+ * Batched IMU (bias drift + white noise), GPS, TRIAD attitude and the dead-reckoning integrators, evaluated the way
+ * visual_landing/rl_worker.py:164-175 (`sensor_sp`) calls them after every quad.step.  sens: caller-owned
+ * [QENV_SENSOR_ROWS][N] array in the handle's dtype (per-env sensor state).  Noise: injected standard normals
+ * (z27 [27][N] in the reference's draw order, u3 [3][N] uniforms for bias_reset) or, if NULL, Philox keyed by
+ * (seed; global env index, step).  error = sensor.error (0 disables noise and drift).
+ * qenv_sensor_read writes out [24][N] = states_sens[14] {x,vx,y,vy,z,vz dead-reckoned, quaternion_gyro[4],
+ * quaternion_vel[4]}, gps_pos[3], gps_vel[3], quaternion_triad[4].  It needs the ACCEL / W rows, i.e. the env must be
+ * stepped with QENV_STEP_FULL.  Faithful to the reference's aliasing quirk: after a reset, the first gyro
+ * integration advances the ENV's own quaternion rows in place (quaternion_t0 is a view of quad.state, :630,:719). */
+#define QENV_SENSOR_ROWS 25
+int qenv_sensor_reset(qenv_t q, void *sens, const void *u3, uint64_t seed, uint64_t episode,
+                      int64_t env_offset, int error);
+int qenv_sensor_read(qenv_t q, void *sens, const void *z27, uint64_t seed, uint64_t step,
+                     int64_t env_offset, int error, void *out);
+
 /* Dense tail of the legacy landing policy (visual_landing/rl_nn_model.py:58-66 actor, :77-84 critic):
  * Linear(K,H) tanh Linear(H,H) tanh Linear(H,n_out) [tanh] on flattened conv features (K = 800, H = 64,
  * n_out = 3 / 1) -- the GEMM-shaped part of that model; its conv front-end needs rendered camera images

@@ -587,6 +587,61 @@ def g16():
     save("g16_mission", **out)
 
 
+def g17():
+    """sensor (quadrotor_env.py:579-724) driven as rl_worker.py:164-175 does, with np.random patched so that every
+    normal draw is mean + std * z from a recorded standard-normal stream (the noise is an INPUT of the fixture)."""
+    rng = np.random.RandomState(117)
+    rec = {}
+    for tag, error in (("noisy", True), ("clean", False)):
+        env = make_env(t_step=0.01, n=1000, training=False, euler=0, direct_control=1, T=1)
+        x0 = rand_state(np.random.RandomState(7), 0.3)
+        with quiet:
+            env.reset(x0.copy())
+        sens = qe.sensor(env)
+        sens.error = error
+        zs, us = [], []
+        real_normal, real_random = np.random.normal, np.random.random
+
+        def fake_normal(loc=0.0, scale=1.0, size=None):
+            n = int(np.prod(size)) if size is not None else int(np.size(loc))
+            z = rng.normal(0, 1, n)
+            zs.append(z)
+            return np.asarray(loc) + np.asarray(scale) * (z if n > 1 or size is not None else z[0])
+
+        def fake_random(size=None):
+            u = rng.random_sample()
+            us.append(u)
+            return u
+        np.random.normal, np.random.random = fake_normal, fake_random
+        try:
+            sens.reset()
+            outs, states, acts = [], [], []
+            arng = np.random.RandomState(5)
+            for k in range(60):
+                _, vel_a, pos_a = sens.accel_int()
+                q_gyro = sens.gyro_int()
+                ang_vel = sens.gyro()
+                q_vel = qu.deriv_quat(ang_vel, q_gyro)
+                pos_gps, vel_gps = sens.gps()
+                q_triad, _ = sens.triad()
+                outs.append(np.concatenate([[pos_a[0], vel_a[0], pos_a[1], vel_a[1], pos_a[2], vel_a[2]], np.array(q_gyro, dtype=float),
+                                            q_vel, pos_gps, vel_gps, q_triad]))
+                states.append(np.array(env.state, dtype=float))
+                a = np.clip(arng.normal(0, 0.3, 4), -1, 1)
+                acts.append(a)
+                with quiet:
+                    env.step(a)
+        finally:
+            np.random.normal, np.random.random = real_normal, real_random
+        rec[f"{tag}_x0"] = x0
+        rec[f"{tag}_u3"] = np.array(us[:3])
+        rec[f"{tag}_z"] = np.concatenate(zs).reshape(60, 27)
+        rec[f"{tag}_out"] = np.array(outs)
+        rec[f"{tag}_state_before_step"] = np.array(states)
+        rec[f"{tag}_actions"] = np.array(acts)
+    save("g17_sensor", **rec)
+
+
 def g11():
     rng = np.random.RandomState(111)
     rows = []
@@ -615,6 +670,6 @@ def g11():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17"]
     for name in todo:
         globals()[name]()

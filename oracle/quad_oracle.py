@@ -310,6 +310,36 @@ class OraclePid:
         return a
 
 
+class _Sensor(C.Structure):
+    _fields_ = [("std", C.c_double * 5), ("a_b_d", C.c_double), ("g_b_d", C.c_double), ("m_b_d", C.c_double),
+                ("a_b_accel", C.c_double), ("g_b", C.c_double), ("position_t0", C.c_double * 3),
+                ("velocity_t0", C.c_double * 3), ("quaternion_t0", C.c_double * 4), ("R", C.c_double * 9),
+                ("quat_alias", C.c_int)]
+
+
+class OracleSensor:
+    """sensor of environment/quadrotor_env.py:579-724 with injected noise (z27 standard normals per sensor_sp call,
+    u3 uniform draws per reset, in the reference's draw order)."""
+
+    def __init__(self, env):
+        self.env = env
+        self._s = _Sensor()
+        assert lib().qo_sensor_size() == C.sizeof(_Sensor)
+        lib().qo_sensor_init(C.byref(self._s))
+
+    def reset(self, u3=(0.5, 0.5, 0.5), error=True):
+        lib().qo_sensor_reset(C.byref(self._s), C.byref(self.env._e), _p(_a(u3, 3)), int(bool(error)))
+
+    def sensor_sp(self, z27=None):
+        """rl_worker.py:164-175.  Returns (states_sens[14], gps_pos[3], gps_vel[3], quaternion_triad[4])."""
+        z = _a(np.zeros(27) if z27 is None else z27, 27)
+        w = np.array(self.env._e.w[:])
+        f_thrust = 1.435e-5 * float(np.sum(w * w))
+        out = np.zeros(24)
+        lib().qo_sensor_sp(C.byref(self._s), C.byref(self.env._e), C.c_double(f_thrust), _p(z), _p(out))
+        return out[:14], out[14:17], out[17:20], out[20:24]
+
+
 class OraclePidPos:
     """pid_control of environment/controller/PID_control.py:29-106 (position tracking)."""
 

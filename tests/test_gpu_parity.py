@@ -441,3 +441,39 @@ def test_mixed_handle_fp64_rows_fp32_arithmetic(aq):
     assert torch.equal(e3.state, e2.state)
     with pytest.raises(ValueError):
         aq.BatchedQuad(4, 0.01, 10, dtype=torch.float32, compute="f32")
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-11), ("f32", 2e-4)])
+def test_sensor_model_golden(aq, dt, tol):
+    """G17: batched sensor (IMU / GPS / TRIAD / dead reckoning) with the recorded noise stream injected; the env is
+    stepped with the recorded actions in between, so the aliasing quirk's effect on the dynamics is covered too."""
+    g = golden("g17_sensor")
+    for tag, error in (("noisy", True), ("clean", False)):
+        env = aq.BatchedQuad(4, 0.01, 1000, training=False, direct_control=1, T=1, dtype=DT[dt])
+        env.reset(_dev(np.repeat(g[tag + "_x0"][:, None], 4, 1), dt))
+        s = aq.BatchedSensor(env, error=error)
+        s.reset(_dev(np.repeat(g[tag + "_u3"][:, None], 4, 1), dt))
+        for k in range(60):
+            out = _np(s.sensor_sp(_dev(np.repeat(g[tag + "_z"][k][:, None], 4, 1), dt)))
+            ref = g[tag + "_out"][k]
+            assert np.max(np.abs(out[:, 2] - ref) / np.maximum(np.abs(ref), 1.0)) < tol * (1 + k), (tag, k)
+            assert scaled_err(_np(env.state)[:, 1], g[tag + "_state_before_step"][k]) < tol * 5
+            env.step(_dev(np.repeat(g[tag + "_actions"][k][:, None], 4, 1), dt))
+
+
+def test_sensor_philox_noise_statistics(aq):
+    n = 100000
+    env = aq.BatchedQuad(n, 0.01, 1000, training=False, direct_control=1, T=1)
+    x0 = np.zeros((13, n)); x0[6] = 1
+    env.reset(torch.from_numpy(x0))
+    s = aq.BatchedSensor(env, seed=3)
+    s.reset()
+    env.step(None)
+    out = _np(s.sensor_sp())
+    st = _np(env.state)
+    assert abs((out[14] - st[0]).std() - 1.71) < 0.03 and abs((out[17] - st[1]).std() - 0.5) < 0.01   # gps
+    assert abs(out[14].mean() - st[0].mean()) < 0.03
+    assert np.allclose(np.linalg.norm(out[20:24], axis=0), 1, atol=1e-5)  # TRIAD quaternion
+    s2 = aq.BatchedSensor(env, seed=3); s2._ws.copy_(s._ws); s2.calls = s.calls - 1
+    # determinism of the Philox stream: same (seed, step) -> same noise (GPS rows do not depend on sensor state)
+    assert torch.equal(s2.sensor_sp()[14:20], torch.from_numpy(out[14:20]).float().cuda())

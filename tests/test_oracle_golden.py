@@ -281,3 +281,20 @@ def test_g15_ppo_loss(oracle):
     # scale**2 and log(scale) in fp32: the reference's own numbers carry ~1e-7 of that; the oracle is fp64
     assert abs(out[0] - g["loss"]) < 2e-6 and abs(out[1] - g["actor"]) < 2e-6
     assert abs(out[2] - g["critic"]) < 1e-12 and abs(out[3] - g["entropy"]) < 1e-8
+
+
+def test_g17_sensor_model(oracle):
+    """sensor (quadrotor_env.py:579-724) as rl_worker.py:164-175 drives it, with the reference's normal draws replaced
+    by a recorded stream: IMU bias drift, GPS, TRIAD (scipy from_matrix/as_quat), dead reckoning, and the in-place
+    quaternion update through the numpy view after reset."""
+    g = golden("g17_sensor")
+    for tag, error in (("noisy", True), ("clean", False)):
+        env = oracle.OracleQuad(0.01, 1000, training=False, direct_control=1, T=1)
+        env.reset(g[tag + "_x0"])
+        s = oracle.OracleSensor(env)
+        s.reset(g[tag + "_u3"], error)
+        for k in range(60):
+            out = np.concatenate(s.sensor_sp(g[tag + "_z"][k]))
+            assert np.max(np.abs(out - g[tag + "_out"][k])) < 1e-12, (tag, k)
+            assert np.max(np.abs(env.state - g[tag + "_state_before_step"][k])) < 1e-12, (tag, k)
+            env.step(g[tag + "_actions"][k])
