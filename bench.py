@@ -67,7 +67,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="launch=step: eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    p.add_argument("--extras", action="store_true", help="also time the other integrators / launch modes / sizes")
+    p.add_argument("--extras", action="store_true", help="also time the other integrators / launch modes")
+    p.add_argument("--no-extras", action="store_true", help="skip the extras that the default 1-GPU config-2 run adds")
     return p.parse_args()
 
 
@@ -339,7 +340,9 @@ def main():
         "roofline": roofline,
     }
 
-    if args.extras and world == 1 and not ppo:
+    # the default single-GPU run of config 2 also reports the other operating points (a few seconds): the
+    # per-step API path (hipGraph-replayed qenv_step launches) and the fixed-step integrators
+    if (args.extras or (args.workload == "config2" and not args.no_extras and args.envs == 0)) and world == 1 and not ppo:
         extras = {}
         for integ in ("rk45", "dp5", "rk4"):
             e2 = build_env(integ)
