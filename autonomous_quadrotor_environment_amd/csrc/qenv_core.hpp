@@ -266,13 +266,21 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
 // (FSAL) whose rows 6..9 are the reference's V_q.  Every lane leaves the loop after at
 // most MAX_ATTEMPTS attempts.
 template <typename T>
-__device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13]) {
+__device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13],
+                                               bool have_f0 = false) {
     using m = Mth<T>;
     constexpr int MAX_ATTEMPTS = 96;
     T k1[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) dy[i] = T(0);
-    rhs(y, u, cm_xy, cm_z, k1);
+    // have_f0 (wave-uniform): kq already holds f(y) from the previous env step of the same rollout with the same
+    // actuation (FSAL across env steps): the same numbers rhs() would return, so results do not change
+    if (have_f0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) k1[i] = kq[i];
+    } else {
+        rhs(y, u, cm_xy, cm_z, k1);
+    }
     T h_abs;
     {
         T d0 = T(0), d1 = T(0);
@@ -432,18 +440,30 @@ __device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, F2
 }
 
 template <typename T>
-__device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13]) {
+__device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13],
+                                              bool have_f0 = false) {
     T k1[13], yn[13];
-    rhs(y, u, cm_xy, cm_z, k1);
+    if (have_f0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) k1[i] = kq[i];
+    } else {
+        rhs(y, u, cm_xy, cm_z, k1);
+    }
     dp5_step<T, false>(y, k1, u, cm_xy, cm_z, tb, yn, kq, dy);
 #pragma unroll
     for (int i = 0; i < 13; ++i) y[i] = yn[i];
 }
 
 template <typename T>
-__device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, T cm_xy, T cm_z, T h, T kq[13], T dy[13]) {
+__device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, T cm_xy, T cm_z, T h, T kq[13], T dy[13],
+                                              bool have_f0 = false) {
     T k1[13], k2[13], k3[13], k4[13], ys[13];
-    rhs(y, u, cm_xy, cm_z, k1);
+    if (have_f0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) k1[i] = kq[i];
+    } else {
+        rhs(y, u, cm_xy, cm_z, k1);
+    }
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + T(0.5) * h * k1[i];
     rhs(ys, u, cm_xy, cm_z, k2);
@@ -468,10 +488,11 @@ template <typename T, int INTEG>
 // On exit: y = state at tb, kq = f(t_end, y_end), dy = y_end - y_start as the SUM OF THE
 // INTEGRATOR'S INCREMENTS (not the difference of the rounded states): the cancellation-free input
 // of the increment-based Euler rates below.
-__device__ __forceinline__ void integrate(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13]) {
-    if (INTEG == INT_RK45) integrate_rk45(y, u, cm_xy, cm_z, tb, kq, dy);
-    else if (INTEG == INT_DP5) integrate_dp5(y, u, cm_xy, cm_z, tb, kq, dy);
-    else integrate_rk4(y, u, cm_xy, cm_z, tb, kq, dy);
+__device__ __forceinline__ void integrate(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13],
+                                          bool have_f0 = false) {
+    if (INTEG == INT_RK45) integrate_rk45(y, u, cm_xy, cm_z, tb, kq, dy, have_f0);
+    else if (INTEG == INT_DP5) integrate_dp5(y, u, cm_xy, cm_z, tb, kq, dy, have_f0);
+    else integrate_rk4(y, u, cm_xy, cm_z, tb, kq, dy, have_f0);
 }
 
 template <int INTEG>

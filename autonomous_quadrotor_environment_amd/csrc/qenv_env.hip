@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             prepare_action(raw, cfg, w, effort, cl, act, u);
         }
         const T q_old[4] = {y[6], y[7], y[8], y[9]};
-        integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy);
+        // constant actuation: f(y_end) of the previous step IS f0 of this one (not in the mixed handle, where the
+        // step starts from the re-rounded fp64 state)
+        integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !MIXED && s > 0);
         if (MIXED) {
 #pragma unroll
             for (int k = 0; k < 13; ++k) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; }
