@@ -642,6 +642,77 @@ def g17():
     save("g17_sensor", **rec)
 
 
+def g18():
+    """robust_control (quadrotor_env.py:84-109): the flag is an attribute the user flips after construction (:183).
+    Harness-side adaptation: robust_control.reset stores episode_m as a 1-element array, which numpy >= 1.24 refuses
+    to mix with scalars in drone_eq's output list (:401, an ordinary ValueError); the instance's reset is wrapped to
+    turn it into the same number as a float.  np.random.normal is wrapped only to RECORD the gust triples it returns
+    (the global seeded stream is untouched), so the draws are inputs of the fixture."""
+    rec = {}
+    cases = (("direct", 1, 1, 520, 11), ("indirect", 0, 5, 520, 12), ("direct_resets", 1, 1, 40, 13))
+    for tag, direct, T, steps, seed in cases:
+        env = make_env(t_step=0.01, n=2000, training=True, euler=0, direct_control=direct, T=T)
+        env.robust_control = True
+        rp = env.robust_parameters
+        orig_reset = rp.reset
+
+        def reset_float_m(orig=orig_reset, rp=rp):
+            orig()
+            rp.episode_m = float(np.asarray(rp.episode_m).ravel()[0])
+        rp.reset = reset_float_m
+        gusts = []
+        real_normal = np.random.normal
+
+        def rec_normal(loc=0.0, scale=1.0, size=None):
+            out = real_normal(loc, scale, size)
+            if np.shape(out) == (3, 1):
+                gusts.append(np.array(out, dtype=float).ravel())
+            return out
+        np.random.normal = rec_normal
+        try:
+            env.seed(seed)
+            arng = np.random.RandomState(seed + 100)
+            episodes = 3 if tag == "direct_resets" else 1
+            for ep in range(episodes):
+                x0 = rand_state(np.random.RandomState(seed + 7 * ep), 0.3)
+                with quiet:
+                    st, _ = env.reset(x0.copy())
+                params = np.concatenate([rp.episode_kf, [rp.episode_m], rp.episode_ir, np.diag(rp.episode_J)])
+                rows = {k: [] for k in ("actions", "state", "quat_state", "reward", "done", "step_effort",
+                                        "clipped_action", "accel", "w", "nfev_draws")}
+                n_before = len(gusts)
+                for k in range(steps):
+                    if direct:
+                        a = np.clip(arng.normal(0, 0.3, 4), -1.2, 1.2)
+                    else:
+                        a = np.array([qe.M * qe.G, 0, 0, 0]) + arng.normal(0, [1.0, 0.05, 0.05, 0.02])
+                    g0 = len(gusts)
+                    with quiet:
+                        qs, r, d = env.step(a)
+                    rows["actions"].append(a)
+                    rows["state"].append(np.array(env.state, dtype=float))
+                    rows["quat_state"].append(np.array(qs, dtype=float).ravel())
+                    rows["reward"].append(float(r))
+                    rows["done"].append(bool(d))
+                    rows["step_effort"].append(np.array(env.step_effort, dtype=float).ravel())
+                    rows["clipped_action"].append(np.array(env.clipped_action, dtype=float).ravel())
+                    rows["accel"].append(np.array(env.accel, dtype=float).ravel())
+                    rows["w"].append(np.array(env.w, dtype=float).ravel())
+                    rows["nfev_draws"].append(len(gusts) - g0)
+                pre = f"{tag}_ep{ep}_"
+                rec[pre + "x0"] = x0
+                rec[pre + "params"] = params
+                rec[pre + "reset_states"] = np.array(st, dtype=float)
+                rec[pre + "gusts_after_reset"] = np.array([n_before])
+                for k, v in rows.items():
+                    rec[pre + k] = np.array(v)
+        finally:
+            np.random.normal = real_normal
+        rec[f"{tag}_gusts"] = np.array(gusts)
+        rec[f"{tag}_meta"] = np.array([direct, T, steps, seed])
+    save("g18_robust", **rec)
+
+
 def g11():
     rng = np.random.RandomState(111)
     rows = []
@@ -670,6 +741,6 @@ def g11():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18"]
     for name in todo:
         globals()[name]()

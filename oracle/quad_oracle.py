@@ -45,6 +45,9 @@ class _Env(C.Structure):
         ("reward", C.c_double), ("abs_sum", C.c_double),
         ("target_state", C.c_double), ("current_state", C.c_double),
         ("nfev", C.c_int), ("nsub", C.c_int),
+        ("robust", C.c_int), ("ep_kf", C.c_double * 4), ("ep_m", C.c_double), ("ep_ir", C.c_double * 4),
+        ("ep_J", C.c_double * 3), ("gust", C.c_double * 3), ("last_gust", C.c_double * 3),
+        ("gust_draws", C.c_void_p), ("gust_cursor", C.c_int), ("gust_count", C.c_int),
     ]
 
 
@@ -262,6 +265,21 @@ class OracleQuad:
         out = np.zeros(13)
         lib().qo_drone_eq(C.byref(self._e), _p(_a(x, 13)), _p(_a(action, 4)), _p(out))
         return out
+
+    def set_robust(self, on=True, params=None, gust_draws=None):
+        """env.robust_control = on; params = the 12 episode draws (kf4, m, ir4, J3), gust_draws [n,3] = the
+        np.random.normal(0,[5,5,2]) triples robust_control.wind consumes, in call order."""
+        pp = _a(params, 12) if params is not None else None
+        if gust_draws is not None:
+            self._gd = _a(gust_draws).reshape(-1, 3).copy()
+            lib().qo_set_robust(C.byref(self._e), int(bool(on)), _p(pp) if pp is not None else None,
+                                _p(self._gd), int(self._gd.shape[0]))
+        else:
+            lib().qo_set_robust(C.byref(self._e), int(bool(on)), _p(pp) if pp is not None else None, None, -1)
+
+    gust_cursor = property(lambda s: s._e.gust_cursor)
+    gust = property(lambda s: s._vec("gust"))
+    last_gust = property(lambda s: s._vec("last_gust"))
 
     def set_w(self, w):
         for k in range(4):

@@ -3,7 +3,7 @@ reference itself (oracle/gen_golden.py).  This is what pins the oracle."""
 import numpy as np
 import pytest
 
-from .conftest import golden, rel_err
+from .conftest import STATE_SCALE, golden, rel_err, scaled_err
 
 TOL = 1e-11  # fp64 restatement vs fp64 reference
 
@@ -298,3 +298,40 @@ def test_g17_sensor_model(oracle):
             assert np.max(np.abs(out - g[tag + "_out"][k])) < 1e-12, (tag, k)
             assert np.max(np.abs(env.state - g[tag + "_state_before_step"][k])) < 1e-12, (tag, k)
             env.step(g[tag + "_actions"][k])
+
+
+# ---- N2: robust_control (quadrotor_env.py:84-109) ---------------------------------------------------------------
+def _robust_replay(O, g, tag, episodes):
+    direct, T, steps, _ = (int(v) for v in g[f"{tag}_meta"])
+    env = O.OracleQuad(0.01, 2000, training=True, euler=0, direct_control=direct, T=T)
+    gusts = g[f"{tag}_gusts"]
+    env.set_robust(True, gust_draws=gusts)
+    worst = 0.0
+    for ep in range(episodes):
+        pre = f"{tag}_ep{ep}_"
+        env.set_robust(True, params=g[pre + "params"])
+        st, _ = env.reset(g[pre + "x0"])
+        assert env.gust_cursor == int(g[pre + "gusts_after_reset"][0])  # draws of the warm-up steps (i = 1)
+        worst = max(worst, scaled_err(st[:, :13], g[pre + "reset_states"][:, :13], STATE_SCALE))
+        for k in range(steps):
+            c0 = env.gust_cursor
+            qs, r, d = env.step(g[pre + "actions"][k])
+            assert env.gust_cursor - c0 == int(g[pre + "nfev_draws"][k]), (tag, ep, k)
+            worst = max(worst, scaled_err(env.state, g[pre + "state"][k], STATE_SCALE))
+            assert rel_err(env.step_effort, g[pre + "step_effort"][k], floor=1.0) < 1e-12
+            assert rel_err(env.clipped_action, g[pre + "clipped_action"][k], floor=1.0) < 1e-12
+            assert rel_err(env.accel.ravel(), g[pre + "accel"][k], floor=1.0) < 1e-9
+            assert rel_err(env.w.ravel(), g[pre + "w"][k], floor=100.0) < 1e-12
+            assert abs(r - g[pre + "reward"][k]) < 1e-8 * max(1.0, abs(g[pre + "reward"][k]))
+            assert bool(d) == bool(g[pre + "done"][k])
+    assert env.gust_cursor == gusts.shape[0]  # every recorded draw consumed, none missing
+    return worst
+
+
+@pytest.mark.parametrize("tag,episodes", [("direct", 1), ("indirect", 1), ("direct_resets", 3)])
+def test_robust_control_matches_reference(oracle, tag, episodes):
+    """The reference with env.robust_control = True: episode parameter perturbation, per-RHS-evaluation gust
+    redraw in the steps with i % 500 == 1 (hundreds of rejected sub-steps), linspace wind in between, gust state
+    surviving reset().  The oracle consumes the recorded gust triples in the same order and count."""
+    g = golden("g18_robust")
+    assert _robust_replay(oracle, g, tag, episodes) < 1e-9
