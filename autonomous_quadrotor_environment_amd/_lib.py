@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 1
+QENV_ABI_VERSION = 2
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -23,7 +23,8 @@ FLAG_DONE, FLAG_SOLVED, FLAG_HAS_SHAPING = 1, 2, 4
 
 (FIELD_STATE, FIELD_ANG, FIELD_PREV_ANG, FIELD_ANG_VEL, FIELD_VQ, FIELD_W, FIELD_STEP_EFFORT,
  FIELD_CLIPPED_ACTION, FIELD_ACCEL, FIELD_PREV_SHAPING, FIELD_REWARD, FIELD_ABS_SUM, FIELD_EP_RETURN,
- FIELD_PID, FIELD_I, FIELD_FLAGS, FIELD_WINDOW, FIELD_LAST_RETURN, FIELD_EPISODES) = range(19)
+ FIELD_PID, FIELD_I, FIELD_FLAGS, FIELD_WINDOW, FIELD_LAST_RETURN, FIELD_EPISODES, FIELD_ROBUST_PARAMS,
+ FIELD_GUST, FIELD_GUST_EVALS) = range(22)
 
 
 class QenvConfig(C.Structure):
@@ -62,6 +63,9 @@ SYMBOLS = {
     "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
+    "qenv_set_robust": (_i, [_vp, _i]),
+    "qenv_robust_params": (_i, [_vp, _vp, C.c_uint64, _i64, _vp]),
+    "qenv_robust_gusts": (_i, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, _i64]),
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adv_normalize": (_i, [_i, _i64, _vp, _vp, _i, _vp]),
     "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 13),

@@ -110,9 +110,128 @@ template <typename T> struct Act {
     T F, Mx, My, Mz, omr;  // omr = (-w1+w2-w3+w4)*I_R
 };
 
-// f2F, quadrotor_env.py:247-272 (direct mode).  a = clipped action in [-1,1].
+// The plant the RHS integrates.  Nominal: the constants above plus the variant's drag-moment coefficients.
+// Robust (robust_control, quadrotor_env.py:84-109, flag :183): the episode's perturbed thrust coefficients, mass,
+// rotor inertias and body inertia, and the gust process -- per env, in registers for the whole step.
+template <typename T, bool ROBUST> struct Plant;
+template <typename T> struct Plant<T, false> {
+    static constexpr bool robust = false;
+    T cm_xy, cm_z;
+};
+constexpr int GUST_PERIOD = 500;  // robust_control.gust_period (:94)
+template <typename T> struct Plant<T, true> {
+    static constexpr bool robust = true;
+    T cm_xy, cm_z;
+    T kf[4];           // episode_kf: fraction of thrust lost per rotor (:98)
+    T ir[4];           // I_R (1 + episode_ir) (:342)
+    T inv_m, mg;       // 1/quad_m and quad_m G, quad_m = M (1 + episode_m) (:361)
+    T ij[3];           // 1 / (J_k + J_k episode_J_k) (:382)
+    T gust[3], last[3];  // robust_control.gust / last_gust: end points of linear_wind_change
+    T wind[3];         // this step's wind when it is not a redraw step
+    bool redraw;       // i % 500 == 1: EVERY RHS evaluation of this step draws a new gust and sees the previous one
+    int32_t k;         // RHS evaluations of this step so far = index of the next draw
+    int32_t evals;     // draws consumed by the most recent redraw step seen by this lane (-1: none yet)
+    // draw source: an injected table [E][K][3][N] (parity runs) or Philox keyed by (seed; env, episode, epoch, k)
+    const void* table; int32_t table_f64, table_E, table_K, epoch;
+    int64_t N, e;      // row stride and this lane's env
+    uint32_t key0, key1, ctr0, ctr1, episode;
+};
+
+// Philox4x32-10 (Salmon et al. 2011), the same generator qenv_ppo.hip uses for actions and initial states.
+__device__ __forceinline__ void philox_core(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float philox_u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ void philox_normal2(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float r = sqrtf(-2.0f * logf(philox_u01(a)));
+    float sn, cs;
+    sincosf(6.283185307179586f * philox_u01(b), &sn, &cs);
+    z0 = r * cs; z1 = r * sn;
+}
+
+// One gust triple ~ N(0, [5,5,2]) (gust_std, :93): draw k of redraw epoch `epoch`.  Kept out of line on purpose: it
+// is needed only in the steps with i % 500 == 1, and inlining Philox + Box-Muller (logf, sincosf) into each of the
+// integrator's ~20 RHS call sites bloats the robust kernels into SGPR/VGPR spilling.
+template <typename T> struct Gust3 { T x, y, z; };
 template <typename T>
-__device__ __forceinline__ void mix_direct(const T a[4], T w[4], Act<T>& u) {
+__device__ __noinline__ Gust3<T> draw_gust(const void* table, int32_t f64, int32_t E, int32_t K, int32_t epoch, int32_t k,
+                                           int64_t N, int64_t e, uint32_t key0, uint32_t key1, uint32_t ctr0, uint32_t ctr1,
+                                           uint32_t episode) {
+    Gust3<T> g;
+    if (table) {
+        const int kk = k < K ? k : K - 1;
+        const int ee = epoch < E ? epoch : E - 1;
+        const int64_t base = ((int64_t)(ee * K + kk) * 3) * N + e;
+        if (f64) {
+            const double* t = (const double*)table;
+            g.x = (T)t[base]; g.y = (T)t[base + N]; g.z = (T)t[base + 2 * N];
+        } else {
+            const float* t = (const float*)table;
+            g.x = (T)t[base]; g.y = (T)t[base + N]; g.z = (T)t[base + 2 * N];
+        }
+    } else {
+        uint32_t c[4] = {ctr0, ctr1, episode, ((uint32_t)epoch << 16) | (uint32_t)(k & 0xFFFF)};
+        philox_core(c, key0, key1);
+        float z0, z1, z2, z3;
+        philox_normal2(c[0], c[1], z0, z1);
+        philox_normal2(c[2], c[3], z2, z3);
+        g.x = T(5) * (T)z0; g.y = T(5) * (T)z1; g.z = T(2) * (T)z2;
+    }
+    return g;
+}
+
+// robust_control.wind(i) as the k-th RHS evaluation of a step sees it (:102-108)
+template <typename T>
+__device__ __forceinline__ void next_wind(Plant<T, true>& pl, T wd[3]) {
+    if (pl.redraw) {
+        const Gust3<T> g = draw_gust<T>(pl.table, pl.table_f64, pl.table_E, pl.table_K, pl.epoch, pl.k, pl.N, pl.e,
+                                        pl.key0, pl.key1, pl.ctr0, pl.ctr1, pl.episode);
+        pl.last[0] = pl.gust[0]; pl.last[1] = pl.gust[1]; pl.last[2] = pl.gust[2];
+        pl.gust[0] = g.x; pl.gust[1] = g.y; pl.gust[2] = g.z;
+        wd[0] = pl.last[0]; wd[1] = pl.last[1]; wd[2] = pl.last[2];
+        pl.evals = pl.k + 1;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wd[c] = pl.wind[c];
+    }
+    pl.k += 1;
+}
+
+// Start of a step with step counter i (already incremented, :467): decide redraw / interpolate the wind.
+// linear_wind_change = np.linspace(last_gust, gust, 500); wind(i) returns row (i % 500) - 1, row -1 = the end.
+template <typename T>
+__device__ __forceinline__ void begin_step_wind(Plant<T, true>& pl, int32_t i) {
+    const int r = i % GUST_PERIOD;
+    pl.redraw = (r == 1);
+    pl.k = 0;
+    pl.epoch = (i - 1) / GUST_PERIOD;
+    const int j = (r == 0) ? GUST_PERIOD - 1 : r - 1;
+    T step[3];
+    bool any_zero = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        step[c] = (pl.gust[c] - pl.last[c]) / T(GUST_PERIOD - 1);
+        any_zero = any_zero || (step[c] == T(0));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        // numpy.linspace: j*step + start, or (j/div)*delta + start when any step is 0; the last row is `stop` exactly
+        if (j == GUST_PERIOD - 1) pl.wind[c] = pl.gust[c];
+        else if (any_zero) pl.wind[c] = (T(j) / T(GUST_PERIOD - 1)) * (pl.gust[c] - pl.last[c]) + pl.last[c];
+        else pl.wind[c] = T(j) * step[c] + pl.last[c];
+    }
+}
+
+// f2F, quadrotor_env.py:247-272 (direct mode).  a = clipped action in [-1,1].
+template <typename T, typename P>
+__device__ __forceinline__ void mix_direct(const T a[4], const P& pl, T w[4], Act<T>& u) {
     using m = Mth<T>;
     const T c = T(phys::M * phys::G) * T(phys::T2WR / 8.0);  // fl(M G)/4: four hover rotors sum to fl(M G) exactly
     T f[4];
@@ -120,18 +239,20 @@ __device__ __forceinline__ void mix_direct(const T a[4], T w[4], Act<T>& u) {
     for (int k = 0; k < 4; ++k) {
         f[k] = (a[k] + T(1)) * c;
         w[k] = m::sqrt(f[k] * T(1.0 / phys::K_F));
+        if constexpr (P::robust) f[k] = f[k] - pl.kf[k] * f[k];  // after w (:265-266)
     }
     u.F = (f[0] + f[1]) + (f[2] + f[3]);
     u.Mx = (f[2] - f[0]) * T(phys::D);
     u.My = (f[1] - f[3]) * T(phys::D);
     u.Mz = ((f[1] - f[0]) + (f[3] - f[2])) * T(phys::K_M / phys::K_F);
-    u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
+    if constexpr (P::robust) u.omr = ((w[1] * pl.ir[1] - w[0] * pl.ir[0]) + (w[3] * pl.ir[3] - w[2] * pl.ir[2]));
+    else u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
 }
 
 // f2w, quadrotor_env.py:197-245 / quadrotor_env_opt.py:144-176 (indirect mode), with the
 // closed-form inverse of the 4x4 mixing matrix.
-template <typename T>
-__device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool opt, T w[4], T effort[4],
+template <typename T, typename P>
+__device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool opt, const P& pl, T w[4], T effort[4],
                                              T cl[4], Act<T>& u) {
     using m = Mth<T>;
     const T a = act[0] * T(1.0 / (4 * phys::K_F));
@@ -147,22 +268,25 @@ __device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool 
         } else {
             w[k] = s[k] < T(0) ? -m::sqrt(-s[k]) : m::sqrt(s[k]);
         }
+        if constexpr (P::robust) s[k] -= s[k] * pl.kf[k];  // u -= u*episode_kf after w (:235-236)
         effort[k] = opt ? s[k] * T(phys::K_F) : s[k] * T(phys::K_F / phys::F_MAX_ROTOR * 2.0) - T(1);
     }
     u.F = T(phys::K_F) * ((s[0] + s[1]) + (s[2] + s[3]));
     u.Mx = T(phys::D * phys::K_F) * (s[2] - s[0]);
     u.My = T(phys::D * phys::K_F) * (s[1] - s[3]);
     u.Mz = T(phys::K_M) * ((s[1] - s[0]) + (s[3] - s[2]));
-    u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
+    if constexpr (P::robust) u.omr = ((w[1] * pl.ir[1] - w[0] * pl.ir[0]) + (w[3] * pl.ir[3] - w[2] * pl.ir[2]));
+    else u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
     cl[0] = u.F; cl[1] = u.Mx; cl[2] = u.My; cl[3] = u.Mz;
 }
 
 // State layout (quadrotor_env.py:399-400): x vx y vy z vz q0 q1 q2 q3 wx wy wz
 // RHS drone_eq, quadrotor_env.py:274-406, closed form.
 // `acc` returns the inertial acceleration (self.accel side output).
-template <typename T>
-__device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, T cm_xy, T cm_z, T dy[13]) {
+template <typename T, typename P>
+__device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, P& pl, T dy[13]) {
     using m = Mth<T>;
+    const T cm_xy = pl.cm_xy, cm_z = pl.cm_z;
     const T vx = y[1], vy = y[3], vz = y[5];
     const T wx = y[10], wy = y[11], wz = y[12];
     const T inv = m::rsqrt(y[6] * y[6] + y[7] * y[7] + y[8] * y[8] + y[9] * y[9]);
@@ -172,19 +296,27 @@ __device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, T cm_xy, T c
     const T r00 = (aa + bb) - (cc + dd), r01 = T(2) * (bc - ad), r02 = T(2) * (bd + ac);
     const T r10 = T(2) * (bc + ad), r11 = (aa - bb) + (cc - dd), r12 = T(2) * (cd - ab);
     const T r20 = T(2) * (bd - ac), r21 = T(2) * (cd + ab), r22 = (aa - bb) - (cc - dd);
-    // body velocity and aerodynamic drag
-    const T vbx = r00 * vx + r10 * vy + r20 * vz;
-    const T vby = r01 * vx + r11 * vy + r21 * vz;
-    const T vbz = r02 * vx + r12 * vy + r22 * vz;
+    // body velocity and aerodynamic drag (robust: air-relative velocity = v + wind, :317-320)
+    T vax = vx, vay = vy, vaz = vz;
+    if constexpr (P::robust) {
+        T wd[3];
+        next_wind(pl, wd);
+        vax = vx + wd[0]; vay = vy + wd[1]; vaz = vz + wd[2];
+    }
+    const T vbx = r00 * vax + r10 * vay + r20 * vaz;
+    const T vby = r01 * vax + r11 * vay + r21 * vaz;
+    const T vbz = r02 * vax + r12 * vay + r22 * vaz;
     const T fbx = -T(phys::KDX) * (m::abs(vbx) * vbx);
     const T fby = -T(phys::KDY) * (m::abs(vby) * vby);
     const T fbz = u.F - T(phys::KDZ) * (m::abs(vbz) * vbz);
     // inertial acceleration
-    const T ax = (r00 * fbx + r01 * fby + r02 * fbz) * T(1.0 / phys::M);
-    const T ay = (r10 * fbx + r11 * fby + r12 * fbz) * T(1.0 / phys::M);
+    T inv_m = T(1.0 / phys::M), mg = T(phys::M * phys::G);
+    if constexpr (P::robust) { inv_m = pl.inv_m; mg = pl.mg; }
+    const T ax = (r00 * fbx + r01 * fby + r02 * fbz) * inv_m;
+    const T ay = (r10 * fbx + r11 * fby + r12 * fbz) * inv_m;
     // (f_z - M G)/M instead of f_z/M - G: the same number, but the weight cancels before the
     // scaling, so an exact hover (f_z == fl(M G)) has az == 0 exactly in fp32 as well
-    const T az = ((r20 * fbx + r21 * fby + r22 * fbz) - T(phys::M * phys::G)) * T(1.0 / phys::M);
+    const T az = ((r20 * fbx + r21 * fby + r22 * fbz) - mg) * inv_m;
     // moments: action + gyro (sic: x uses -wx, y uses +wy, :347-349) + drag - w x (J w)
     const T mx = u.Mx - wx * u.omr - cm_xy * (m::abs(wx) * wx) - wy * wz * T(phys::JZ - phys::JY);
     const T my = u.My + wy * u.omr - cm_xy * (m::abs(wy) * wy) - wz * wx * T(phys::JX - phys::JZ);
@@ -195,9 +327,13 @@ __device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, T cm_xy, T c
     dy[7] = T(0.5) * (wx * a + wz * c - wy * d);
     dy[8] = T(0.5) * (wy * a - wz * b + wx * d);
     dy[9] = T(0.5) * (wz * a + wy * b - wx * c);
-    dy[10] = mx * T(1.0 / phys::JX);
-    dy[11] = my * T(1.0 / phys::JY);
-    dy[12] = mz * T(1.0 / phys::JZ);
+    if constexpr (P::robust) {
+        dy[10] = mx * pl.ij[0]; dy[11] = my * pl.ij[1]; dy[12] = mz * pl.ij[2];
+    } else {
+        dy[10] = mx * T(1.0 / phys::JX);
+        dy[11] = my * T(1.0 / phys::JY);
+        dy[12] = mz * T(1.0 / phys::JZ);
+    }
 }
 
 // ---- Dormand-Prince 5(4) tableau (scipy rk.py RK45) -----------------------------------
@@ -215,36 +351,36 @@ constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 
 
 // One DP5 step of size h from (y, k1 = f(y)) -> y_new, k7 = f(y_new), and the scaled
 // error norm of scipy's _estimate_error_norm (rk.py:108-109,143-144) if WITH_ERR.
-template <typename T, bool WITH_ERR>
-__device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T>& u, T cm_xy, T cm_z, T h,
+template <typename T, bool WITH_ERR, typename P>
+__device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T>& u, P& pl, T h,
                                       T yn[13], T k7[13], T inc[13]) {
     using m = Mth<T>;
     T k2[13], k3[13], k4[13], k5[13], k6[13], ys[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A21) * k1[i]);
-    rhs(ys, u, cm_xy, cm_z, k2);
+    rhs(ys, u, pl, k2);
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A31) * k1[i] + T(dp::A32) * k2[i]);
-    rhs(ys, u, cm_xy, cm_z, k3);
+    rhs(ys, u, pl, k3);
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A41) * k1[i] + T(dp::A42) * k2[i] + T(dp::A43) * k3[i]);
-    rhs(ys, u, cm_xy, cm_z, k4);
+    rhs(ys, u, pl, k4);
 #pragma unroll
     for (int i = 0; i < 13; ++i)
         ys[i] = y[i] + h * (T(dp::A51) * k1[i] + T(dp::A52) * k2[i] + T(dp::A53) * k3[i] + T(dp::A54) * k4[i]);
-    rhs(ys, u, cm_xy, cm_z, k5);
+    rhs(ys, u, pl, k5);
 #pragma unroll
     for (int i = 0; i < 13; ++i)
         ys[i] = y[i] + h * (T(dp::A61) * k1[i] + T(dp::A62) * k2[i] + T(dp::A63) * k3[i] + T(dp::A64) * k4[i] +
                             T(dp::A65) * k5[i]);
-    rhs(ys, u, cm_xy, cm_z, k6);
+    rhs(ys, u, pl, k6);
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
         const T sum = T(dp::B1) * k1[i] + T(dp::B3) * k3[i] + T(dp::B4) * k4[i] + T(dp::B5) * k5[i] + T(dp::B6) * k6[i];
         inc[i] = h * sum;
         yn[i] = y[i] + h * sum;  // one fma: a single rounding of the new state
     }
-    rhs(yn, u, cm_xy, cm_z, k7);
+    rhs(yn, u, pl, k7);
     T err2 = T(0);
     if (WITH_ERR) {
 #pragma unroll
@@ -265,11 +401,14 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
 // per iteration.  On exit y = state at tb and kq = f(t_end, y_end)
 // (FSAL) whose rows 6..9 are the reference's V_q.  Every lane leaves the loop after at
 // most MAX_ATTEMPTS attempts.
-template <typename T>
-__device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13],
+template <typename T, typename P>
+__device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, T tb, T kq[13], T dy[13],
                                                bool have_f0 = false) {
     using m = Mth<T>;
-    constexpr int MAX_ATTEMPTS = 96;
+    // scipy has no cap; the nominal plant needs 1-4 attempts per env step.  A robust redraw step (a new gust at every
+    // RHS evaluation) legitimately takes hundreds of rejected sub-steps, so its cap is far higher; either way every
+    // lane leaves the loop after a bounded number of attempts.
+    constexpr int MAX_ATTEMPTS = P::robust ? 16384 : 96;
     T k1[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) dy[i] = T(0);
@@ -279,7 +418,7 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
 #pragma unroll
         for (int i = 0; i < 13; ++i) k1[i] = kq[i];
     } else {
-        rhs(y, u, cm_xy, cm_z, k1);
+        rhs(y, u, pl, k1);
     }
     T h_abs;
     {
@@ -298,7 +437,7 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
         T y1[13], f1[13];
 #pragma unroll
         for (int i = 0; i < 13; ++i) y1[i] = y[i] + h0 * k1[i];
-        rhs(y1, u, cm_xy, cm_z, f1);
+        rhs(y1, u, pl, f1);
         T d2 = T(0);
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
@@ -322,7 +461,7 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
         const T h = t_new - t;
         h_abs = h;
         T yn[13], k7[13], inc[13];
-        const T err2 = dp5_step<T, true>(y, k1, u, cm_xy, cm_z, h, yn, k7, inc);
+        const T err2 = dp5_step<T, true>(y, k1, u, pl, h, yn, k7, inc);
         const T err = m::sqrt(err2 * T(1.0 / 13));
         if (err < T(1)) {
             T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow_ctl(err, T(-0.2)));
@@ -345,7 +484,7 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, T cm_xy
 // combinations, error norm) is packed; the step-size control is scalar per env and drives per-env
 // selects.  Each env follows exactly the instruction sequence of the scalar version (an env that has
 // reached t_bound idles with h = 0 while its partner finishes), so results are bit-identical to it.
-__device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, F2 cm_xy, F2 cm_z, float tb, F2 kq[13],
+__device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, Plant<F2, false>& pl, float tb, F2 kq[13],
                                                   F2 dy[13]) {
     using m = Mth<float>;
     using m2 = Mth<F2>;
@@ -353,7 +492,7 @@ __device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, F2
     F2 k1[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) dy[i] = F2{0.f, 0.f};
-    rhs(y, u, cm_xy, cm_z, k1);
+    rhs(y, u, pl, k1);
     float h_abs[2];
     {
         F2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
@@ -376,7 +515,7 @@ __device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, F2
         F2 y1[13], f1[13];
 #pragma unroll
         for (int i = 0; i < 13; ++i) y1[i] = y[i] + h0v * k1[i];
-        rhs(y1, u, cm_xy, cm_z, f1);
+        rhs(y1, u, pl, f1);
         F2 d2 = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
@@ -411,7 +550,7 @@ __device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, F2
         }
         if (!act[0] && !act[1]) break;
         F2 yn[13], k7[13], inc[13];
-        const F2 err2 = dp5_step<F2, true>(y, k1, u, cm_xy, cm_z, F2{h[0], h[1]}, yn, k7, inc);
+        const F2 err2 = dp5_step<F2, true>(y, k1, u, pl, F2{h[0], h[1]}, yn, k7, inc);
         bool accept[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -439,67 +578,67 @@ __device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, F2
     for (int i = 0; i < 13; ++i) kq[i] = k1[i];
 }
 
-template <typename T>
-__device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13],
+template <typename T, typename P>
+__device__ __forceinline__ void integrate_dp5(T y[13], const Act<T>& u, P& pl, T tb, T kq[13], T dy[13],
                                               bool have_f0 = false) {
     T k1[13], yn[13];
     if (have_f0) {
 #pragma unroll
         for (int i = 0; i < 13; ++i) k1[i] = kq[i];
     } else {
-        rhs(y, u, cm_xy, cm_z, k1);
+        rhs(y, u, pl, k1);
     }
-    dp5_step<T, false>(y, k1, u, cm_xy, cm_z, tb, yn, kq, dy);
+    dp5_step<T, false>(y, k1, u, pl, tb, yn, kq, dy);
 #pragma unroll
     for (int i = 0; i < 13; ++i) y[i] = yn[i];
 }
 
-template <typename T>
-__device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, T cm_xy, T cm_z, T h, T kq[13], T dy[13],
+template <typename T, typename P>
+__device__ __forceinline__ void integrate_rk4(T y[13], const Act<T>& u, P& pl, T h, T kq[13], T dy[13],
                                               bool have_f0 = false) {
     T k1[13], k2[13], k3[13], k4[13], ys[13];
     if (have_f0) {
 #pragma unroll
         for (int i = 0; i < 13; ++i) k1[i] = kq[i];
     } else {
-        rhs(y, u, cm_xy, cm_z, k1);
+        rhs(y, u, pl, k1);
     }
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + T(0.5) * h * k1[i];
-    rhs(ys, u, cm_xy, cm_z, k2);
+    rhs(ys, u, pl, k2);
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + T(0.5) * h * k2[i];
-    rhs(ys, u, cm_xy, cm_z, k3);
+    rhs(ys, u, pl, k3);
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * k3[i];
-    rhs(ys, u, cm_xy, cm_z, k4);
+    rhs(ys, u, pl, k4);
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
         const T sum = T(1.0 / 6) * ((k1[i] + k4[i]) + T(2) * (k2[i] + k3[i]));
         dy[i] = h * sum;
         y[i] = y[i] + h * sum;
     }
-    rhs(y, u, cm_xy, cm_z, kq);
+    rhs(y, u, pl, kq);
 }
 
 enum { INT_RK45 = 0, INT_DP5 = 1, INT_RK4 = 2 };
 
-template <typename T, int INTEG>
+template <typename T, int INTEG, typename P>
 // On exit: y = state at tb, kq = f(t_end, y_end), dy = y_end - y_start as the SUM OF THE
 // INTEGRATOR'S INCREMENTS (not the difference of the rounded states): the cancellation-free input
 // of the increment-based Euler rates below.
-__device__ __forceinline__ void integrate(T y[13], const Act<T>& u, T cm_xy, T cm_z, T tb, T kq[13], T dy[13],
+__device__ __forceinline__ void integrate(T y[13], const Act<T>& u, P& pl, T tb, T kq[13], T dy[13],
                                           bool have_f0 = false) {
-    if (INTEG == INT_RK45) integrate_rk45(y, u, cm_xy, cm_z, tb, kq, dy, have_f0);
-    else if (INTEG == INT_DP5) integrate_dp5(y, u, cm_xy, cm_z, tb, kq, dy, have_f0);
-    else integrate_rk4(y, u, cm_xy, cm_z, tb, kq, dy, have_f0);
+    if (INTEG == INT_RK45) integrate_rk45(y, u, pl, tb, kq, dy, have_f0);
+    else if (INTEG == INT_DP5) integrate_dp5(y, u, pl, tb, kq, dy, have_f0);
+    else integrate_rk4(y, u, pl, tb, kq, dy, have_f0);
 }
 
 template <int INTEG>
-__device__ __forceinline__ void integrate2(F2 y[13], const Act<F2>& u, F2 cm_xy, F2 cm_z, float tb, F2 kq[13], F2 dy[13]) {
-    if constexpr (INTEG == INT_RK45) integrate_rk45_x2(y, u, cm_xy, cm_z, tb, kq, dy);
-    else if constexpr (INTEG == INT_DP5) integrate_dp5<F2>(y, u, cm_xy, cm_z, F2{tb, tb}, kq, dy);
-    else integrate_rk4<F2>(y, u, cm_xy, cm_z, F2{tb, tb}, kq, dy);
+__device__ __forceinline__ void integrate2(F2 y[13], const Act<F2>& u, Plant<F2, false>& pl, float tb, F2 kq[13], F2 dy[13]) {
+    if constexpr (INTEG == INT_RK45) integrate_rk45_x2(y, u, pl, tb, kq, dy);
+    else if constexpr (INTEG == INT_DP5) integrate_dp5<F2>(y, u, pl, F2{tb, tb}, kq, dy);
+    else integrate_rk4<F2>(y, u, pl, F2{tb, tb}, kq, dy);
 }
 
 // ---- per-env bookkeeping carried between steps (registers in fused rollouts) -------------
@@ -671,9 +810,9 @@ __device__ __forceinline__ void done_reward(const T y[13], const T act[4], const
 
 // Action pre-processing of step(), quadrotor_env.py:470-479: returns the held
 // actuation `u`, and fills w / effort / clipped_action / self.action.
-template <typename T>
-__device__ __forceinline__ void prepare_action(const T raw[4], const Cfg<T>& cfg, T w[4], T effort[4], T cl[4],
-                                               T act[4], Act<T>& u) {
+template <typename T, typename P>
+__device__ __forceinline__ void prepare_action(const T raw[4], const Cfg<T>& cfg, const P& pl, T w[4], T effort[4],
+                                               T cl[4], T act[4], Act<T>& u) {
     using m = Mth<T>;
     if (cfg.direct) {
 #pragma unroll
@@ -682,11 +821,11 @@ __device__ __forceinline__ void prepare_action(const T raw[4], const Cfg<T>& cfg
             cl[k] = act[k];
             effort[k] = cfg.variant ? (act[k] + T(1)) * T(phys::T2WR * phys::M * phys::G / 8.0) : act[k];
         }
-        mix_direct(act, w, u);
+        mix_direct(act, pl, w, u);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[k] = raw[k];
-        mix_indirect(raw, cfg.clipped != 0, cfg.variant != 0, w, effort, cl, u);
+        mix_indirect(raw, cfg.clipped != 0, cfg.variant != 0, pl, w, effort, cl, u);
     }
 }
 

@@ -15,7 +15,10 @@ namespace qenv {
 // T = arithmetic type, S = storage type of the workspace and of the caller's arrays.  S == T for the fp32 and
 // fp64 handles; the mixed handle (fp64 rows, fp32 arithmetic) uses T = float, S = double: the state rows are
 // advanced by state += (double)increment, so no per-step rounding of the state enters the closed loop.
+using GustSrc = qenv_gust_src;
+
 template <typename T, typename S = T> struct StepArgs {
+    GustSrc gust;
     Cfg<T> cfg;
     S* ws;                 // workspace rows of type S
     int32_t* wsi;          // int rows (I, FLAGS)
@@ -35,6 +38,7 @@ template <typename T, typename S = T> struct StepArgs {
 };
 
 template <typename T, typename S = T> struct RolloutArgs {
+    GustSrc gust;
     Cfg<T> cfg;
     S* ws;
     int32_t* wsi;
@@ -93,12 +97,46 @@ __device__ __forceinline__ void store_book(S* ws, int32_t* wsi, int64_t N, int64
     wsi[IROW_FLAGS * N + e] = bk.flags;
 }
 
+// robust handles: the episode's plant parameters and the gust state of env e (rows ROW_ROB.., ROW_GUST..)
+template <typename T, typename S>
+__device__ __forceinline__ void load_plant(const S* ws, const int32_t* wsi, int64_t N, int64_t e, const GustSrc& g,
+                                           Plant<T, true>& pl) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pl.kf[k] = (T)ld(ws, ROW_ROB + k, N, e);
+        pl.ir[k] = T(phys::I_R) * (T(1) + (T)ld(ws, ROW_ROB + 5 + k, N, e));
+    }
+    const T qm = T(phys::M) * (T(1) + (T)ld(ws, ROW_ROB + 4, N, e));
+    pl.inv_m = T(1) / qm;
+    pl.mg = qm * T(phys::G);
+    const T J[3] = {T(phys::JX), T(phys::JY), T(phys::JZ)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pl.ij[k] = T(1) / (J[k] + J[k] * (T)ld(ws, ROW_ROB + 9 + k, N, e));
+        pl.gust[k] = (T)ld(ws, ROW_GUST + k, N, e);
+        pl.last[k] = (T)ld(ws, ROW_GUST + 3 + k, N, e);
+        pl.wind[k] = T(0);
+    }
+    pl.redraw = false; pl.k = 0; pl.epoch = 0; pl.evals = -1;
+    pl.table = g.table; pl.table_f64 = g.f64; pl.table_E = g.E; pl.table_K = g.K;
+    pl.N = N; pl.e = e;
+    const uint64_t ge = (uint64_t)(g.env_offset + e);
+    pl.key0 = g.key0; pl.key1 = g.key1; pl.ctr0 = (uint32_t)ge; pl.ctr1 = (uint32_t)(ge >> 32);
+    pl.episode = (uint32_t)wsi[IROW_EPISODES * N + e];
+}
+template <typename T, typename S>
+__device__ __forceinline__ void store_gust(S* ws, int32_t* wsi, int64_t N, int64_t e, const Plant<T, true>& pl) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { st(ws, ROW_GUST + k, N, e, pl.gust[k]); st(ws, ROW_GUST + 3 + k, N, e, pl.last[k]); }
+    if (pl.evals >= 0) wsi[IROW_GUST_K * N + e] = pl.evals;  // draws the last redraw step consumed (host RNG replay)
+}
+
 #ifndef QENV_MIN_WAVES
 #define QENV_MIN_WAVES 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
 #endif
 
 // quad.step for N envs: one launch, one lane per env.
-template <typename T, typename S, int INTEG>
+template <typename T, typename S, int INTEG, bool ROBUST>
 __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
     int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
@@ -120,8 +158,15 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, 
     T w[4], effort[4], cl[4], act[4], kq[13], dy[13];
     const T q_old[4] = {y[6], y[7], y[8], y[9]};
     Act<T> u;
-    prepare_action(raw, cfg, w, effort, cl, act, u);
-    integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy);
+    Plant<T, ROBUST> pl;
+    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
+    if constexpr (ROBUST) {
+        load_plant(a.ws, a.wsi, N, e, a.gust, pl);
+        begin_step_wind(pl, a.wsi[IROW_I * N + e] + 1);  // self.i += 1 comes first in step (:467)
+    }
+    prepare_action(raw, cfg, pl, w, effort, cl, act, u);
+    integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy);
+    if constexpr (ROBUST) store_gust(a.ws, a.wsi, N, e, pl);
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         if (MIXED) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; st(a.ws, ROW_STATE + k, N, e, ys[k]); }
@@ -168,7 +213,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, 
 }
 
 // n_steps env steps in one launch, controller on device, state in VGPRs throughout.
-template <typename T, typename S, int INTEG, int CTRL>
+template <typename T, typename S, int INTEG, int CTRL, bool ROBUST>
 __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T, S> a) {
     int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
@@ -199,21 +244,24 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
     }
     T w[4], effort[4], cl[4], act[4], kq[13], raw[4], dy[13];
     Act<T> u;
+    Plant<T, ROBUST> pl;
+    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
+    if constexpr (ROBUST) load_plant(a.ws, a.wsi, N, e, a.gust, pl);  // the host refuses dynamics-only robust rollouts
     if (CTRL == QENV_CTRL_CONST) {  // constant action: mix once for the whole rollout
-        prepare_action(a.const_action, cfg, w, effort, cl, act, u);
+        prepare_action(a.const_action, cfg, pl, w, effort, cl, act, u);
     }
     bool ang_ok = a.ang_ok != 0;
     for (int s = 0; s < a.n_steps; ++s) {
         if (CTRL == QENV_CTRL_LQR) {
             lqr_law(y, bk, a.lqr, raw);
-            prepare_action(raw, cfg, w, effort, cl, act, u);
+            prepare_action(raw, cfg, pl, w, effort, cl, act, u);
         } else if (CTRL == QENV_CTRL_PID) {
             if (s == 0 && a.pid_first) {
                 raw[0] = T(phys::M * phys::G); raw[1] = raw[2] = raw[3] = T(0);
             } else {
                 pid_law(y, bk, a.pid, ps, a.pid_target, cfg.t_step, raw);
             }
-            prepare_action(raw, cfg, w, effort, cl, act, u);
+            prepare_action(raw, cfg, pl, w, effort, cl, act, u);
         } else if (CTRL == QENV_CTRL_PIDPOS) {
             if (a.target_table) {
                 T tg[7];
@@ -223,12 +271,14 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             } else {
                 pidpos_law(y, bk, ps, a.pid_target, cfg.t_step, raw);
             }
-            prepare_action(raw, cfg, w, effort, cl, act, u);
+            prepare_action(raw, cfg, pl, w, effort, cl, act, u);
         }
         const T q_old[4] = {y[6], y[7], y[8], y[9]};
         // constant actuation: f(y_end) of the previous step IS f0 of this one (not in the mixed handle, where the
         // step starts from the re-rounded fp64 state)
-        integrate<T, INTEG>(y, u, cfg.cm_xy, cfg.cm_z, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !MIXED && s > 0);
+        // (nor in a robust plant: the wind changes from step to step)
+        if constexpr (ROBUST) begin_step_wind(pl, bk.i + 1);
+        integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !MIXED && !ROBUST && s > 0);
         if (MIXED) {
 #pragma unroll
             for (int k = 0; k < 13; ++k) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; }
@@ -256,6 +306,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         else st(a.ws, ROW_STATE + k, N, e, y[k]);
     }
     if (dyn_only) return;
+    if constexpr (ROBUST) store_gust(a.ws, a.wsi, N, e, pl);
     store_book(a.ws, a.wsi, N, e, bk, true);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -306,17 +357,20 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
             }
         }
     }
+    Plant<F2, false> pl2;
+    pl2.cm_xy = F2{cfg.cm_xy, cfg.cm_xy}; pl2.cm_z = F2{cfg.cm_z, cfg.cm_z};
+    Plant<float, false> pl1;
+    pl1.cm_xy = cfg.cm_xy; pl1.cm_z = cfg.cm_z;
     float w[2][4], effort[2][4], cl[2][4], act[2][4], raw[4];
     Act<float> us[2];
     Act<F2> u;
     if (CTRL == QENV_CTRL_CONST) {
-        prepare_action(a.const_action, cfg, w[0], effort[0], cl[0], act[0], us[0]);
+        prepare_action(a.const_action, cfg, pl1, w[0], effort[0], cl[0], act[0], us[0]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { w[1][k] = w[0][k]; effort[1][k] = effort[0][k]; cl[1][k] = cl[0][k]; act[1][k] = act[0][k]; }
         u.F = F2{us[0].F, us[0].F}; u.Mx = F2{us[0].Mx, us[0].Mx}; u.My = F2{us[0].My, us[0].My};
         u.Mz = F2{us[0].Mz, us[0].Mz}; u.omr = F2{us[0].omr, us[0].omr};
     }
-    const F2 cm_xy = {cfg.cm_xy, cfg.cm_xy}, cm_z = {cfg.cm_z, cfg.cm_z};
     bool ang_ok = a.ang_ok != 0;
     F2 kq[13], dy[13];
     for (int s = 0; s < a.n_steps; ++s) {
@@ -331,13 +385,13 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
                     if (s == 0 && a.pid_first) { raw[0] = float(phys::M * phys::G); raw[1] = raw[2] = raw[3] = 0.f; }
                     else pid_law(yc, bk[c], a.pid, ps[c], a.pid_target, cfg.t_step, raw);
                 } else pidpos_law(yc, bk[c], ps[c], a.target_table ? a.target_table + s * 7 : a.pid_target, cfg.t_step, raw);
-                prepare_action(raw, cfg, w[c], effort[c], cl[c], act[c], us[c]);
+                prepare_action(raw, cfg, pl1, w[c], effort[c], cl[c], act[c], us[c]);
             }
             u.F = F2{us[0].F, us[1].F}; u.Mx = F2{us[0].Mx, us[1].Mx}; u.My = F2{us[0].My, us[1].My};
             u.Mz = F2{us[0].Mz, us[1].Mz}; u.omr = F2{us[0].omr, us[1].omr};
         }
         const F2 q_old[4] = {y[6], y[7], y[8], y[9]};
-        integrate2<INTEG>(y, u, cm_xy, cm_z, cfg.t_step, kq, dy);
+        integrate2<INTEG>(y, u, pl2, cfg.t_step, kq, dy);
         if (!dyn_only) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -519,6 +573,40 @@ __global__ __launch_bounds__(256) void k_pid_reset(T* ws, int64_t N, const uint8
     for (int k = 0; k < 15; ++k) st(ws, ROW_PID + k, N, e, T(0));
 }
 
+// robust_control.reset (quadrotor_env.py:97-101): the 12 episode draws, injected or Philox
+template <typename S>
+__global__ __launch_bounds__(256) void k_robust_params(S* ws, const int32_t* wsi, int64_t N, const S* params, uint64_t seed,
+                                                       int64_t env_offset, const uint8_t* mask) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    if (mask && mask[e] == 0) return;
+    if (params) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st(ws, ROW_ROB + k, N, e, params[(int64_t)k * N + e]);
+        return;
+    }
+    const uint64_t ge = (uint64_t)(env_offset + e);
+    float v[12];
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        // a masked call precedes the masked qenv_reset that ends the episode and bumps the counter: key the NEXT episode
+        uint32_t c[4] = {(uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(wsi[IROW_EPISODES * N + e] + (mask ? 1 : 0)), (uint32_t)blk};
+        philox_core(c, (uint32_t)seed ^ 0x0B0Bu, (uint32_t)(seed >> 32) ^ 0xE915u);
+        if (blk == 0) {         // episode_kf = random(4) * D_KF
+            for (int k = 0; k < 4; ++k) v[k] = 0.1f * philox_u01(c[k]);
+        } else if (blk == 1) {  // episode_ir = random(4) * D_IR
+            for (int k = 0; k < 4; ++k) v[5 + k] = 0.1f * philox_u01(c[k]);
+        } else {                // episode_m ~ N(0, D_M), episode_J ~ N(0, D_J)
+            float z0, z1, z2, z3;
+            philox_normal2(c[0], c[1], z0, z1);
+            philox_normal2(c[2], c[3], z2, z3);
+            v[4] = 0.3f * z0; v[9] = 0.1f * z1; v[10] = 0.1f * z2; v[11] = 0.1f * z3;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st(ws, ROW_ROB + k, N, e, v[k]);
+}
+
 // ---- host-side helpers -------------------------------------------------------------------------
 template <typename T> static Cfg<T> make_cfg(const qenv_s* q) {
     Cfg<T> c;
@@ -603,15 +691,36 @@ template <typename T, typename S> static int do_step(qenv_s* q, const void* acti
     if (flags == QENV_STEP_DYNAMICS_ONLY) q->ang_ok = 0;
     else if (!mask) q->ang_ok = 1;
     const dim3 g = grid_for(q->N), b(256);
+    a.gust = q->gust;
+    if (q->robust) {
+        if (flags == QENV_STEP_DYNAMICS_ONLY)
+            return fail(QENV_ERR_ARG, "robust_control: the gusts follow the step counter, dynamics-only steps are not available");
+        switch (q->cfg.integrator) {
+            case QENV_RK45: hipLaunchKernelGGL((k_step<T, S, INT_RK45, true>), g, b, 0, q->stream, a); break;
+            case QENV_DP5: hipLaunchKernelGGL((k_step<T, S, INT_DP5, true>), g, b, 0, q->stream, a); break;
+            default: hipLaunchKernelGGL((k_step<T, S, INT_RK4, true>), g, b, 0, q->stream, a); break;
+        }
+        return check_launch("k_step(robust)");
+    }
     switch (q->cfg.integrator) {
-        case QENV_RK45: hipLaunchKernelGGL((k_step<T, S, INT_RK45>), g, b, 0, q->stream, a); break;
-        case QENV_DP5: hipLaunchKernelGGL((k_step<T, S, INT_DP5>), g, b, 0, q->stream, a); break;
-        default: hipLaunchKernelGGL((k_step<T, S, INT_RK4>), g, b, 0, q->stream, a); break;
+        case QENV_RK45: hipLaunchKernelGGL((k_step<T, S, INT_RK45, false>), g, b, 0, q->stream, a); break;
+        case QENV_DP5: hipLaunchKernelGGL((k_step<T, S, INT_DP5, false>), g, b, 0, q->stream, a); break;
+        default: hipLaunchKernelGGL((k_step<T, S, INT_RK4, false>), g, b, 0, q->stream, a); break;
     }
     return check_launch("k_step");
 }
 
 template <typename T, typename S, int INTEG> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T, S>& a) {
+    const dim3 g = grid_for(q->N), b(256);
+    if (q->robust) {
+        switch (controller) {
+            case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST, true>), g, b, 0, q->stream, a); break;
+            case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_LQR, true>), g, b, 0, q->stream, a); break;
+            case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PIDPOS, true>), g, b, 0, q->stream, a); break;
+            default: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PID, true>), g, b, 0, q->stream, a); break;
+        }
+        return;
+    }
     if constexpr (sizeof(T) == 4 && sizeof(S) == 4) {
         if (q->packed && (q->N % 2) == 0) {  // two envs per lane, packed fp32 integrator
             const dim3 g2 = grid_for(q->N / 2), b2(256);
@@ -624,12 +733,11 @@ template <typename T, typename S, int INTEG> static void launch_rollout(qenv_s* 
             return;
         }
     }
-    const dim3 g = grid_for(q->N), b(256);
     switch (controller) {
-        case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST>), g, b, 0, q->stream, a); break;
-        case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_LQR>), g, b, 0, q->stream, a); break;
-        case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PIDPOS>), g, b, 0, q->stream, a); break;
-        default: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PID>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST, false>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_LQR, false>), g, b, 0, q->stream, a); break;
+        case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PIDPOS, false>), g, b, 0, q->stream, a); break;
+        default: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PID, false>), g, b, 0, q->stream, a); break;
     }
 }
 
@@ -643,6 +751,9 @@ template <typename T, typename S> static int do_rollout(qenv_s* q, int controlle
         if (q->warmup_push) { a.win = q->window; a.win_head = q->win_head; }
     }
     a.cfg = make_cfg<T>(q);
+    a.gust = q->gust;
+    if (q->robust && flags == QENV_STEP_DYNAMICS_ONLY)
+        return fail(QENV_ERR_ARG, "robust_control: the gusts follow the step counter, dynamics-only rollouts are not available");
     a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
     a.ang_ok = q->ang_ok;
     if (!a.idx) q->ang_ok = flags == QENV_STEP_DYNAMICS_ONLY ? 0 : 1;  // a masked warm-up leaves the global flag alone
@@ -742,6 +853,8 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->compact_valid = 0;
     q->warmup_push = 0;
     q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : 0;  // developer A/B switch
+    q->robust = 0;
+    q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
     if (e != hipSuccess) { delete q; return fail_hip(e, "hipMemsetAsync(workspace)"); }
     *out = q;
@@ -769,8 +882,14 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
     if (field_id >= 0 && field_id <= QENV_FIELD_PID) {
         *dev_ptr = (char*)q->ws + (size_t)row_of[field_id] * q->N * esz;
         if (rows) *rows = rows_of[field_id];
+    } else if (field_id == QENV_FIELD_ROBUST_PARAMS || field_id == QENV_FIELD_GUST) {
+        *dev_ptr = (char*)q->ws + (size_t)(field_id == QENV_FIELD_GUST ? ROW_GUST : ROW_ROB) * q->N * esz;
+        if (rows) *rows = field_id == QENV_FIELD_GUST ? 6 : 12;
     } else if (field_id == QENV_FIELD_LAST_RETURN) {
         *dev_ptr = (char*)q->ws + (size_t)ROW_LAST_RETURN * q->N * esz;
+        if (rows) *rows = 1;
+    } else if (field_id == QENV_FIELD_GUST_EVALS) {
+        *dev_ptr = q->wsi + IROW_GUST_K * q->N;
         if (rows) *rows = 1;
     } else if (field_id == QENV_FIELD_I || field_id == QENV_FIELD_FLAGS || field_id == QENV_FIELD_EPISODES) {
         *dev_ptr = q->wsi + (field_id == QENV_FIELD_I ? IROW_I : field_id == QENV_FIELD_FLAGS ? IROW_FLAGS : IROW_EPISODES) * q->N;
@@ -781,6 +900,37 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
     } else {
         return fail(QENV_ERR_ARG, "qenv_field: unknown field id");
     }
+    return QENV_OK;
+}
+
+int qenv_set_robust(qenv_t q, int enabled) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_set_robust: null handle");
+    if (enabled && q->cfg.variant != QENV_MAIN)
+        return fail(QENV_ERR_ARG, "qenv_set_robust: only the main variant has robust_control (quadrotor_env.py:84-109)");
+    q->robust = enabled ? 1 : 0;
+    return QENV_OK;
+}
+
+int qenv_robust_params(qenv_t q, const void* params, uint64_t seed, int64_t env_offset, const uint8_t* mask) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_robust_params: null handle");
+    const dim3 g = grid_for(q->N), b(256);
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_robust_params<double>), g, b, 0, q->stream, (double*)q->ws, q->wsi, q->N, (const double*)params,
+                           seed, env_offset, mask);
+    else
+        hipLaunchKernelGGL((k_robust_params<float>), g, b, 0, q->stream, (float*)q->ws, q->wsi, q->N, (const float*)params,
+                           seed, env_offset, mask);
+    return check_launch("k_robust_params");
+}
+
+int qenv_robust_gusts(qenv_t q, const void* table, int32_t E, int32_t K, uint64_t seed, int64_t env_offset) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_robust_gusts: null handle");
+    if (table && (E < 1 || K < 1)) return fail(QENV_ERR_ARG, "qenv_robust_gusts: a table needs E >= 1 and K >= 1");
+    q->gust.table = table;
+    q->gust.f64 = q->cfg.dtype == QENV_F64;
+    q->gust.E = table ? E : 1; q->gust.K = table ? K : 1;
+    q->gust.key0 = (uint32_t)seed ^ 0x0B57u; q->gust.key1 = (uint32_t)(seed >> 32) ^ 0x6057u;
+    q->gust.env_offset = env_offset;
     return QENV_OK;
 }
 

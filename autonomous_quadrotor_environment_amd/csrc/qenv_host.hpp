@@ -30,9 +30,11 @@ enum {
     ROW_EP_RETURN = 44,     // 1
     ROW_PID = 45,           // 15
     ROW_LAST_RETURN = 60,   // 1
-    ROWS_T = 61
+    ROW_ROB = 61,           // 12: episode_kf(4), episode_m, episode_ir(4), episode_J diag(3) (robust_control.reset)
+    ROW_GUST = 73,          // 6: gust(3), last_gust(3)
+    ROWS_T = 79
 };
-enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_COUNT = 4, IROWS = 5 };  // IDX/COUNT: compacted reset list
+enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_COUNT = 4, IROW_GUST_K = 5, IROWS = 6 };  // IDX/COUNT: compacted reset list
 
 struct WsLayout {
     size_t int_off, win_off, total;
@@ -52,8 +54,18 @@ static inline WsLayout ws_layout(const qenv_config& c) {
 
 }  // namespace qenv
 
+// where a robust handle's gust draws come from (see Plant<T, true> in qenv_core.hpp)
+struct qenv_gust_src {
+    const void* table;        // null = Philox; else [E][K][3][N] in the handle's storage type
+    int32_t f64, E, K;
+    uint32_t key0, key1;
+    int64_t env_offset;       // global index of local env 0 (shard-invariant streams)
+};
+
 struct qenv_s {
     qenv_config cfg;
+    int32_t robust;           // env.robust_control
+    qenv_gust_src gust;
     int64_t N;
     void* ws;
     size_t ws_bytes;

@@ -303,6 +303,9 @@ class PolicyRollout:
         env = self.env
         if init_states is None:
             init_states = env.sample_init_states(self.seed, 0, self.env_offset, out=self.init)
+        if env.robust_control:  # domain randomisation: a new plant per episode, Philox gusts (quadrotor_env.py:84-109)
+            env.robust_gusts(None, self.seed, self.env_offset)
+            env.robust_params(None, self.seed, self.env_offset)
         env.reset(init_states, return_history=False, push_window=True)
         self.t = 0
 
@@ -322,6 +325,8 @@ class PolicyRollout:
                  push_window=True)
         if self.auto_reset:  # worker loop: `while` episodes until the batch is full (ppo.py:232-262)
             env.sample_init_states(self.seed, self.global_step + 1, self.env_offset, mask=self.done, out=self.init)
+            if env.robust_control:
+                env.robust_params(None, self.seed, self.env_offset, mask=self.done)
             env.reset(self.init, mask=self.done, return_history=False, push_window=True)
         self.t += 1
         self.global_step += 1

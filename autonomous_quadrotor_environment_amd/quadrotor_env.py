@@ -42,24 +42,34 @@ def quat_euler(q):
                      np.arctan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] ** 2 + q[3] ** 2))])
 
 
-def random_init_states(rng, n_envs, variant="main"):
+def draw_robust_params(rng):
+    """robust_control.reset (quadrotor_env.py:97-101) in the reference's draw order:
+    episode_kf(4) ~ U(0,.1), episode_m ~ N(0,.3), episode_ir(4) ~ U(0,.1), diag episode_J(3) ~ N(0,.1)."""
+    kf = rng.random_sample(4) * 0.1
+    m = rng.normal(0, 0.3, 1)
+    ir = rng.random_sample(4) * 0.1
+    jj = rng.normal(np.zeros(3), 0.1 * np.ones(3), [3])
+    return np.concatenate([kf, m, ir, jj])
+
+
+def random_init_states(rng, n_envs, variant="main", return_params=False):
     """Initial 13-states in the reference's RNG draw order (reset(): quadrotor_env.py:426,
     440-445; robust_control.reset consumes 12 draws first, :97-101), env after env on one
     legacy MT19937 stream.  `rng`: np.random.RandomState, the np.random module, or a seed.
-    Returns float64 [n_envs, 13]."""
+    Returns float64 [n_envs, 13] (and the [n_envs, 12] robust episode draws if asked)."""
     if isinstance(rng, (int, np.integer)):
         rng = np.random.RandomState(int(rng))
     out = np.zeros((n_envs, 13))
+    params = np.zeros((n_envs, 12))
     for k in range(n_envs):
         if variant == "main":
-            rng.random_sample(4); rng.normal(0, 0.3, 1); rng.random_sample(4)
-            rng.normal(np.zeros(3), 0.1 * np.ones(3), [3])
+            params[k] = draw_robust_params(rng)
         ang = rng.rand(3) - 0.5
         out[k, 0:5:2] = np.clip(rng.normal([0, 0, 0], 2), -BB_POS / 2, BB_POS / 2)
         out[k, 1:6:2] = np.clip(rng.normal([0, 0, 0], 2), -BB_VEL / 2, BB_VEL / 2)
         out[k, 6:10] = euler_quat(ang)
         out[k, 10:13] = np.clip(rng.normal([0, 0, 0], 2), -BB_VEL * 1.5, BB_POS * 1.5)
-    return out
+    return (out, params) if return_params else out
 
 
 def _draw_block(g, n):
@@ -208,6 +218,9 @@ class BatchedQuad:
     window = property(lambda s: s._field(L.FIELD_WINDOW, torch.float32))
     last_return = property(lambda s: s._field(L.FIELD_LAST_RETURN)[0])
     episodes = property(lambda s: s._field(L.FIELD_EPISODES, torch.int32)[0])
+    robust_parameters = property(lambda s: s._field(L.FIELD_ROBUST_PARAMS))  # [12, N] kf4, m, ir4, J3
+    gust = property(lambda s: s._field(L.FIELD_GUST))                        # [6, N] gust(3), last_gust(3)
+    gust_evals = property(lambda s: s._field(L.FIELD_GUST_EVALS, torch.int32)[0])
     done = property(lambda s: (s.flags & L.FLAG_DONE) != 0)
     solved = property(lambda s: ((s.flags & L.FLAG_SOLVED) != 0).to(torch.int32))
 
@@ -340,6 +353,39 @@ class BatchedQuad:
                                          int(env_offset), L.ptr(out), L.ptr(logprob)), "qenv_sample_action")
         return out
 
+    # ---- robust_control (quadrotor_env.py:84-109): episode plant perturbation + gusts -----------------
+    @property
+    def robust_control(self):
+        return getattr(self, "_robust", False)
+
+    @robust_control.setter
+    def robust_control(self, on):
+        L.check(L.lib.qenv_set_robust(self._h, int(bool(on))), "qenv_set_robust")
+        self._robust = bool(on)
+
+    def robust_params(self, params=None, seed=0, env_offset=0, mask=None):
+        """robust_control.reset for the masked envs: params [12, N] (reference draw order: kf4, m, ir4, J3) or
+        None = the same distributions from Philox keyed by (seed; global env, episode)."""
+        p = self._as_rows(params, 12, "params")
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._bind()
+        L.check(L.lib.qenv_robust_params(self._h, L.ptr(p), int(seed), int(env_offset), L.ptr(m)), "qenv_robust_params")
+
+    def robust_gusts(self, table=None, seed=0, env_offset=0):
+        """Source of the gust draws: table [E, K, 3, N] (recorded draws, parity runs; kept alive here) or None =
+        Philox keyed by (seed; global env, episode, epoch, draw)."""
+        if table is not None:
+            if isinstance(table, np.ndarray):
+                table = torch.from_numpy(np.ascontiguousarray(table))
+            table = table.to(device=self.device, dtype=self.dtype).contiguous()
+            if table.dim() != 4 or table.shape[2] != 3 or table.shape[3] != self.n_envs:
+                raise ValueError(f"gust table: expected [E, K, 3, {self.n_envs}], got {tuple(table.shape)}")
+            E, K = int(table.shape[0]), int(table.shape[1])
+        else:
+            E = K = 1
+        self._gust_table = table
+        L.check(L.lib.qenv_robust_gusts(self._h, L.ptr(table), E, K, int(seed), int(env_offset)), "qenv_robust_gusts")
+
     def sample_init_states(self, seed, episode=0, env_offset=0, mask=None, out=None):
         """Device-side random branch of quad.reset (same distributions, Philox streams)."""
         out = torch.zeros(13, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
@@ -348,6 +394,17 @@ class BatchedQuad:
         L.check(L.lib.qenv_sample_init_states(self._h, int(seed), int(episode), int(env_offset), L.ptr(m), L.ptr(out)),
                 "qenv_sample_init_states")
         return out
+
+
+class _RobustParameters:
+    """The attribute bag of the reference's robust_control object (quadrotor_env.py:84-101), filled by quad.reset."""
+    D_KF, D_KM, D_M, D_IR = 0.1, 0.1, 0.3, 0.1
+    gust_std, gust_period = [[5], [5], [2]], 500
+
+    def __init__(self):
+        self.D_J = np.ones(3) * 0.1
+        self.episode_kf, self.episode_m, self.episode_ir = np.zeros(4), np.zeros(1), np.zeros(4)
+        self.episode_J = np.zeros((3, 3))
 
 
 class quad:
@@ -372,7 +429,7 @@ class quad:
         self.zero_control = b.zero_control
         self.direct_control_flag = direct_control
         self.J_mat = J
-        self.robust_control = False
+        self.robust_parameters = _RobustParameters()
         self.i = 0
         self.done = True
         self.solved = 0
@@ -388,6 +445,33 @@ class quad:
 
     def seed(self, seed):
         np.random.seed(seed)  # the reference seeds the GLOBAL numpy stream (:193)
+
+    # the reference hard-codes robust_control = False (:183); users flip the attribute
+    @property
+    def robust_control(self):
+        return self._b.robust_control
+
+    @robust_control.setter
+    def robust_control(self, on):
+        self._b.robust_control = on
+
+    _GUST_K = 6002  # gust triples staged per redraw step (1000 attempted sub-steps; the reference's runs use 8..300)
+
+    def _stage_gusts(self):
+        """A step with i % 500 == 1 draws one gust triple per RHS evaluation from the GLOBAL numpy stream, a data
+        dependent number of times.  Stage the next _GUST_K triples from a snapshot of the stream as the device's
+        table; after the step the stream is advanced by exactly the draws the integrator consumed."""
+        self._rng_snapshot = np.random.get_state()
+        z = np.random.normal(0.0, 1.0, self._GUST_K * 3).reshape(self._GUST_K, 3) * np.array([5.0, 5.0, 2.0])
+        self._b.robust_gusts(torch.from_numpy(z.reshape(1, self._GUST_K, 3, 1).copy()))
+
+    def _commit_gusts(self, n_steps_with_redraw):
+        used = int(self._b.gust_evals[0].item())
+        if used >= self._GUST_K:
+            raise RuntimeError(f"robust_control: the redraw step consumed {used} gust draws, more than the {self._GUST_K} staged")
+        np.random.set_state(self._rng_snapshot)
+        if used:
+            np.random.normal(0.0, 1.0, used * 3)
 
     def _pull(self):
         """One D2H copy of the whole (tiny) workspace, then refresh the numpy attributes."""
@@ -442,12 +526,29 @@ class quad:
 
     def reset(self, det_state=None):
         b = self._b
+        params = None
+        if b.variant == "main":  # robust_parameters.reset() draws first, whatever det_state is (:426)
+            params = draw_robust_params(np.random)
+            rp = self.robust_parameters
+            rp.episode_kf, rp.episode_m, rp.episode_ir = params[0:4], params[4:5], params[5:9]
+            rp.episode_J = np.eye(3) * params[9:12]
         if det_state is None:
-            x0 = random_init_states(np.random, 1, b.variant)  # global stream, reference draw order
+            ang = np.random.rand(3) - 0.5  # reference draw order (:440-445)
+            x0 = np.zeros((1, 13))
+            x0[0, 0:5:2] = np.clip(np.random.normal([0, 0, 0], 2), -BB_POS / 2, BB_POS / 2)
+            x0[0, 1:6:2] = np.clip(np.random.normal([0, 0, 0], 2), -BB_VEL / 2, BB_VEL / 2)
+            x0[0, 6:10] = euler_quat(ang)
+            x0[0, 10:13] = np.clip(np.random.normal([0, 0, 0], 2), -BB_VEL * 1.5, BB_POS * 1.5)
         else:
             x0 = np.asarray(det_state, dtype=np.float64).reshape(1, 13)
         self.action_hist = [self.zero_control for _ in range(self.T)]
+        robust = self.robust_control
+        if robust:
+            b.robust_params(torch.from_numpy(params.reshape(12, 1).copy()))
+            self._stage_gusts()  # the first warm-up step has i == 1: a redraw step
         states, actions = b.reset(torch.from_numpy(x0.T.copy()))
+        if robust:
+            self._commit_gusts(1)
         self.action = self.zero_control
         self._pull()
         return (states[:, :, 0].double().cpu().numpy(), actions[:, :, 0].double().cpu().numpy())
@@ -456,7 +557,12 @@ class quad:
         b = self._b
         a = np.asarray(action, dtype=np.float64).reshape(4)
         self.action = np.clip(a, -1, 1) if self.direct_control_flag else a
+        redraw = self.robust_control and (self.i + 1) % 500 == 1
+        if redraw:
+            self._stage_gusts()
         b.step(torch.from_numpy(a.reshape(4, 1)))
+        if redraw:
+            self._commit_gusts(1)
         self._pull()
         self.action_hist.append(self.clipped_action)
         return self.quat_state, self.reward, self.done

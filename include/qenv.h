@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define QENV_ABI_VERSION 1
+#define QENV_ABI_VERSION 2
 
 typedef struct qenv_s *qenv_t;
 
@@ -93,7 +93,10 @@ typedef enum {
                                                s = slice written at push s mod T)   */
     QENV_FIELD_LAST_RETURN = 17,   /* [1][N]   return of the last finished episode    */
     QENV_FIELD_EPISODES = 18,      /* [1][N]   int32 episodes finished (masked resets)  */
-    QENV_FIELD_COUNT_ = 19
+    QENV_FIELD_ROBUST_PARAMS = 19, /* [12][N]  episode_kf(4), episode_m, episode_ir(4), diag episode_J(3) */
+    QENV_FIELD_GUST = 20,          /* [6][N]   robust_control.gust(3), last_gust(3)   */
+    QENV_FIELD_GUST_EVALS = 21,    /* [1][N]   int32 RHS evaluations (= gust draws) of the env's last redraw step */
+    QENV_FIELD_COUNT_ = 22
 } qenv_field_id;
 
 #define QENV_FLAG_DONE 1
@@ -257,6 +260,30 @@ int qenv_sample_action(qenv_t q, const void *mean, double std, const void *noise
  * host replay for seed parity).  out [13][N]; only envs with mask != 0 are written (nullable). */
 int qenv_sample_init_states(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset,
                             const uint8_t *mask, void *out_states);
+
+/* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------
+ * The reference hard-codes `self.robust_control = False` (:183) and a user flips the attribute; this is that
+ * switch.  Main variant only (quadrotor_env_opt.py has no such mode).  With it on, every step / rollout of the
+ * handle runs the perturbed plant: thrust loss u -= u*episode_kf after w (:235,:265), wind added to the
+ * air-relative velocity (:317-320), per-rotor inertia (:341-343), mass (:360-361), body inertia (:381-382).
+ * Dynamics-only steps are refused (the gusts follow the step counter i). */
+int qenv_set_robust(qenv_t q, int enabled);
+
+/* robust_control.reset (:97-101): the 12 episode draws of the envs with mask != 0 (mask nullable).
+ *   params non-null: [12][N] in the handle's dtype, rows = episode_kf(4) ~ U(0,0.1), episode_m ~ N(0,0.3),
+ *     episode_ir(4) ~ U(0,0.1), diag episode_J(3) ~ N(0,0.1) -- the reference's draw order, so its seeded
+ *     stream can be replayed on the host;
+ *   params null: the same distributions from Philox4x32-10 keyed by (seed; env_offset + e, episode), episode =
+ *     episodes[e], or episodes[e] + 1 in a masked call (made BEFORE the masked qenv_reset that bumps the counter). */
+int qenv_robust_params(qenv_t q, const void *params, uint64_t seed, int64_t env_offset, const uint8_t *mask);
+
+/* Source of the gust draws of robust_control.wind (:102-108).  In the steps with i % 500 == 1 the reference
+ * draws a new gust ~ N(0,[5,5,2]) at EVERY RHS evaluation (8 ... several hundred per step, data dependent)
+ * and each evaluation sees the previous draw; in between the wind is linspace(last_gust, gust, 500)[i%500-1].
+ *   table non-null: [E][K][3][N] in the handle's dtype, borrowed until replaced: draw k of redraw epoch
+ *     (i-1)/500 of the current episode (k, epoch clamped to K-1, E-1) -- parity runs replay recorded draws;
+ *   table null: Philox4x32-10 keyed by (seed; env_offset + e, episodes[e], epoch, k) + Box-Muller. */
+int qenv_robust_gusts(qenv_t q, const void *table, int32_t E, int32_t K, uint64_t seed, int64_t env_offset);
 
 /* Replaces PPO.get_advantages (environment/controller/ppo.py:125-141, ddof=0;
  * visual_landing/ppo_trainer.py:133-148, ddof=1) on a time-major rollout:

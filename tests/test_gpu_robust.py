@@ -1,0 +1,184 @@
+"""GPU: robust_control (environment/quadrotor_env.py:84-109) -- the perturbed plant and the gust
+process through the C-ABI against the reference's own trajectories (g18) and against the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import STATE_SCALE, golden, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aq():
+    import autonomous_quadrotor_environment_amd as aq
+    assert torch.cuda.is_available()
+    return aq
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+@pytest.mark.parametrize("tag,episodes", [("direct", 1), ("indirect", 1), ("direct_resets", 3)])
+def test_quad_dropin_robust_replays_the_reference_stream(aq, tag, episodes):
+    """`env.robust_control = True` on the N=1 drop-in, seeded like the reference run: the 12 episode draws and the
+    data-dependent number of gust triples (8 ... 248 per redraw step) come off the GLOBAL numpy stream exactly as in
+    the reference, so whole trajectories -- including the second redraw at i = 501 -- match in fp64."""
+    g = golden("g18_robust")
+    direct, T, steps, seed = (int(v) for v in g[f"{tag}_meta"])
+    env = aq.quad(0.01, 2000, training=True, euler=0, direct_control=direct, T=T)
+    env.robust_control = True
+    env.seed(seed)
+    worst = 0.0
+    for ep in range(episodes):
+        pre = f"{tag}_ep{ep}_"
+        st, _ = env.reset(g[pre + "x0"].copy())
+        p = env.robust_parameters
+        got = np.concatenate([p.episode_kf, p.episode_m, p.episode_ir, np.diag(p.episode_J)])
+        assert np.array_equal(got, g[pre + "params"])
+        worst = max(worst, scaled_err(st[:, :13], g[pre + "reset_states"][:, :13], STATE_SCALE))
+        for k in range(steps):
+            qs, r, d = env.step(g[pre + "actions"][k])
+            worst = max(worst, scaled_err(env.state, g[pre + "state"][k], STATE_SCALE))
+            assert abs(r - g[pre + "reward"][k]) < 1e-7 * max(1.0, abs(g[pre + "reward"][k])), (ep, k)
+            assert bool(d) == bool(g[pre + "done"][k])
+            assert np.abs(env.step_effort - g[pre + "step_effort"][k]).max() < 1e-10
+            assert np.abs(env.clipped_action - g[pre + "clipped_action"][k]).max() < 1e-9
+    assert worst < 1e-9, worst
+
+
+def _oracle_batch(oracle, N, direct, T, params, table, x0, actions):
+    """N oracle envs, each with its own params [12] and gust draws table[:, :, e] -> states [S, N, 13], gust rows."""
+    S = actions.shape[0]
+    out = np.zeros((S, N, 13))
+    rew = np.zeros((S, N))
+    gust = np.zeros((S, N, 6))
+    iters = np.zeros((S, N), dtype=int)
+    after_reset = np.zeros((N, 13))
+    for e in range(N):
+        env = oracle.OracleQuad(0.01, 2000, training=True, euler=0, direct_control=direct, T=T)
+        env.set_robust(True, params=params[:, e], gust_draws=table[0, :, :, e])
+        env.reset(x0[:, e])
+        after_reset[e] = env.state
+        for k in range(S):
+            env.step(actions[k, :, e])
+            out[k, e] = env.state
+            rew[k, e] = env.reward
+            gust[k, e] = np.concatenate([env.gust, env.last_gust])
+            iters[k, e] = env.i
+    return after_reset, out, rew, gust, iters
+
+
+def _inputs(N, direct, S, seed):
+    rng = np.random.RandomState(seed)
+    params = np.concatenate([rng.random_sample((4, N)) * 0.1, rng.normal(0, 0.3, (1, N)), rng.random_sample((4, N)) * 0.1,
+                             rng.normal(0, 0.1, (3, N))])
+    table = rng.normal(0, 1, (1, 600, 3, N)) * np.array([5.0, 5.0, 2.0])[None, None, :, None]
+    from autonomous_quadrotor_environment_amd import random_init_states
+    x0 = random_init_states(rng, N).T.copy()
+    x0[1:6:2] *= 0.3; x0[10:13] *= 0.2
+    if direct:
+        actions = np.clip(rng.normal(0, 0.3, (S, 4, N)), -1.2, 1.2)
+    else:
+        actions = np.array([1.03 * 9.82, 0, 0, 0])[None, :, None] + rng.normal(0, 1, (S, 4, N)) * np.array([1.0, 0.05, 0.05, 0.02])[None, :, None]
+    return params, table, x0, actions
+
+
+@pytest.mark.parametrize("direct,T", [(1, 1), (0, 5)])
+def test_batched_robust_fp64_vs_oracle(aq, oracle, direct, T):
+    """Every env its own perturbed plant and its own recorded gust table; the redraw step of the reset (hundreds of
+    rejected sub-steps, one draw per RHS evaluation) and the linspace wind afterwards, closed loop in fp64."""
+    N, S = 48, 25
+    params, table, x0, actions = _inputs(N, direct, S, 181)
+    ar, ref, rew, gust, _ = _oracle_batch(oracle, N, direct, T, params, table, x0, actions)
+    env = aq.BatchedQuad(N, 0.01, 2000, training=True, direct_control=direct, T=T, dtype=torch.float64)
+    env.robust_control = True
+    env.robust_params(params)
+    env.robust_gusts(table)
+    env.reset(x0)
+    assert scaled_err(_np(env.state).T, ar, STATE_SCALE) < 1e-9
+    for k in range(S):
+        _, r, _ = env.step(actions[k])
+        assert scaled_err(_np(env.state).T, ref[k], STATE_SCALE) < 1e-9, k
+        assert np.abs(_np(r) - rew[k]).max() < 1e-7 * max(1.0, np.abs(rew[k]).max())
+    assert np.abs(_np(env.gust).T - gust[-1]).max() < 1e-12
+    assert int(env.gust_evals.min()) >= 8  # every env drew at least [f0, f1, 6 stages] in its redraw step
+
+
+@pytest.mark.parametrize("direct,T", [(1, 1), (0, 1)])
+def test_batched_robust_fp32_one_step_vs_oracle(aq, oracle, direct, T):
+    """fp32: teacher-forced single steps in the interpolated-wind regime (the redraw step is chaotic by construction:
+    which sub-steps are accepted decides how many draws are consumed).  Tolerance: the north-star's 1e-5 on the
+    scale-floored metric."""
+    N, S = 64, 12
+    params, table, x0, actions = _inputs(N, direct, S, 182)
+    ar, ref, rew, gust, iters = _oracle_batch(oracle, N, direct, T, params, table, x0, actions)
+    env = aq.BatchedQuad(N, 0.01, 2000, training=True, direct_control=direct, T=T, dtype=torch.float32)
+    env.robust_control = True
+    env.robust_params(params)
+    env.robust_gusts(table)
+    env.reset(x0)  # sizes the bookkeeping; state and gust rows are overwritten below
+    prev_state, prev_gust, prev_i = ar, None, None
+    worst = 0.0
+    for k in range(1, S):
+        env.state.copy_(torch.from_numpy(ref[k - 1].T.copy()).to("cuda", torch.float32))
+        env.gust.copy_(torch.from_numpy(gust[k - 1].T.copy()).to("cuda", torch.float32))
+        env.i.copy_(torch.from_numpy(iters[k - 1].astype(np.int32)).cuda())
+        env.step(actions[k])
+        worst = max(worst, scaled_err(_np(env.state).T, ref[k], STATE_SCALE))
+    assert worst < 1e-5, worst
+
+
+def test_robust_rollout_equals_steps_and_is_shard_invariant(aq):
+    """Philox gusts/params: (i) the fused LQR rollout equals step-by-step bit for bit across a redraw step,
+    (ii) env e of a shard [lo,hi) with env_offset=lo equals env lo+e of the full batch."""
+    N, S = 512, 40
+    from autonomous_quadrotor_environment_amd import random_init_states
+    x0 = random_init_states(5, N).T.copy()
+
+    def make(n, lo):
+        env = aq.BatchedQuad(n, 0.01, 2000, training=True, direct_control=0, T=1)
+        env.robust_control = True
+        env.robust_gusts(None, seed=77, env_offset=lo)
+        env.robust_params(None, seed=77, env_offset=lo)
+        env.reset(x0[:, lo:lo + n])
+        return env
+    full = make(N, 0)
+    full.rollout("lqr", S)
+    stepped = make(N, 0)
+    ctl = aq.LqrController(stepped)
+    for _ in range(S):
+        stepped.step(ctl.control())
+    assert torch.equal(full.state, stepped.state)
+    assert torch.equal(full.gust, stepped.gust)
+    shard = make(128, 256)
+    shard.rollout("lqr", S)
+    assert torch.equal(shard.state, full.state[:, 256:384])
+    assert torch.equal(shard.robust_parameters, full.robust_parameters[:, 256:384])
+    # the draws have the reference's distributions (quadrotor_env.py:87-93,98-101)
+    big = aq.BatchedQuad(1 << 16, 0.01, 2000, direct_control=1)
+    big.robust_control = True
+    big.robust_gusts(None, seed=3)
+    big.robust_params(None, seed=3)
+    p = _np(big.robust_parameters)
+    assert abs(p[0:4].mean() - 0.05) < 1e-3 and p[0:4].min() >= 0 and p[0:4].max() <= 0.1
+    assert abs(p[5:9].mean() - 0.05) < 1e-3
+    assert abs(p[4].std() - 0.3) < 5e-3 and abs(p[4].mean()) < 5e-3
+    assert abs(p[9:12].std() - 0.1) < 2e-3
+    big.reset(np.array([0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0]))
+    gst = _np(big.gust)
+    assert abs(gst[0].std() - 5) < 0.1 and abs(gst[1].std() - 5) < 0.1 and abs(gst[2].std() - 2) < 0.05
+    assert abs(gst[0:3].mean()) < 0.1
+
+
+def test_robust_refuses_what_the_reference_cannot_do(aq):
+    env = aq.BatchedQuad(64, 0.01, 1000, variant="opt")
+    with pytest.raises(Exception, match="main variant"):
+        env.robust_control = True
+    env = aq.BatchedQuad(64, 0.01, 1000)
+    env.robust_control = True
+    env.reset(np.array([0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0]))
+    from autonomous_quadrotor_environment_amd import _lib as L
+    with pytest.raises(Exception, match="dynamics-only"):
+        env.step(None, flags=L.STEP_DYNAMICS_ONLY)
