@@ -713,6 +713,109 @@ def g18():
     save("g18_robust", **rec)
 
 
+def _policy_loop_env():
+    env = make_env(t_step=0.01, n=3000, training=False, euler=0, direct_control=1, T=5)
+    pol, _ = load_policy(128, "nn_old_solved_128_32000_e8f2b04d78f34fc794e686dcb00944d2.pth")
+    return env, pol
+
+
+def g19():
+    """Mission tracking with the PPO velocity policy and the outer position loop of velocity_pid.py:16-35, driven as
+    environment/position.py:216-244 does with REAL_CTRL (position.py itself needs panda3d; the loop below is the
+    harness's own, every called piece is the reference's)."""
+    from environment.controller.velocity_pid import vel_pid
+    from mission_control.mission_control import mission
+    rec = {}
+    for tag in ("point", "spiral"):
+        env, pol = _policy_loop_env()
+        mc = mission(0.01)
+        if tag == "point":
+            mc.gen_trajectory(5000, int(2.0 / 0.01), np.array([1.0, -0.5, 0.8]))
+        else:
+            mc.spiral_trajectory(150, 400, 0.4, 1.5, 0.6, np.array([0.0, 0.0, 0.0]))
+        aux = dl_in_gen(5, 13, 4)
+        x0 = np.array([0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0])
+        with quiet:
+            states, action = env.reset(x0.copy())
+        net_in = aux.dl_input(states, action)
+        cumm, der = 0, np.array([0, 0])
+        rows, acts, cmds, tgts = [], [], [], []
+        for k in range(350):
+            with torch.no_grad():
+                action = pol.actor(torch.FloatTensor(net_in)).cpu().detach().numpy()
+            with quiet:
+                states, _, _ = env.step(action)
+            err = mc.get_error(env.i * env.t_step)
+            tgts.append(err.copy())
+            pid_error, cumm, der = vel_pid(env.state, err, cumm, der)
+            err = err + pid_error
+            net_in = aux.dl_input(states - err, [action])
+            rows.append(np.array(env.state, dtype=float)); acts.append(np.array(action, dtype=float))
+            cmds.append(np.array(pid_error, dtype=float)[1:6:2])
+        rec[tag + "_x0"] = x0
+        rec[tag + "_targets"] = np.array(tgts)
+        rec[tag + "_state"] = np.array(rows)
+        rec[tag + "_actions"] = np.array(acts)
+        rec[tag + "_vel_cmd"] = np.array(cmds)
+        rec[tag + "_window_last"] = np.array(net_in, dtype=np.float32)
+    save("g19_mission_velpid", **rec)
+
+
+def g20():
+    """The analytical landing baseline of visual_landing/math_trajectory.py:46-157: PD position loop -> clipped
+    velocity command -> PPO velocity policy, visual_reward deciding the end of the episode.  The script runs at import
+    (hard-coded weight path, sys.exit on failure), so pos_pi is pulled out with ast and the episode loop is the
+    harness's; marker and initial state are drawn with the script's formulas (:34-43) from a seeded RandomState."""
+    tree = ast.parse(open(os.path.join(REF, "visual_landing/math_trajectory.py")).read())
+    ns = {"np": np}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "pos_pi":
+            exec(compile(ast.Module([node], []), "math_trajectory.pos_pi", "exec"), ns)
+    pos_control = ns["pos_pi"](4.5, 0.5, 0.00, 0.01)
+    env, pol = _policy_loop_env()
+    aux = dl_in_gen(5, 13, 4)
+    rng = np.random.RandomState(120)
+    VELOCITY_SCALE = np.array([0.5, 0.5, 1]); VELOCITY_D = np.array([0, 0, -VELOCITY_SCALE[2] / 1.5])
+    rec = {}
+    for ep in range(4):
+        aux.reset()
+        marker = np.append(rng.normal([0, 0], 0.8), 0.001)
+        qz = -5 * rng.random_sample() + 1
+        qxy = marker[0:2] + (rng.random_sample(2) - 0.5) * abs(-5 - qz) / 7 * 4
+        x0 = np.array([qxy[0], 0, qxy[1], 0, qz, 0, 1, 0, 0, 0, 0, 0, 0])
+        with quiet:
+            state, action = env.reset(x0.copy())
+        net_in = aux.dl_input(state, action)
+        last_shaping = None
+        rows, cmds, rews, acts = [], [], [], []
+        n_solved = 0
+        for k in range(3000):
+            with torch.no_grad():
+                action = pol.actor(torch.FloatTensor(net_in)).cpu().detach().numpy()
+            with quiet:
+                state, _, _ = env.step(action)
+            s, ds = state[0, 0:5:2], state[0, 1:6:2]
+            s_d = np.array([marker[0], marker[1], -5])
+            vel_error = pos_control.vel_error(s, s_d, ds, np.zeros(3))
+            vel_error = np.clip(vel_error, np.array([-0.5, -0.5, -1.666]), np.array([0.5, 0.5, 0.333]))
+            control = (vel_error - VELOCITY_D) / VELOCITY_SCALE
+            state_error = np.zeros([1, 14])
+            state_error[0, 1], state_error[0, 3], state_error[0, 5] = vel_error
+            net_in = aux.dl_input(state - state_error, [action])
+            reward, last_shaping, done_visual, n_solved = visual_reward(
+                k, marker, env.state[0:5:2], env.state[1:6:2], control, last_shaping, k, env.ang, env.state[-3:])
+            rows.append(np.array(env.state, dtype=float)); cmds.append(vel_error.copy()); rews.append(float(reward))
+            acts.append(np.array(action, dtype=float))
+            if done_visual:
+                break
+        pre = f"ep{ep}_"
+        rec[pre + "marker"] = marker; rec[pre + "x0"] = x0
+        rec[pre + "state"] = np.array(rows); rec[pre + "vel_cmd"] = np.array(cmds); rec[pre + "reward"] = np.array(rews)
+        rec[pre + "actions"] = np.array(acts)
+        rec[pre + "n_solved"] = np.array([n_solved]); rec[pre + "steps"] = np.array([len(rows)])
+    save("g20_landing_baseline", **rec)
+
+
 def g11():
     rng = np.random.RandomState(111)
     rows = []
@@ -741,6 +844,6 @@ def g11():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for name in todo:
         globals()[name]()

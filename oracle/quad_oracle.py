@@ -386,6 +386,32 @@ class OracleLqr:
         return a
 
 
+class OracleVelPid:
+    """vel_pid of environment/controller/velocity_pid.py:16-35 with the caller-side state of position.py:209-210."""
+
+    def __init__(self):
+        self.cumm, self.prev_err = np.zeros(3), np.zeros(3)
+
+    def __call__(self, state, target):
+        out = np.zeros(14)
+        lib().qo_vel_pid(_p(_a(state, 13)), _p(_a(target, 14)), _p(self.cumm), _p(self.prev_err), _p(out))
+        return out
+
+
+class OraclePosPi:
+    """pos_pi of visual_landing/math_trajectory.py:46-62 plus the velocity clip of :123."""
+
+    def __init__(self, P, D, I, dt):
+        self.P, self.D, self.I, self.dt = float(P), float(D), float(I), float(dt)
+        self.integrator = np.zeros(3)
+
+    def vel_error(self, s, s_d, ds, ds_d):
+        out = np.zeros(3)
+        lib().qo_pos_pi(C.c_double(self.P), C.c_double(self.D), C.c_double(self.I), C.c_double(self.dt),
+                        _p(self.integrator), _p(_a(s, 3)), _p(_a(s_d, 3)), _p(_a(ds, 3)), _p(_a(ds_d, 3)), _p(out))
+        return out
+
+
 class OracleWindow:
     """dl_in_gen of environment/controller/dl_auxiliary.py:15-32."""
 
