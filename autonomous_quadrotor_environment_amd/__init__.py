@@ -12,8 +12,9 @@ from .controllers import LqrController, PidController, PidPosController, pid_con
 from .ppo import ActorCriticWeights, dense_tail, dl_in_gen, gae, ppo_loss, visual_reward, PolicyRollout, PpoLearner  # noqa: F401
 from .mission import mission  # noqa: F401
 from .sensor import BatchedSensor  # noqa: F401
+from .position_control import MissionTracker, LandingBaseline  # noqa: F401
 from .distributed import shard_range, ShardedQuad, all_gather_returns  # noqa: F401
 
 __all__ = ["BatchedQuad", "quad", "random_init_states", "LqrController", "PidController", "PidPosController", "pid_control",
-           "ActorCriticWeights", "dl_in_gen", "gae", "dense_tail", "ppo_loss", "visual_reward", "PolicyRollout", "PpoLearner", "mission", "BatchedSensor", "shard_range",
+           "ActorCriticWeights", "dl_in_gen", "gae", "dense_tail", "ppo_loss", "visual_reward", "PolicyRollout", "PpoLearner", "mission", "BatchedSensor", "MissionTracker", "LandingBaseline", "shard_range",
            "ShardedQuad", "all_gather_returns"]

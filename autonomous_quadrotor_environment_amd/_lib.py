@@ -24,7 +24,8 @@ FLAG_DONE, FLAG_SOLVED, FLAG_HAS_SHAPING = 1, 2, 4
 (FIELD_STATE, FIELD_ANG, FIELD_PREV_ANG, FIELD_ANG_VEL, FIELD_VQ, FIELD_W, FIELD_STEP_EFFORT,
  FIELD_CLIPPED_ACTION, FIELD_ACCEL, FIELD_PREV_SHAPING, FIELD_REWARD, FIELD_ABS_SUM, FIELD_EP_RETURN,
  FIELD_PID, FIELD_I, FIELD_FLAGS, FIELD_WINDOW, FIELD_LAST_RETURN, FIELD_EPISODES, FIELD_ROBUST_PARAMS,
- FIELD_GUST, FIELD_GUST_EVALS) = range(22)
+ FIELD_GUST, FIELD_GUST_EVALS, FIELD_OUTER) = range(23)
+OUTER_NONE, OUTER_VELPID, OUTER_POSPI = 0, 1, 2
 
 
 class QenvConfig(C.Structure):
@@ -63,6 +64,9 @@ SYMBOLS = {
     "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
+    "qenv_outer_velpid": (_i, [_vp, _vp, C.c_int32]),
+    "qenv_outer_pospi": (_i, [_vp, _vp, C.c_double, C.c_double, C.c_double]),
+    "qenv_outer_reset": (_i, [_vp, _vp]),
     "qenv_set_robust": (_i, [_vp, _i]),
     "qenv_robust_params": (_i, [_vp, _vp, C.c_uint64, _i64, _vp]),
     "qenv_robust_gusts": (_i, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, _i64]),

@@ -100,6 +100,7 @@ template <typename T> struct Cfg {
     T bb[9];         // done box: |v|(3), |ang|(3), |omega|(3)
     T zero_control0; // zero_control = [zc0,0,0,0] (indirect) or [zc0]*4 (direct, zc0=0)
     int32_t n_max;   // n + T
+    int32_t warmup;  // T: warm-up steps of reset = window depth
     int32_t training, direct, clipped, variant;
 };
 

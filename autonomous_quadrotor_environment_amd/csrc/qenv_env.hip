@@ -35,6 +35,10 @@ template <typename T, typename S = T> struct StepArgs {
     int32_t win_slot;      // ring slot this step's slice goes to
     int32_t mode;          // QENV_STEP_* (mode bits only)
     int32_t ang_ok;        // every env's prev_ang row is the angle of its state row (see euler_update)
+    int32_t outer_kind;    // outer position loop evaluated at the window push (QENV_OUTER_*)
+    int32_t outer_rows;
+    const S* outer_target; // VELPID: [rows][7] mission table (wave-uniform rows); POSPI: [3][N]
+    T outer_gain[3];       // POSPI: P, D, I
 };
 
 template <typename T, typename S = T> struct RolloutArgs {
@@ -206,7 +210,40 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, 
         float* wv = a.win + (int64_t)a.win_slot * 15 * N + e;
 #pragma unroll
         for (int k = 0; k < 4; ++k) wv[(int64_t)k * N] = (float)raw[k];
-        wv[4 * N] = (float)y[1]; wv[5 * N] = (float)y[3]; wv[6 * N] = (float)y[5];
+        T voff[3] = {T(0), T(0), T(0)};
+        if (a.outer_kind != QENV_OUTER_NONE) {  // the policy sees state - state_error (position.py:233-244)
+            T integ[3], cmd[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) integ[k] = (T)ld(a.ws, ROW_OUTER + k, N, e);
+            if (a.outer_kind == QENV_OUTER_VELPID) {  // velocity_pid.py:16-35
+                int row = bk.i - cfg.warmup - 1;     // k-th policy step after the T warm-ups
+                row = row < 0 ? 0 : (row >= a.outer_rows ? a.outer_rows - 1 : row);
+                const S* tg = a.outer_target + (int64_t)row * 7;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T err = (T)tg[k] - y[2 * k];
+                    const T prev = (T)ld(a.ws, ROW_OUTER + 3 + k, N, e);
+                    integ[k] = integ[k] + err * T(0.01);
+                    const T der = (err - prev) / T(0.01);
+                    cmd[k] = T(3) * err + T(0) * integ[k] + T(0.05) * der;
+                    voff[k] = (T)tg[3 + k] + cmd[k];
+                    st(a.ws, ROW_OUTER + 3 + k, N, e, err);
+                }
+            } else {  // pos_pi, math_trajectory.py:46-62, clip of :123
+                const T lo[3] = {T(-0.5), T(-0.5), T(-1.666)}, hi[3] = {T(0.5), T(0.5), T(0.333)};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T err = (T)a.outer_target[(int64_t)k * N + e] - y[2 * k];
+                    integ[k] += err * cfg.t_step;
+                    const T v = a.outer_gain[0] * err + a.outer_gain[1] * (T(0) - y[2 * k + 1]) + a.outer_gain[2] * integ[k];
+                    cmd[k] = v < lo[k] ? lo[k] : (v > hi[k] ? hi[k] : v);
+                    voff[k] = cmd[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { st(a.ws, ROW_OUTER + k, N, e, integ[k]); st(a.ws, ROW_OUTER + 6 + k, N, e, cmd[k]); }
+        }
+        wv[4 * N] = (float)(y[1] - voff[0]); wv[5 * N] = (float)(y[3] - voff[1]); wv[6 * N] = (float)(y[5] - voff[2]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
     }
@@ -573,6 +610,15 @@ __global__ __launch_bounds__(256) void k_pid_reset(T* ws, int64_t N, const uint8
     for (int k = 0; k < 15; ++k) st(ws, ROW_PID + k, N, e, T(0));
 }
 
+template <typename S>
+__global__ __launch_bounds__(256) void k_outer_reset(S* ws, int64_t N, const uint8_t* mask) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    if (mask && mask[e] == 0) return;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st(ws, ROW_OUTER + k, N, e, S(0));
+}
+
 // robust_control.reset (quadrotor_env.py:97-101): the 12 episode draws, injected or Philox
 template <typename S>
 __global__ __launch_bounds__(256) void k_robust_params(S* ws, const int32_t* wsi, int64_t N, const S* params, uint64_t seed,
@@ -626,6 +672,7 @@ template <typename T> static Cfg<T> make_cfg(const qenv_s* q) {
     for (int k = 0; k < 9; ++k) c.bb[k] = (T)bb[k];
     c.zero_control0 = f.direct_control ? (T)(2.0 / phys::T2WR - 1.0) : (T)(phys::M * phys::G);
     c.n_max = f.n_max + f.T;
+    c.warmup = f.T;
     c.training = f.training ? 1 : 0;
     c.direct = f.direct_control ? 1 : 0;
     c.clipped = f.clipped ? 1 : 0;
@@ -685,6 +732,10 @@ template <typename T, typename S> static int do_step(qenv_s* q, const void* acti
     a.out_mask = (S*)out_mask;
     a.win = win_slot >= 0 ? q->window : nullptr;
     a.win_slot = win_slot;
+    a.outer_kind = q->outer.kind;
+    a.outer_rows = q->outer.rows;
+    a.outer_target = (const S*)q->outer.target;
+    for (int k = 0; k < 3; ++k) a.outer_gain[k] = (T)q->outer.gain[k];
     a.ang_ok = q->ang_ok;
     // host-side half of the prev_ang bookkeeping: a dynamics-only step moves every state without
     // touching the angle rows; an unmasked full step re-synchronises all of them
@@ -798,6 +849,8 @@ template <typename T, typename S> static int do_reset(qenv_s* q, const void* ini
         q->compact_valid = 0;
         return rc;
     }
+    const int outer_keep = q->outer.kind;
+    q->outer.kind = QENV_OUTER_NONE;  // the warm-up slices are the plain states (position.py:205-206, math_trajectory.py:106)
     for (int t = 0; t < q->cfg.T && rc == 0; ++t) {
         S* obs = out_states ? (S*)out_states + (int64_t)t * 14 * q->N : nullptr;
         // warm-up slice t goes to ring slot head+t: after T of them the reset env's ring is full and in
@@ -812,6 +865,7 @@ template <typename T, typename S> static int do_reset(qenv_s* q, const void* ini
             rc = check_launch("k_fill_actions");
         }
     }
+    q->outer.kind = outer_keep;
     q->compact_valid = 0;
     return rc;
 }
@@ -854,6 +908,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->warmup_push = 0;
     q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : 0;  // developer A/B switch
     q->robust = 0;
+    q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
     if (e != hipSuccess) { delete q; return fail_hip(e, "hipMemsetAsync(workspace)"); }
@@ -885,6 +940,9 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
     } else if (field_id == QENV_FIELD_ROBUST_PARAMS || field_id == QENV_FIELD_GUST) {
         *dev_ptr = (char*)q->ws + (size_t)(field_id == QENV_FIELD_GUST ? ROW_GUST : ROW_ROB) * q->N * esz;
         if (rows) *rows = field_id == QENV_FIELD_GUST ? 6 : 12;
+    } else if (field_id == QENV_FIELD_OUTER) {
+        *dev_ptr = (char*)q->ws + (size_t)ROW_OUTER * q->N * esz;
+        if (rows) *rows = 9;
     } else if (field_id == QENV_FIELD_LAST_RETURN) {
         *dev_ptr = (char*)q->ws + (size_t)ROW_LAST_RETURN * q->N * esz;
         if (rows) *rows = 1;
@@ -901,6 +959,30 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
         return fail(QENV_ERR_ARG, "qenv_field: unknown field id");
     }
     return QENV_OK;
+}
+
+int qenv_outer_velpid(qenv_t q, const void* table, int32_t n_rows) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_outer_velpid: null handle");
+    if (table && n_rows < 1) return fail(QENV_ERR_ARG, "qenv_outer_velpid: a table needs n_rows >= 1");
+    q->outer.kind = table ? QENV_OUTER_VELPID : QENV_OUTER_NONE;
+    q->outer.target = table; q->outer.rows = table ? n_rows : 0;
+    return QENV_OK;
+}
+
+int qenv_outer_pospi(qenv_t q, const void* targets, double P, double D, double I) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_outer_pospi: null handle");
+    q->outer.kind = targets ? QENV_OUTER_POSPI : QENV_OUTER_NONE;
+    q->outer.target = targets; q->outer.rows = 0;
+    q->outer.gain[0] = P; q->outer.gain[1] = D; q->outer.gain[2] = I;
+    return QENV_OK;
+}
+
+int qenv_outer_reset(qenv_t q, const uint8_t* mask) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_outer_reset: null handle");
+    const dim3 g = grid_for(q->N), b(256);
+    if (q->cfg.dtype == QENV_F64) hipLaunchKernelGGL((k_outer_reset<double>), g, b, 0, q->stream, (double*)q->ws, q->N, mask);
+    else hipLaunchKernelGGL((k_outer_reset<float>), g, b, 0, q->stream, (float*)q->ws, q->N, mask);
+    return check_launch("k_outer_reset");
 }
 
 int qenv_set_robust(qenv_t q, int enabled) {

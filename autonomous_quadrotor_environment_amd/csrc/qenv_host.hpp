@@ -32,7 +32,8 @@ enum {
     ROW_LAST_RETURN = 60,   // 1
     ROW_ROB = 61,           // 12: episode_kf(4), episode_m, episode_ir(4), episode_J diag(3) (robust_control.reset)
     ROW_GUST = 73,          // 6: gust(3), last_gust(3)
-    ROWS_T = 79
+    ROW_OUTER = 79,         // 9: outer position loop: integral(3), previous error(3), velocity command(3)
+    ROWS_T = 88
 };
 enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_COUNT = 4, IROW_GUST_K = 5, IROWS = 6 };  // IDX/COUNT: compacted reset list
 
@@ -62,8 +63,17 @@ struct qenv_gust_src {
     int64_t env_offset;       // global index of local env 0 (shard-invariant streams)
 };
 
+// outer position loop evaluated inside PUSH_WINDOW steps (velocity_pid.py / math_trajectory.py pos_pi)
+struct qenv_outer {
+    int32_t kind;             // QENV_OUTER_*
+    const void* target;       // VELPID: mission table [rows][7]; POSPI: per-env targets [3][N]; storage dtype
+    int32_t rows;
+    double gain[3];           // POSPI: P, D, I
+};
+
 struct qenv_s {
     qenv_config cfg;
+    qenv_outer outer;
     int32_t robust;           // env.robust_control
     qenv_gust_src gust;
     int64_t N;

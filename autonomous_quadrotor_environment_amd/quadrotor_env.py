@@ -353,6 +353,34 @@ class BatchedQuad:
                                          int(env_offset), L.ptr(out), L.ptr(logprob)), "qenv_sample_action")
         return out
 
+    # ---- outer position loops around the velocity policy (position.py:233-244, math_trajectory.py:118-133) ----
+    outer_state = property(lambda s: s._field(L.FIELD_OUTER))       # [9, N] integral, previous error, command
+    vel_cmd = property(lambda s: s._field(L.FIELD_OUTER)[6:9])      # [3, N] velocity command of the last step
+
+    def outer_velpid(self, table):
+        """vel_pid (velocity_pid.py:16-35) on a mission table [n, 7] (mission.table()); None switches it off.
+        From now on every step(push_window=True) pushes state - (target + pid_error) into the policy window."""
+        if table is not None:
+            if isinstance(table, np.ndarray):
+                table = torch.from_numpy(np.ascontiguousarray(table))
+            table = table.to(device=self.device, dtype=self.dtype).contiguous()
+            if table.dim() != 2 or table.shape[1] != 7:
+                raise ValueError(f"mission table: expected [n, 7], got {tuple(table.shape)}")
+        self._outer_target = table
+        L.check(L.lib.qenv_outer_velpid(self._h, L.ptr(table), 0 if table is None else int(table.shape[0])),
+                "qenv_outer_velpid")
+
+    def outer_pospi(self, targets, P=4.5, D=0.5, I=0.0):
+        """pos_pi + velocity clip (math_trajectory.py:46-62,:123) towards per-env targets [3, N]; None = off."""
+        t = self._as_rows(targets, 3, "targets")
+        self._outer_target = t
+        L.check(L.lib.qenv_outer_pospi(self._h, L.ptr(t), float(P), float(D), float(I)), "qenv_outer_pospi")
+
+    def outer_reset(self, mask=None):
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._bind()
+        L.check(L.lib.qenv_outer_reset(self._h, L.ptr(m)), "qenv_outer_reset")
+
     # ---- robust_control (quadrotor_env.py:84-109): episode plant perturbation + gusts -----------------
     @property
     def robust_control(self):

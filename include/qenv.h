@@ -96,7 +96,8 @@ typedef enum {
     QENV_FIELD_ROBUST_PARAMS = 19, /* [12][N]  episode_kf(4), episode_m, episode_ir(4), diag episode_J(3) */
     QENV_FIELD_GUST = 20,          /* [6][N]   robust_control.gust(3), last_gust(3)   */
     QENV_FIELD_GUST_EVALS = 21,    /* [1][N]   int32 RHS evaluations (= gust draws) of the env's last redraw step */
-    QENV_FIELD_COUNT_ = 22
+    QENV_FIELD_OUTER = 22,         /* [9][N]   outer loop: integral(3), previous error(3), velocity command(3) */
+    QENV_FIELD_COUNT_ = 23
 } qenv_field_id;
 
 #define QENV_FLAG_DONE 1
@@ -284,6 +285,25 @@ int qenv_robust_params(qenv_t q, const void *params, uint64_t seed, int64_t env_
  *     (i-1)/500 of the current episode (k, epoch clamped to K-1, E-1) -- parity runs replay recorded draws;
  *   table null: Philox4x32-10 keyed by (seed; env_offset + e, episodes[e], epoch, k) + Box-Muller. */
 int qenv_robust_gusts(qenv_t q, const void *table, int32_t E, int32_t K, uint64_t seed, int64_t env_offset);
+
+/* ---- outer position loops around the PPO velocity policy -----------------------------------------------------
+ * The reference steers its velocity-stabilising policy by feeding it `state - state_error` (environment/position.py
+ * :233-244, visual_landing/math_trajectory.py:118-133): only the three velocity entries of the window slice change.
+ * With a loop configured, every qenv_step(... | QENV_STEP_PUSH_WINDOW) evaluates it on the NEW state inside the step
+ * kernel, pushes [action, v - v_offset, q, q_dot] and leaves the velocity command in QENV_FIELD_OUTER rows 6..8.
+ *
+ * QENV_OUTER_VELPID  vel_pid (environment/controller/velocity_pid.py:16-35; P=3, I=0, D=0.05, dt=0.01 as hard-coded
+ *   there): table [n_rows][7] = {xd,yd,zd,dxd,dyd,dzd,psi_d} rows of mission.get_error (mission.table()), in the
+ *   handle's dtype; an env at step counter i uses row i - T - 1 (its k-th policy step), clamped to the last row.
+ *   v_offset = target velocity + PID(position error); command = the PID term (`pid_error`).
+ * QENV_OUTER_POSPI   pos_pi (math_trajectory.py:46-62) + the clip of :123 to [-0.5,-0.5,-1.666]..[0.5,0.5,0.333]:
+ *   targets [3][N] = s_d per env; v_offset = command = clip(P (s_d - s) + D (0 - ds) + I integral).
+ * A null table/targets pointer switches the loop off.  qenv_outer_reset zeroes the loop state of the masked envs
+ * (position.py:209-210; math_trajectory.py `pos_pi.reset`). */
+enum { QENV_OUTER_NONE = 0, QENV_OUTER_VELPID = 1, QENV_OUTER_POSPI = 2 };
+int qenv_outer_velpid(qenv_t q, const void *table, int32_t n_rows);
+int qenv_outer_pospi(qenv_t q, const void *targets, double P, double D, double I);
+int qenv_outer_reset(qenv_t q, const uint8_t *mask);
 
 /* Replaces PPO.get_advantages (environment/controller/ppo.py:125-141, ddof=0;
  * visual_landing/ppo_trainer.py:133-148, ddof=1) on a time-major rollout:

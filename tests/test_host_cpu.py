@@ -36,9 +36,9 @@ def test_argument_validation_without_a_device(built):
     n32 = L.lib.qenv_workspace_bytes(C.byref(cfg))
     cfg.dtype = L.F64
     n64 = L.lib.qenv_workspace_bytes(C.byref(cfg))
-    # 79 rows of T (61 + 12 robust parameters + 6 gust) + 6 int rows + 15*T float rows, 256-byte aligned sections
-    assert n32 == 79 * 1024 * 4 + 6 * 1024 * 4 + 75 * 1024 * 4
-    assert n64 == 79 * 1024 * 8 + 6 * 1024 * 4 + 75 * 1024 * 4
+    # 88 rows of T (61 + 12 robust parameters + 6 gust + 9 outer loop) + 6 int rows + 15*T float rows, 256-byte aligned sections
+    assert n32 == 88 * 1024 * 4 + 6 * 1024 * 4 + 75 * 1024 * 4
+    assert n64 == 88 * 1024 * 8 + 6 * 1024 * 4 + 75 * 1024 * 4
     bad = L.QenvConfig(0, 0.01, 1000, 1, 1, 1, 1, 0, 0, 0, 0)
     assert L.lib.qenv_workspace_bytes(C.byref(bad)) == 0
     h = C.c_void_p()
