@@ -486,14 +486,19 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, 
 // selects.  Each env follows exactly the instruction sequence of the scalar version (an env that has
 // reached t_bound idles with h = 0 while its partner finishes), so results are bit-identical to it.
 __device__ __forceinline__ void integrate_rk45_x2(F2 y[13], const Act<F2>& u, Plant<F2, false>& pl, float tb, F2 kq[13],
-                                                  F2 dy[13]) {
+                                                  F2 dy[13], bool have_f0 = false) {
     using m = Mth<float>;
     using m2 = Mth<F2>;
     constexpr int MAX_ATTEMPTS = 96;
     F2 k1[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) dy[i] = F2{0.f, 0.f};
-    rhs(y, u, pl, k1);
+    if (have_f0) {  // see integrate_rk45
+#pragma unroll
+        for (int i = 0; i < 13; ++i) k1[i] = kq[i];
+    } else {
+        rhs(y, u, pl, k1);
+    }
     float h_abs[2];
     {
         F2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
@@ -636,10 +641,11 @@ __device__ __forceinline__ void integrate(T y[13], const Act<T>& u, P& pl, T tb,
 }
 
 template <int INTEG>
-__device__ __forceinline__ void integrate2(F2 y[13], const Act<F2>& u, Plant<F2, false>& pl, float tb, F2 kq[13], F2 dy[13]) {
-    if constexpr (INTEG == INT_RK45) integrate_rk45_x2(y, u, pl, tb, kq, dy);
-    else if constexpr (INTEG == INT_DP5) integrate_dp5<F2>(y, u, pl, F2{tb, tb}, kq, dy);
-    else integrate_rk4<F2>(y, u, pl, F2{tb, tb}, kq, dy);
+__device__ __forceinline__ void integrate2(F2 y[13], const Act<F2>& u, Plant<F2, false>& pl, float tb, F2 kq[13], F2 dy[13],
+                                           bool have_f0 = false) {
+    if constexpr (INTEG == INT_RK45) integrate_rk45_x2(y, u, pl, tb, kq, dy, have_f0);
+    else if constexpr (INTEG == INT_DP5) integrate_dp5<F2>(y, u, pl, F2{tb, tb}, kq, dy, have_f0);
+    else integrate_rk4<F2>(y, u, pl, F2{tb, tb}, kq, dy, have_f0);
 }
 
 // ---- per-env bookkeeping carried between steps (registers in fused rollouts) -------------

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
             u.Mz = F2{us[0].Mz, us[1].Mz}; u.omr = F2{us[0].omr, us[1].omr};
         }
         const F2 q_old[4] = {y[6], y[7], y[8], y[9]};
-        integrate2<INTEG>(y, u, pl2, cfg.t_step, kq, dy);
+        integrate2<INTEG>(y, u, pl2, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && s > 0);
         if (!dyn_only) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -773,7 +773,12 @@ template <typename T, typename S, int INTEG> static void launch_rollout(qenv_s* 
         return;
     }
     if constexpr (sizeof(T) == 4 && sizeof(S) == 4) {
-        if (q->packed && (q->N % 2) == 0) {  // two envs per lane, packed fp32 integrator
+        // two envs per lane, packed fp32 integrator: bit-identical results; measured (tools/ab_packed.py) +26..37 %
+        // for the fixed-step integrators under a constant action once there are >= 2 lane-pairs-worth of waves per
+        // SIMD (N >= 131072), a loss below that, and no gain for rk45 or with a controller in the loop.
+        // QENV_PACKED=0/1 overrides the rule.
+        const bool auto_packed = q->packed < 0 && INTEG != INT_RK45 && controller == QENV_CTRL_CONST && q->N >= 131072;
+        if ((q->packed > 0 || auto_packed) && (q->N % 2) == 0) {
             const dim3 g2 = grid_for(q->N / 2), b2(256);
             switch (controller) {
                 case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_CONST>), g2, b2, 0, q->stream, a); break;
@@ -906,7 +911,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->ang_ok = 0;
     q->compact_valid = 0;
     q->warmup_push = 0;
-    q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : 0;  // developer A/B switch
+    q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : -1;  // -1: automatic (see launch_rollout)
     q->robust = 0;
     q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};

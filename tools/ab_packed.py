@@ -22,7 +22,7 @@ for integ in ("rk45", "dp5", "rk4"):
         same = torch.equal(a.state, b.state) and (flags == 1 or (torch.equal(a.flags, b.flags) and torch.equal(a.episode_return, b.episode_return) and torch.equal(a.ang_vel, b.ang_vel)))
         md = float((a.state - b.state).abs().max())
         print(integ, ctrl, "flags", flags, "bit-identical" if same else f"DIFFERENT maxdiff {md:.3e}", flush=True)
-for n in (65536, 1048576):
+for n in (65536, 131072, 262144, 524288, 1048576):
     for integ in ("rk45", "dp5", "rk4"):
         for packed in (False, True):
             env = make(n, integ, packed)
