@@ -13,8 +13,8 @@ from .ppo import ActorCriticWeights, dense_tail, dl_in_gen, gae, ppo_loss, visua
 from .mission import mission  # noqa: F401
 from .sensor import BatchedSensor  # noqa: F401
 from .position_control import MissionTracker, LandingBaseline  # noqa: F401
-from .distributed import shard_range, ShardedQuad, all_gather_returns  # noqa: F401
+from .distributed import shard_range, ShardedQuad, all_gather_returns, GradBucket  # noqa: F401
 
 __all__ = ["BatchedQuad", "quad", "random_init_states", "LqrController", "PidController", "PidPosController", "pid_control",
            "ActorCriticWeights", "dl_in_gen", "gae", "dense_tail", "ppo_loss", "visual_reward", "PolicyRollout", "PpoLearner", "mission", "BatchedSensor", "MissionTracker", "LandingBaseline", "shard_range",
-           "ShardedQuad", "all_gather_returns"]
+           "ShardedQuad", "all_gather_returns", "GradBucket"]

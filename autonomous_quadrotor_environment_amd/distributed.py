@@ -67,6 +67,35 @@ def all_gather_returns(local_returns, n_global=None, group=None):
     return torch.cat([buf[r * max_n:r * max_n + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
+class GradBucket:
+    """One flat fp32 buffer holding every parameter gradient of the actor and the critic (53 k floats = 212 KB for
+    N=128): the data-parallel learner averages it with a single all-reduce (RCCL over xGMI: latency-bound at this
+    size, so one bucket, not one collective per tensor).  `views[i]` aliases the slice of parameter i."""
+
+    def __init__(self, params):
+        total = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce_mean_(self, group=None):
+        """Average over the ranks (each rank's loss is a mean over its equal-sized shard of the batch).  No-op
+        without an initialised process group or with one rank."""
+        if group is False or not (dist.is_available() and dist.is_initialized()):
+            return self.flat
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(self.flat, group=group)
+            self.flat.div_(world)
+        return self.flat
+
+
 class ShardedQuad:
     """This rank's slice of a global batch of `n_global` envs."""
 

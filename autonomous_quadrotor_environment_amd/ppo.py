@@ -175,15 +175,22 @@ class PpoLearner:
     Gradients of the weights are fp32-atomic sums over the batch (order not deterministic to the last bit)."""
 
     def __init__(self, weights: ActorCriticWeights, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, eps_clip=0.2, c_value=0.5,
-                 c_entropy=0.006, K_epochs=10):
+                 c_entropy=0.006, K_epochs=10, group=None):
+        """group: torch.distributed group of the data-parallel learners (None = the default group if one is
+        initialised, False = never reduce).  Each rank holds an equal shard of the batch; gradients are averaged
+        with one bucketed all-reduce per epoch, so every rank applies the same Adam step."""
         assert weights.critic is not None
         self.w, self.lr, self.betas, self.eps = weights, lr, betas, eps
         self.eps_clip, self.c_value, self.c_entropy, self.K_epochs = eps_clip, c_value, c_entropy, K_epochs
         self.step = 0
+        self.group = group
+        from .distributed import GradBucket
+        keys = [(head, k) for head in ("actor", "critic") for k in range(6)]
+        self.bucket = GradBucket([weights.head(h)[k] for h, k in keys])  # every .grad is a slice of one flat buffer
         self._state = {}
-        for head in ("actor", "critic"):
-            for k, p in enumerate(weights.head(head)):
-                self._state[(head, k)] = (torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p))  # grad, m, v
+        for key, g in zip(keys, self.bucket.views):
+            p = weights.head(key[0])[key[1]]
+            self._state[key] = (g, torch.zeros_like(p), torch.zeros_like(p))  # grad, m, v
         self._buf = None
 
     def _buffers(self, H, n, N, dev):
@@ -230,6 +237,7 @@ class PpoLearner:
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
                 L.check(L.lib.qenv_weight_grad(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb), stream),
                         "qenv_weight_grad")
+        self.bucket.all_reduce_mean_(self.group)
         return loss
 
     def adam_step(self):

@@ -50,3 +50,36 @@ def test_all_gather_returns_world2(n_global):
     for rank, full, stats in res:
         assert np.array_equal(full, want), rank
         assert stats[0] == n_global and abs(stats[1] - want.sum()) < 1e-6 and abs(stats[2] - (want ** 2).sum()) < 1e-3
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autonomous_quadrotor_environment_amd.distributed import GradBucket
+    shapes = [(128, 75), (128,), (128, 128), (128,), (4, 128), (4,), (128, 75), (128,), (128, 128), (128,), (1, 128), (1,)]
+    params = [torch.zeros(s) for s in shapes]
+    b = GradBucket(params)
+    for k, v in enumerate(b.views):  # the per-tensor gradients of this rank's shard
+        v.copy_(torch.full(v.shape, float(k + 1) * (rank + 1)))
+    b.all_reduce_mean_()
+    q.put((rank, [float(v.mean()) for v in b.views], int(b.flat.numel()), [tuple(v.shape) for v in b.views] == shapes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_all_reduce_world2():
+    """The data-parallel learner's one exchange: all 12 gradient tensors travel as ONE 52 869-float bucket and come
+    back as the mean over the ranks, in place, through the per-tensor views the Adam kernel reads."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, 29733, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, means, numel, shapes_ok in res:
+        assert shapes_ok and numel == 2 * (128 * 75 + 128 + 128 * 128 + 128) + 4 * 128 + 4 + 128 + 1
+        assert means == [1.5 * (k + 1) for k in range(12)], rank
