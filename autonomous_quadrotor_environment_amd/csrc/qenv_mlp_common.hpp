@@ -10,15 +10,16 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // C/D layout of v_mfma_f32_32x32x2_f32: register j of lane-half `half` holds row (j&3) + 8 (j>>2) + 4 half
 __device__ __forceinline__ int acc_row(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }
 
-// tanh with ~1e-7 absolute error in ~12 VALU instructions (ocml's tanhf is ~3x that and the two
-// hidden layers need 256 of them per env): odd Taylor polynomial below 0.3 (next term < 2e-8),
-// 1 - 2/(exp(2|x|)+1) on v_exp_f32 / v_rcp_f32 above; saturates cleanly for large |x|.
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32: 5 VALU instructions (7 issue slots; ocml's tanhf is
+// ~40 and the two hidden layers need 256 of them per env).  ABSOLUTE error <= ~1.2e-7 everywhere (near 0 the
+// subtraction from 1 rounds at ulp(1) = 6e-8: the relative error of a tiny activation is large, its absolute error is
+// not, and only that propagates through the next layer's dot products); exact +-1 saturation (exp -> inf / 0).
+// fp32 MFMAs execute on the SIMD's vector FMA lanes (measured, tools/ubench/mfma_interleave.hip: VALU instructions
+// placed between dependent v_mfma_f32_32x32x2_f32 are not hidden, each costs its full issue time and more), so every
+// VALU instruction of the activation adds directly to the kernel time.
 __device__ __forceinline__ float fast_tanh(float x) {
-    const float ax = fabsf(x), x2 = x * x;
-    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
-    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    const float small = ax * (1.0f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f))));
-    return copysignf(ax < 0.3f ? small : big, x);
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 }  // namespace qenv
