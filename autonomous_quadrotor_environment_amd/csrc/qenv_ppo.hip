@@ -60,10 +60,10 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     const int K1P = (K1 + 1) & ~1;
     float* W1t = lds;                                   // [K1P][HP]
     float* W2t = W1t + (size_t)K1P * HP;                // [HP][HP]   (k-major), only if W2_LDS
-    float* W3t = W2t + (W2_LDS ? (size_t)HP * HP : 0);  // [HP][4]    (h-major: one ds_read_b128 per hidden unit)
-    float* b1s = W3t + 4 * HP;
+    float* W3t = W2t + (W2_LDS ? (size_t)HP * HP : 0);  // [HP][32]   (k-major; output rows >= n_out are zero)
+    float* b1s = W3t + 32 * HP;
     float* b2s = b1s + HP;
-    float* b3s = b2s + HP;  // [4]
+    float* b3s = b2s + HP;  // [32], zero beyond n_out
     for (int idx = threadIdx.x; idx < K1P * HP; idx += BLOCK) {
         const int k = idx / HP, h = idx % HP;  // write-coalesced, conflict-free
         W1t[idx] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
@@ -73,15 +73,15 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
             const int k = idx / HP, h = idx % HP;
             W2t[idx] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
         }
-    for (int idx = threadIdx.x; idx < 4 * HP; idx += BLOCK) {
-        const int h = idx / 4, o = idx % 4;
+    for (int idx = threadIdx.x; idx < 32 * HP; idx += BLOCK) {
+        const int h = idx / 32, o = idx % 32;
         W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
     }
     for (int h = threadIdx.x; h < HP; h += BLOCK) {
         b1s[h] = h < H ? a.b1[h] : 0.f;
         b2s[h] = h < H ? a.b2[h] : 0.f;
     }
-    if (threadIdx.x < 4) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    if (threadIdx.x < 32) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
@@ -166,10 +166,14 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
         }
-        // layer 2 (MFMA) + layer 3 (VALU), one output tile at a time.  Register j of input tile ti IS the B
-        // operand of the k-step that pairs hidden rows 32 ti + acc_row(j,0) and 32 ti + acc_row(j,1); each lane
-        // then holds half of its env's hidden vector for the 4-output dot products.
-        float o3[4] = {0.f, 0.f, 0.f, 0.f};
+        // layer 2 + layer 3, both on the MFMA, one layer-2 output tile at a time.  Register j of input tile ti IS
+        // the B operand of the k-step that pairs hidden rows 32 ti + acc_row(j,0) and 32 ti + acc_row(j,1).  Layer 3
+        // (n_out <= 4 rows, padded to one 32-row tile) consumes each finished layer-2 tile the same way: 16 more
+        // MFMAs per tile instead of 64 dependent VALU fmas + 16 ds_read_b128 -- on this chip fp32 MFMAs and VALU
+        // share the vector lanes, and the VALU form of this layer cost 26 us of a 99 us launch (ablation, A/B).
+        f32x16 acc3;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc3[j] = b3s[acc_row(j, half)];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x16 acc2;
@@ -186,18 +190,17 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                     if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh(acc2[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float hv = fast_tanh(acc2[j]);
-                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * (32 * t + acc_row(j, half))]);
-                o3[0] = fmaf(w3.x, hv, o3[0]); o3[1] = fmaf(w3.y, hv, o3[1]);
-                o3[2] = fmaf(w3.z, hv, o3[2]); o3[3] = fmaf(w3.w, hv, o3[3]);
-                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(W3t[(32 * t + acc_row(j, half)) * 32 + col], acc2[j], acc3, 0, 0, 0);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            float v = o3[o] + __shfl_xor(o3[o], 32);
-            v += b3s[o];
+            float v = acc3[o];  // output row o = acc_row(o, 0): held by the lower lane half
             if (a.final_tanh) v = tanhf(v);  // the 4 outputs keep the exact tanh
             if (valid && half == 0 && o < a.n_out) {
                 if (a.out_f64) ((double*)a.out)[(int64_t)o * a.N + e] = (double)v;
@@ -211,7 +214,7 @@ template <int H, int TW, int BLOCK, bool W2_LDS>
 static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
     const int K1P = (15 * T + 1) & ~1;
-    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 4 * HP + 2 * HP + 4);
+    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 32 * HP + 2 * HP + 32);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");
     hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
