@@ -246,14 +246,14 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* W1c = lds;                   // [KC][H+1]
     float* W2t = W1c + KC * LDW;        // [H][H]  k-major
-    float* W3t = W2t + HP * HP;         // [HP][4]
-    float* b1s = W3t + 4 * HP;
+    float* W3t = W2t + HP * HP;         // [HP][32] k-major, output rows >= n_out zero (layer 3 runs on the MFMA, see k_mlp)
+    float* b1s = W3t + 32 * HP;
     float* b2s = b1s + HP;
     float* b3s = b2s + HP;
     for (int idx = threadIdx.x; idx < HP * HP; idx += 256) { const int k = idx / HP, h = idx % HP; W2t[idx] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f; }
-    for (int idx = threadIdx.x; idx < 4 * HP; idx += 256) { const int h = idx / 4, o = idx % 4; W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f; }
+    for (int idx = threadIdx.x; idx < 32 * HP; idx += 256) { const int h = idx / 32, o = idx % 32; W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f; }
     for (int h = threadIdx.x; h < HP; h += 256) { b1s[h] = h < H ? a.b1[h] : 0.f; b2s[h] = h < H ? a.b2[h] : 0.f; }
-    if (threadIdx.x < 4) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    if (threadIdx.x < 32) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
     const int64_t n_tiles = (a.N + 31) / 32;
@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j] + b1s[32 * t + acc_row(j, half)]);
-        float o3[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x16 acc3;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc3[j] = b3s[acc_row(j, half)];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x16 acc2;
@@ -311,18 +313,17 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
                     if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh(acc2[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float hv = fast_tanh(acc2[j]);
-                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * (32 * t + acc_row(j, half))]);
-                o3[0] = fmaf(w3.x, hv, o3[0]); o3[1] = fmaf(w3.y, hv, o3[1]);
-                o3[2] = fmaf(w3.z, hv, o3[2]); o3[3] = fmaf(w3.w, hv, o3[3]);
-                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(W3t[(32 * t + acc_row(j, half)) * 32 + col], acc2[j], acc3, 0, 0, 0);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            float v = o3[o] + __shfl_xor(o3[o], 32);
-            v += b3s[o];
+            float v = acc3[o];  // output row o is held by the lower lane half
             if (a.final_tanh) v = tanhf(v);
             if (valid && half == 0 && o < a.n_out) a.out[(int64_t)o * a.N + e] = v;
         }
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
 
 template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
-    const size_t lds = sizeof(float) * (64 * (HP + 1) + HP * HP + 4 * HP + 2 * HP + 4);
+    const size_t lds = sizeof(float) * (64 * (HP + 1) + HP * HP + 32 * HP + 2 * HP + 32);
     hipError_t e = hipFuncSetAttribute((const void*)k_dense_tail<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_dense_tail)");
     const int64_t n_tiles = (a.N + 31) / 32;
