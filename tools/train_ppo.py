@@ -17,12 +17,15 @@ p.add_argument("--eval-envs", type=int, default=1024)
 p.add_argument("--lr", type=float, default=5e-4)
 p.add_argument("--seed", type=int, default=1)
 p.add_argument("--integrator", default="rk45")
+p.add_argument("--robust", action="store_true", help="train under robust_control: a new perturbed plant per episode + gusts")
+p.add_argument("--eval-robust", action="store_true", help="evaluate on the perturbed plant as well (else nominal)")
 p.add_argument("--log", default="")
 a = p.parse_args()
 
 w = aq.ActorCriticWeights.random(a.hidden, 75, 4, seed=a.seed)
 w.std = 0.1
 env = aq.BatchedQuad(a.envs, 0.01, 1000, training=True, direct_control=1, T=5, integrator=a.integrator)
+env.robust_control = a.robust  # PolicyRollout then draws the episode parameters / gusts from Philox at every (re)start
 ro = aq.PolicyRollout(env, w, a.horizon, store_obs=True, auto_reset=True, seed=a.seed)
 learner = aq.PpoLearner(w, lr=a.lr)
 ro.start()
@@ -41,7 +44,8 @@ for u in range(1, a.updates + 1):
                loss_first=float(losses[0]["loss"]), loss_last=float(losses[-1]["loss"]))
     if a.eval_every and (u % a.eval_every == 0 or u == 1):
         ev = aq.BatchedQuad(a.eval_envs, 0.01, 1000, training=False, direct_control=1, T=5, integrator=a.integrator)
-        er = aq.PolicyRollout(ev, aq.ActorCriticWeights(w.actor, None), 1)
+        ev.robust_control = a.eval_robust
+        er = aq.PolicyRollout(ev, aq.ActorCriticWeights(w.actor, None), 1, seed=a.seed + 77)
         er.start(ev.sample_init_states(a.seed + 1000, u))
         for _ in range(500):
             er.t = 0
