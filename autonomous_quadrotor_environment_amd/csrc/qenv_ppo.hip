@@ -64,15 +64,25 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     float* b1s = W3t + 32 * HP;
     float* b2s = b1s + HP;
     float* b3s = b2s + HP;  // [32], zero beyond n_out
-    for (int idx = threadIdx.x; idx < K1P * HP; idx += BLOCK) {
-        const int k = idx / HP, h = idx % HP;  // write-coalesced, conflict-free
-        W1t[idx] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
-    }
-    if (W2_LDS)
-        for (int idx = threadIdx.x; idx < HP * HP; idx += BLOCK) {
-            const int k = idx / HP, h = idx % HP;
-            W2t[idx] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
+    // transposing stage-in, 8 x 8 sub-blocks per wave instruction (lane = 8 hl + kl): the global reads fetch 32 B runs
+    // of 8 weight rows (a row-per-lane read would touch 64 different cache lines per instruction, 32 times each over
+    // the loop), the LDS writes land 8 lanes per bank (k stride = HP words) -- an 8-way write conflict that costs less
+    // than the refetching it replaces, and the [k][h] image keeps the MFMA operand reads conflict-free and unpadded
+    {
+        constexpr int KL = 8, HL = 64 / KL;  // 4 x 16 and 16 x 4 sub-blocks measured within 1.5 % of this
+        const int kl = threadIdx.x % KL, hl = (threadIdx.x / KL) % HL, wv = threadIdx.x >> 6;
+        constexpr int NW = BLOCK / 64;
+        const int kb1 = (K1P + KL - 1) / KL;
+        for (int blk = wv; blk < (HP / HL) * kb1; blk += NW) {
+            const int h = (blk / kb1) * HL + hl, k = (blk % kb1) * KL + kl;
+            if (k < K1P) W1t[k * HP + h] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
         }
+        if (W2_LDS)
+            for (int blk = wv; blk < (HP / HL) * (HP / KL); blk += NW) {
+                const int h = (blk / (HP / KL)) * HL + hl, k = (blk % (HP / KL)) * KL + kl;
+                W2t[k * HP + h] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
+            }
+    }
     for (int idx = threadIdx.x; idx < 32 * HP; idx += BLOCK) {
         const int h = idx / 32, o = idx % 32;
         W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
