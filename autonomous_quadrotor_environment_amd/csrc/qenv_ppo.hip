@@ -243,9 +243,9 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
 // padded by one word so the transposing staging writes are conflict-free); the four waves of a workgroup
 // march over the chunks together, each accumulating its own 32-env tile.
 struct DenseArgs {
-    const float* x;  // [K][N]
+    const float* x;  // [n_chunks][K][N]
     int64_t N;
-    int32_t K, n_out, final_tanh;
+    int32_t K, n_out, final_tanh, n_chunks;
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     float* out;
 };
@@ -266,13 +266,18 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
     if (threadIdx.x < 32) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
-    const int64_t n_tiles = (a.N + 31) / 32;
+    const int64_t tiles_per_chunk = (a.N + 31) / 32;
+    const int64_t n_tiles = tiles_per_chunk * a.n_chunks;  // chunk c: x + c K N -> out + c n_out N (time-major rollouts)
     const int64_t rounds = (n_tiles + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4);
     const uint32_t N32 = (uint32_t)a.N;
     for (int64_t r = 0; r < rounds; ++r) {
-        const int64_t tile = (r * gridDim.x + blockIdx.x) * 4 + wave;
+        const int64_t gtile = (r * gridDim.x + blockIdx.x) * 4 + wave;
+        const int64_t chunk = gtile < n_tiles ? gtile / tiles_per_chunk : 0;
+        const int64_t tile = gtile - chunk * tiles_per_chunk;
+        const float* __restrict__ xc = a.x + chunk * (int64_t)a.K * a.N;
+        float* __restrict__ outc = a.out + chunk * (int64_t)a.n_out * a.N;
         const int64_t e = tile * 32 + col;
-        const bool valid = tile < n_tiles && e < a.N;
+        const bool valid = gtile < n_tiles && e < a.N;
         const uint32_t e32 = (uint32_t)(valid ? e : a.N - 1);
         f32x16 acc1[NT];
 #pragma unroll
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
                 for (int s = 0; s < 8; ++s) {  // 8 k-steps of activations in flight before the first MFMA needs one
                     const int k = kc + 2 * (s0 + s) + half;
                     const uint32_t kk = (uint32_t)(k < a.K ? k : a.K - 1);
-                    const float v = a.x[kk * N32 + e32];
+                    const float v = xc[kk * N32 + e32];
                     xs[s] = k < a.K ? v : 0.f;
                 }
 #pragma unroll
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
         for (int o = 0; o < 4; ++o) {
             float v = acc3[o];  // output row o is held by the lower lane half
             if (a.final_tanh) v = tanhf(v);
-            if (valid && half == 0 && o < a.n_out) a.out[(int64_t)o * a.N + e] = v;
+            if (valid && half == 0 && o < a.n_out) outc[(int64_t)o * a.N + e] = v;
         }
     }
 }
@@ -345,7 +350,7 @@ template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream)
     const size_t lds = sizeof(float) * (64 * (HP + 1) + HP * HP + 32 * HP + 2 * HP + 32);
     hipError_t e = hipFuncSetAttribute((const void*)k_dense_tail<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_dense_tail)");
-    const int64_t n_tiles = (a.N + 31) / 32;
+    const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
     int64_t blocks = (n_tiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL((k_dense_tail<H>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -826,14 +831,14 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
     }
 }
 
-int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float* x, const float* W1,
-                    const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* out,
-                    void* stream) {
+int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, int n_out, int final_tanh, const float* x,
+                           const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                           const float* b3, float* out, void* stream) {
     if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_dense_tail: null argument");
-    if (n <= 0 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_dense_tail: bad sizes");
+    if (n <= 0 || n_chunks < 1 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_dense_tail: bad sizes");
     if ((int64_t)k_in * n >= ((int64_t)1 << 31)) return fail(QENV_ERR_ARG, "qenv_dense_tail: K*n must stay below 2^31");
     DenseArgs a;
-    a.x = x; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh;
+    a.x = x; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh; a.n_chunks = n_chunks;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     switch (hidden) {
         case 16: return launch_dense<16>(a, (hipStream_t)stream);
@@ -842,6 +847,12 @@ int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, 
         case 128: return launch_dense<128>(a, (hipStream_t)stream);
         default: return fail(QENV_ERR_ARG, "qenv_dense_tail: hidden must be 16, 32, 64 or 128");
     }
+}
+
+int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float* x, const float* W1,
+                    const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* out,
+                    void* stream) {
+    return qenv_dense_tail_chunks(n, 1, k_in, hidden, n_out, final_tanh, x, W1, b1, W2, b2, W3, b3, out, stream);
 }
 
 int qenv_sample_action(qenv_t q, const void* mean, double std, const void* noise, uint64_t seed, uint64_t step,

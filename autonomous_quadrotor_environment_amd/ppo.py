@@ -212,10 +212,9 @@ class PpoLearner:
         obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
         # forward of both heads on the stored observations (the dense kernel takes feature-major chunks)
         for head, out, ft in (("actor", b["mean"], True), ("critic", b["value"], False)):
-            W = w.head(head)
-            for c in range(n):
-                L.check(L.lib.qenv_dense_tail(N, K, H, W[4].shape[0], int(ft), L.ptr(obs[c]), *[L.ptr(x) for x in W],
-                                              L.ptr(out[c]), stream), "qenv_dense_tail")
+            W = w.head(head)  # all n stored steps in one launch
+            L.check(L.lib.qenv_dense_tail_chunks(N, n, K, H, W[4].shape[0], int(ft), L.ptr(obs), *[L.ptr(x) for x in W],
+                                                 L.ptr(out), stream), "qenv_dense_tail_chunks")
         # loss + seed gradients over the whole batch: view [n, r, N] as r rows of n*N samples
         flat = lambda t, r: t.permute(1, 0, 2).reshape(r, n * N).contiguous()
         loss = ppo_loss(flat(b["mean"], 4), b["value"].reshape(n * N), flat(actions, 4), flat(old_logprob, 4),

@@ -245,6 +245,11 @@ int qenv_sensor_read(qenv_t q, void *sens, const void *z27, uint64_t seed, uint6
 int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float *x,
                     const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                     const float *b3, float *out, void *stream);
+/* The same network over n_chunks independent chunks in ONE launch: x [n_chunks][K][N] -> out [n_chunks][n_out][N]
+ * (the layout of a stored time-major rollout: the forward pass of PPO.update, ppo.py:176-183, over all its steps). */
+int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, int n_out, int final_tanh,
+                           const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                           const float *W3, const float *b3, float *out, void *stream);
 
 /* Replaces ActorCritic.act's sampling (model.py:62-68): action = mean + std * eps,
  * logprob = Normal(mean, std).log_prob(action) per dimension.
