@@ -46,6 +46,7 @@ struct MlpArgs {
     void* out;          // [n_out][N]
     int32_t out_f64;
     float* obs_store;   // null or [15*T][N]: the window in time order
+    int32_t n_chunks;   // > 1: win = [n_chunks][15*T][N] stored observations (head 0), out = [n_chunks][n_out][N]
 };
 
 // K1 = 15*T window elements; TW > 0: compile-time window length (the whole observation of a tile
@@ -96,12 +97,17 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
     const int wave = threadIdx.x >> 6, waves_per_block = BLOCK / 64;
-    const int64_t n_tiles = (a.N + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * waves_per_block + wave; tile < n_tiles;
-         tile += (int64_t)gridDim.x * waves_per_block) {
+    const int64_t tiles_per_chunk = (a.N + 31) / 32;
+    const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
+    for (int64_t gtile = (int64_t)blockIdx.x * waves_per_block + wave; gtile < n_tiles;
+         gtile += (int64_t)gridDim.x * waves_per_block) {
         // The weights in LDS and the ring offsets are invariant across tiles, so LICM would hoist hundreds of
         // LDS reads / offsets out of this loop and spill them; an opaque memory clobber per tile stops that.
         asm volatile("" ::: "memory");
+        const int64_t chunk = a.n_chunks > 1 ? gtile / tiles_per_chunk : 0;  // wave-uniform
+        const int64_t tile = gtile - chunk * tiles_per_chunk;
+        const float* __restrict__ winc = a.win + chunk * (int64_t)K1 * a.N;
+        const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
         const int64_t e = tile * 32 + col;
         const bool valid = e < a.N;
         f32x16 acc1[NT];
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                 if (sl1 >= TW) sl1 -= TW;
                 const uint32_t r0 = (uint32_t)(sl0 * 15 + k0 % 15);
                 const uint32_t r1 = k1 < 15 * TW ? (uint32_t)(sl1 * 15 + k1 % 15) : r0;
-                float x = a.win[(hsel ? r1 : r0) * N32 + e32];
+                float x = winc[(hsel ? r1 : r0) * N32 + e32];
                 if (k1 >= 15 * TW) x = hsel ? 0.f : x;
                 xs[s] = x;
             }
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                 if (valid && k < K1) {
                     int slice = a.head + k / 15;
                     if (slice >= a.T) slice -= a.T;
-                    x = a.win[(int64_t)(slice * 15 + k % 15) * a.N + e];
+                    x = winc[(int64_t)(slice * 15 + k % 15) * a.N + e];
                     if (a.obs_store) a.obs_store[(int64_t)k * a.N + e] = x;
                 }
 #pragma unroll
@@ -213,8 +219,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
             float v = acc3[o];  // output row o = acc_row(o, 0): held by the lower lane half
             if (a.final_tanh) v = tanhf(v);  // the 4 outputs keep the exact tanh
             if (valid && half == 0 && o < a.n_out) {
-                if (a.out_f64) ((double*)a.out)[(int64_t)o * a.N + e] = (double)v;
-                else ((float*)a.out)[(int64_t)o * a.N + e] = v;
+                if (a.out_f64) ((double*)a.out)[out_off + (int64_t)o * a.N + e] = (double)v;
+                else ((float*)a.out)[out_off + (int64_t)o * a.N + e] = v;
             }
         }
     }
@@ -230,7 +236,7 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
     if (TW && (int64_t)15 * TW * a.N >= ((int64_t)1 << 31))
         return fail(QENV_ERR_ARG, "qenv_mlp_forward: 15*T*n_envs must stay below 2^31 (32-bit ring offsets)");
-    const int64_t n_tiles = (a.N + 31) / 32;
+    const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
     const int wpb = BLOCK / 64;
     int64_t blocks = (n_tiles + wpb - 1) / wpb;
     if (blocks > 256) blocks = 256;  // one resident workgroup per CU; waves grid-stride over env tiles
@@ -820,6 +826,7 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     a.out_f64 = q->cfg.dtype == QENV_F64;
     a.obs_store = obs_store;
+    a.n_chunks = 1;
     const bool t5 = q->cfg.T == 5;  // the reference's window (ppo.py:60, T = 5): fully unrolled variant
     switch (hidden) {
         case 16: return t5 ? launch_mlp<16, 5, 512, true>(a, 5, q->stream) : launch_mlp<16, 0, 512, true>(a, q->cfg.T, q->stream);
@@ -837,6 +844,19 @@ int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, in
     if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_dense_tail: null argument");
     if (n <= 0 || n_chunks < 1 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_dense_tail: bad sizes");
     if ((int64_t)k_in * n >= ((int64_t)1 << 31)) return fail(QENV_ERR_ARG, "qenv_dense_tail: K*n must stay below 2^31");
+    if (k_in == 75) {  // the controller's 75-float observation (T = 5): W1 fits the LDS whole -> the k_mlp kernel,
+        MlpArgs m;     // reading each chunk as a window ring with head 0 (row r of a chunk = window element r)
+        m.win = x; m.N = n; m.T = 5; m.head = 0; m.n_out = n_out; m.final_tanh = final_tanh;
+        m.W1 = W1; m.b1 = b1; m.W2 = W2; m.b2 = b2; m.W3 = W3; m.b3 = b3; m.out = out; m.out_f64 = 0;
+        m.obs_store = nullptr; m.n_chunks = n_chunks;
+        switch (hidden) {
+            case 16: return launch_mlp<16, 5, 512, true>(m, 5, (hipStream_t)stream);
+            case 32: return launch_mlp<32, 5, 512, true>(m, 5, (hipStream_t)stream);
+            case 64: return launch_mlp<64, 5, 512, true>(m, 5, (hipStream_t)stream);
+            case 128: return launch_mlp<128, 5, 512, true>(m, 5, (hipStream_t)stream);
+            default: return fail(QENV_ERR_ARG, "qenv_dense_tail: hidden must be 16, 32, 64 or 128");
+        }
+    }
     DenseArgs a;
     a.x = x; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh; a.n_chunks = n_chunks;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
