@@ -353,6 +353,9 @@ def main():
                 extras[f"{integ}:{launch}"] = n_global * args.steps / s
             del e2
         out["extras_env_steps_per_s"] = extras
+        # the same operating points as a fraction of the 8 TB/s HBM peak on the algorithmic bytes per env step;
+        # BASELINE.json words config 2 as "RK4 dynamics only": that operating point is extras["rk4:fused"]
+        out["extras_hbm_frac"] = {k: round(v * bytes_per_step * esz / 1e9 / HBM_PEAK_GBPS, 4) for k, v in extras.items()}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.integrator, args.cpu_seconds)
