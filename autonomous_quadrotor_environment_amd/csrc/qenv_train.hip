@@ -36,10 +36,11 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
     const int K1 = a.K, K1P = (K1 + 1) & ~1;
     float* W1t = lds;                        // [K1P][HP]
     float* W2t = W1t + (size_t)K1P * HP;     // [HP][HP+1]: W2t[k*LD2 + h] = W2[h][k]
-    float* W3t = W2t + (size_t)HP * LD2;     // [HP][4]
-    float* b1s = W3t + 4 * HP;
+    float* W3t = W2t + (size_t)HP * LD2;     // [HP][32]: W3t[h*32 + o] = W3[o][h], output rows o >= n_out zero
+    float* W3r = W3t + 32 * HP;              // [4][HP]:  W3r[o*HP + h] = W3[o][h] (the transposed product's A operand)
+    float* b1s = W3r + 4 * HP;
     float* b2s = b1s + HP;
-    float* b3s = b2s + HP;
+    float* b3s = b2s + HP;                   // [32]
     for (int idx = threadIdx.x; idx < K1P * HP; idx += BLOCK) {
         const int k = idx / HP, h = idx % HP;
         W1t[idx] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
@@ -48,12 +49,16 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
         const int k = idx / HP, h = idx % HP;
         W2t[k * LD2 + h] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
     }
-    for (int idx = threadIdx.x; idx < 4 * HP; idx += BLOCK) {
-        const int h = idx / 4, o = idx % 4;
+    for (int idx = threadIdx.x; idx < 32 * HP; idx += BLOCK) {
+        const int h = idx / 32, o = idx % 32;
         W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
     }
+    for (int idx = threadIdx.x; idx < 4 * HP; idx += BLOCK) {
+        const int o = idx / HP, h = idx % HP;
+        W3r[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
+    }
     for (int h = threadIdx.x; h < HP; h += BLOCK) { b1s[h] = h < H ? a.b1[h] : 0.f; b2s[h] = h < H ? a.b2[h] : 0.f; }
-    if (threadIdx.x < 4) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    if (threadIdx.x < 32) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
@@ -94,8 +99,10 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) h1[t][j] = fast_tanh(h1[t][j]);
-        // ---- layer 2 (+ layer-3 partial sums)
-        float o3[4] = {0.f, 0.f, 0.f, 0.f};
+        // ---- layer 2, and layer 3 on the MFMA as one zero-padded 32-row tile (see k_mlp)
+        f32x16 acc3;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc3[j] = b3s[acc_row(j, half)];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -108,19 +115,20 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
                     if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
+            for (int j = 0; j < 16; ++j) h2[t][j] = fast_tanh(h2[t][j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
-                h2[t][j] = fast_tanh(h2[t][j]);
-                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * (32 * t + acc_row(j, half))]);
-                o3[0] = fmaf(w3.x, h2[t][j], o3[0]); o3[1] = fmaf(w3.y, h2[t][j], o3[1]);
-                o3[2] = fmaf(w3.z, h2[t][j], o3[2]); o3[3] = fmaf(w3.w, h2[t][j], o3[3]);
-                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(W3t[(32 * t + acc_row(j, half)) * 32 + col], h2[t][j], acc3, 0, 0, 0);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- output and its pre-activation gradient (both lane halves hold the same 4 numbers)
+        // ---- output and its pre-activation gradient (made available to both lane halves)
         float dz3[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            float v = o3[o] + __shfl_xor(o3[o], 32) + b3s[o];
+            float v = half == 0 ? acc3[o] : 0.f;   // output row o lives in register o of the lower lane half
+            v += __shfl_xor(v, 32);
             if (a.final_tanh) v = tanhf(v);
             const float sd = o < a.n_out ? (a.seed + (size_t)c * a.n_out * a.N)[(uint32_t)o * N32 + ec] : 0.f;
             dz3[o] = a.final_tanh ? sd * (1.f - v * v) : sd;
@@ -132,7 +140,14 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
         float* const dz2c = a.dz2 + (size_t)c * H * a.N;
         float* const dz1c = a.dz1 + (size_t)c * H * a.N;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            // dH2 tile = W3^T dz3: A[i = h][k = o] = W3[o][h], B[k = o][env] = dz3[o]; k-step s pairs o = 2s | 2s+1
+            f32x16 g;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) g[j] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                g = __builtin_amdgcn_mfma_f32_32x32x2f32(W3r[(2 * s2 + half) * HP + 32 * t + col], half ? dz3[2 * s2 + 1] : dz3[2 * s2], g, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int h = 32 * t + acc_row(j, half);
@@ -140,12 +155,11 @@ __global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
                     h1c[(uint32_t)h * N32 + ec] = h1[t][j];
                     h2c[(uint32_t)h * N32 + ec] = h2[t][j];
                 }
-                const float4 w3 = *reinterpret_cast<const float4*>(&W3t[4 * h]);
-                const float g = w3.x * dz3[0] + w3.y * dz3[1] + w3.z * dz3[2] + w3.w * dz3[3];
-                h2[t][j] = g * (1.f - h2[t][j] * h2[t][j]);
+                h2[t][j] = g[j] * (1.f - h2[t][j] * h2[t][j]);
                 if (valid && h < H) dz2c[(uint32_t)h * N32 + ec] = h2[t][j];
-                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- dH1 = W2^T dZ2 on the MFMA pipe, one output tile at a time; dZ1 = dH1 (1 - H1^2)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -286,7 +300,7 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
     a.obs = obs; a.seed = seed; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
     a.h1 = h1; a.h2 = h2; a.dz2 = dz2; a.dz1 = dz1; a.dz3 = dz3;
     const int HP = hidden < 32 ? 32 : hidden, K1P = (k_in + 1) & ~1;
-    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)HP * (HP + 1) + 4 * HP + 2 * HP + 4);
+    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)HP * (HP + 1) + 32 * HP + 4 * HP + 2 * HP + 32);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_backward: weights do not fit the 160 KiB LDS");
     const int64_t n_tiles = ((n_envs + 31) / 32) * n_chunks;
     const int wpb = hidden >= 128 ? 4 : 8;
