@@ -52,8 +52,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2000)
-    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--steps", type=int, default=20000)
+    p.add_argument("--warmup", type=int, default=2000)
     p.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     p.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the workload's own size)")
     p.add_argument("--integrator", default="rk45", choices=["rk45", "dp5", "rk4"])
