@@ -212,33 +212,53 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
     float rs = 0.f;  // thread r < M accumulates row r's sum
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Every thread carries its share of the NEXT 64-sample tile in registers: the global loads are issued right after
+    // the current tile has been copied to LDS and land while its MFMAs run (the staging latency used to be exposed
+    // between two barriers).  PER = elements per thread and tile.
+    constexpr int PER = (MT + NTN) * 32 * 64 / 256;
+    float pre[PER];
+    auto fetch = [&](int64_t tile) {
         const int64_t c = tile / tiles_per_chunk, e0 = (tile % tiles_per_chunk) * 64;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < MT * 32 * 64; idx += 256) {
-            const int r = idx >> 6, sidx = idx & 63;
-            As[r * LD + sidx] = (r < a.M && e0 + sidx < a.N) ? a.A[((size_t)c * a.M + r) * a.N + e0 + sidx] : 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = threadIdx.x + 256 * i, r = idx >> 6, sidx = idx & 63;  // rows 0..MT*32-1 = A, the rest = B
+            const bool inb = e0 + sidx < a.N;
+            if (r < MT * 32) pre[i] = (r < a.M && inb) ? a.A[((size_t)c * a.M + r) * a.N + e0 + sidx] : 0.f;
+            else pre[i] = ((r - MT * 32) < a.Nn && inb) ? a.B[((size_t)c * a.Nn + (r - MT * 32)) * a.N + e0 + sidx] : 0.f;
         }
-        for (int idx = threadIdx.x; idx < NTN * 32 * 64; idx += 256) {
-            const int r = idx >> 6, sidx = idx & 63;
-            Bs[r * LD + sidx] = (r < a.Nn && e0 + sidx < a.N) ? a.B[((size_t)c * a.Nn + r) * a.N + e0 + sidx] : 0.f;
+    };
+    // the tiles a wave owns are consecutive; when they all sit in one row of output tiles the A operand of a k-step is
+    // read once for all of them (5 LDS reads per 4 MFMAs instead of 8)
+    constexpr bool SAME_A = (NTN % TPW) == 0;
+    const int tid0 = wave * TPW;
+    if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();  // every wave is done reading the previous tile
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = threadIdx.x + 256 * i, r = idx >> 6, sidx = idx & 63;
+            lds[r * LD + sidx] = pre[i];  // As and Bs are contiguous: row r of the combined [ (MT+NTN)*32 ][65] image
         }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
         if (a.rowsum && (int)threadIdx.x < a.M) {
             float sacc = 0.f;
 #pragma unroll 8
             for (int sidx = 0; sidx < 64; ++sidx) sacc += As[threadIdx.x * LD + sidx];
             rs += sacc;
         }
+#pragma unroll 4
+        for (int ks = 0; ks < 32; ++ks) {
+            const int sidx = 2 * ks + half;
+            float a0 = 0.f;
+            if (SAME_A) a0 = As[(32 * (tid0 / NTN) + col) * LD + sidx];
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int tid = wave * TPW + q;
-            if (tid < MT * NTN) {
-                const int tm = tid / NTN, tn = tid % NTN;
-#pragma unroll 8
-                for (int ks = 0; ks < 32; ++ks) {
-                    const int sidx = 2 * ks + half;
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(32 * tm + col) * LD + sidx], Bs[(32 * tn + col) * LD + sidx], acc[q], 0, 0, 0);
+            for (int q = 0; q < TPW; ++q) {
+                const int tid = tid0 + q;
+                if (tid < MT * NTN) {
+                    const int tm = tid / NTN, tn = tid % NTN;
+                    const float av = SAME_A ? a0 : As[(32 * tm + col) * LD + sidx];
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[(32 * tn + col) * LD + sidx], acc[q], 0, 0, 0);
                 }
             }
         }
