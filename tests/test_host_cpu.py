@@ -46,6 +46,15 @@ def test_argument_validation_without_a_device(built):
     assert b"null" in L.lib.qenv_last_error()
     assert L.lib.qenv_step(None, None, None, None, None, None, 0) == -1
     assert L.lib.qenv_gae(0, 0, 10, None, None, None, None, None, None, None) == -1
+    # the entry points of the section-8(f) rows refuse a null handle / null operands the same way, before any HIP call
+    assert L.lib.qenv_set_robust(None, 1) == -1 and b"qenv_set_robust" in L.lib.qenv_last_error()
+    assert L.lib.qenv_robust_params(None, None, 0, 0, None) == -1
+    assert L.lib.qenv_robust_gusts(None, None, 1, 1, 0, 0) == -1
+    assert L.lib.qenv_outer_velpid(None, None, 0) == -1 and L.lib.qenv_outer_pospi(None, None, 0.0, 0.0, 0.0) == -1
+    assert L.lib.qenv_outer_reset(None, None) == -1
+    assert L.lib.qenv_sensor_read(None, None, None, 0, 0, 0, 1, None) == -1
+    assert L.lib.qenv_dense_tail_chunks(64, 0, 75, 128, 4, 1, *([None] * 8), None) == -1
+    assert L.lib.qenv_mlp_backward(0, 1, 75, 128, 4, 1, *([None] * 13), None) == -1
     with pytest.raises(L.QenvError):
         L.check(L.lib.qenv_destroy(None), "qenv_destroy")
 
