@@ -65,6 +65,7 @@ SYMBOLS = {
     "qenv_dense_tail_chunks": (_i, [_i64, C.c_int32, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
+    "qenv_reset_sampled": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i]),
     "qenv_outer_velpid": (_i, [_vp, _vp, C.c_int32]),
     "qenv_outer_pospi": (_i, [_vp, _vp, C.c_double, C.c_double, C.c_double]),
     "qenv_outer_reset": (_i, [_vp, _vp]),

@@ -157,6 +157,39 @@ __device__ __forceinline__ void philox_normal2(uint32_t a, uint32_t b, float& z0
     z0 = r * cs; z1 = r * sn;
 }
 
+// Random branch of quad.reset (quadrotor_env.py:440-445) from Philox streams keyed by (seed; global env g, episode):
+// Euler angles U(-.5,.5) -> quaternion, position / velocity / body rate N(0,2) clipped to +-2.5 / +-5 / [-15, 7.5].
+// One definition for qenv_sample_init_states (qenv_ppo.hip) and the fused masked reset (qenv_env.hip).
+__device__ __forceinline__ void sample_init_state(uint64_t seed, uint64_t episode, uint64_t g, float x[13]) {
+    float u[4], z[12];
+    for (int blk = 0; blk < 4; ++blk) {
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)episode, ((uint32_t)(episode >> 32) & 0x0FFFFFFFu) | ((uint32_t)blk << 28)};
+        philox_core(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x1417u);
+        if (blk == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = philox_u01(c[k]);
+        } else {
+            philox_normal2(c[0], c[1], z[4 * (blk - 1)], z[4 * (blk - 1) + 1]);
+            philox_normal2(c[2], c[3], z[4 * (blk - 1) + 2], z[4 * (blk - 1) + 3]);
+        }
+    }
+    const float phi = u[0] - 0.5f, theta = u[1] - 0.5f, psi = u[2] - 0.5f;
+    float sp, cp, st_, ct, ss, cs;
+    sincosf(0.5f * phi, &sp, &cp); sincosf(0.5f * theta, &st_, &ct); sincosf(0.5f * psi, &ss, &cs);
+    const float q[4] = {cp * ct * cs + sp * st_ * ss, sp * ct * cs - cp * st_ * ss, cp * st_ * cs + sp * ct * ss,
+                        cp * ct * ss - sp * st_ * cs};
+    const float inv = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    auto clip = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        x[2 * k] = clip(2.0f * z[k], -2.5f, 2.5f);          // position
+        x[2 * k + 1] = clip(2.0f * z[3 + k], -5.0f, 5.0f);  // velocity
+        x[10 + k] = clip(2.0f * z[6 + k], -15.0f, 7.5f);    // body rates (sic: asymmetric, :445)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[6 + k] = q[k] * inv;
+}
+
 // One gust triple ~ N(0, [5,5,2]) (gust_std, :93): draw k of redraw epoch `epoch`.  Kept out of line on purpose: it
 // is needed only in the steps with i % 500 == 1, and inlining Philox + Box-Muller (logf, sincosf) into each of the
 // integrator's ~20 RHS call sites bloats the robust kernels into SGPR/VGPR spilling.

@@ -469,37 +469,54 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
     }
 }
 
-// Compaction of a reset mask: idx[0..count) = the envs with mask != 0 (order across waves is arbitrary, which is
-// harmless: envs are independent).  One ballot + one atomic per wave.
-__global__ __launch_bounds__(256) void k_compact_mask(const uint8_t* mask, int64_t N, int32_t* idx, int32_t* count) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool on = e < N && mask[e] != 0;
-    const unsigned long long b = __ballot(on);
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && b) base = atomicAdd(count, __popcll(b));
-    base = __shfl(base, 0);
-    if (on) idx[base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)e;
-}
-
-// quad.reset front half (quadrotor_env.py:428-445): load initial states, clear counters.
-template <typename T>
-__global__ __launch_bounds__(256) void k_reset(T* ws, int32_t* wsi, int64_t N, const T* init, const uint8_t* mask) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    if (mask && mask[e] == 0) return;
+// quad.reset front half (quadrotor_env.py:428-445): load initial states, clear counters -- and, for a masked
+// reset, everything else the reset needs, in the same launch: the initial states can be drawn here (Philox, the
+// qenv_sample_init_states streams) instead of read, and the compacted list of reset envs that the warm-up rollout
+// walks is built with one atomic per 1024-thread block (LDS prefix over the 16 wave ballots).  The list length lives
+// in one of two ping-pong counters: this launch fills `count` and zeroes `count_next` for the next masked reset (the
+// kernel that read it has finished: same stream), so no memset launch is needed.  In config 5 this chain was
+// memset + k_sample_init + k_reset + k_compact_mask = 30 us of a 191 us step.
+struct ResetSample { uint64_t seed, episode; int64_t env_offset; int32_t on; };
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_reset(T* ws, int32_t* wsi, int64_t N, const T* init, const uint8_t* mask,
+                                                 ResetSample smp, int32_t* idx, int32_t* count, int32_t* count_next) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool on = e < N && (!mask || mask[e] != 0);
+    if (idx) {  // compaction (uniform branch: every thread of the block takes part in the barriers)
+        __shared__ int32_t wcnt[BLOCK / 64], wbase[BLOCK / 64];
+        const unsigned long long b = __ballot(on);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) wcnt[wv] = __popcll(b);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) { wbase[w] = tot; tot += wcnt[w]; }
+            const int base = tot ? atomicAdd(count, tot) : 0;
+            for (int w = 0; w < BLOCK / 64; ++w) wbase[w] += base;
+            if (blockIdx.x == 0) *count_next = 0;
+        }
+        __syncthreads();
+        if (on) idx[wbase[wv] + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)e;
+    }
+    if (!on) return;
     using m = Mth<T>;
     if (mask) {  // an episode ends here: bank its return before the counters are cleared
         st(ws, ROW_LAST_RETURN, N, e, ld(ws, ROW_EP_RETURN, N, e));
         wsi[IROW_EPISODES * N + e] += 1;
     }
-    T q[4];
+    T x[13];
+    if (smp.on) {
+        float xf[13];
+        sample_init_state(smp.seed, smp.episode, (uint64_t)(smp.env_offset + e), xf);
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        const T v = init[(int64_t)k * N + e];
-        st(ws, ROW_STATE + k, N, e, v);
-        if (k >= 6 && k < 10) q[k - 6] = v;
+        for (int k = 0; k < 13; ++k) x[k] = (T)xf[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) x[k] = init[(int64_t)k * N + e];
     }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) st(ws, ROW_STATE + k, N, e, x[k]);
+    const T* q = x + 6;
     // self.ang = quat_euler(q) (:438); only the opt variant reads it back (prev_ang = ang)
     st(ws, ROW_ANG + 0, N, e, m::atan2(T(2) * (q[0] * q[1] + q[2] * q[3]), T(1) - T(2) * (q[1] * q[1] + q[2] * q[2])));
     st(ws, ROW_ANG + 1, N, e, m::asin(T(2) * (q[0] * q[2] - q[3] * q[1])));
@@ -727,7 +744,7 @@ template <typename T, typename S> static int do_step(qenv_s* q, const void* acti
     a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N;
     a.actions = (const S*)actions; a.mask = mask;
     a.idx = nullptr; a.count = nullptr;
-    if (mask && q->compact_valid) { a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N; }
+    if (mask && q->compact_valid) { a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N + q->count_used; }
     a.out_obs = (S*)out_obs; a.out_reward = (S*)out_reward; a.out_done = out_done; a.mode = flags;
     a.out_mask = (S*)out_mask;
     a.win = win_slot >= 0 ? q->window : nullptr;
@@ -803,7 +820,7 @@ template <typename T, typename S> static int do_rollout(qenv_s* q, int controlle
     a.target_table = (const S*)target_table;
     a.idx = nullptr; a.count = nullptr; a.win = nullptr; a.win_head = 0; a.win_T = q->cfg.T;
     if (q->compact_valid) {  // called from a masked qenv_reset: warm-up of the reset envs only
-        a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N;
+        a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N + q->count_used;
         if (q->warmup_push) { a.win = q->window; a.win_head = q->win_head; }
     }
     a.cfg = make_cfg<T>(q);
@@ -829,17 +846,25 @@ template <typename T, typename S> static int do_rollout(qenv_s* q, int controlle
 }
 
 template <typename T, typename S> static int do_reset(qenv_s* q, const void* init, const uint8_t* mask, void* out_states,
-                                                      void* out_actions, int push_window) {
+                                                      void* out_actions, int push_window, const ResetSample* sample = nullptr) {
     const dim3 g = grid_for(q->N), b(256);
-    hipLaunchKernelGGL((k_reset<S>), g, b, 0, q->stream, (S*)q->ws, q->wsi, q->N, (const S*)init, mask);
-    int rc = check_launch("k_reset");
+    ResetSample smp{0, 0, 0, 0};
+    if (sample) smp = *sample;
+    int rc;
     q->compact_valid = 0;
-    if (mask && rc == 0) {  // the T warm-up steps touch only the reset envs: run them on a compacted index list
-        hipError_t he = hipMemsetAsync(q->wsi + IROW_COUNT * q->N, 0, sizeof(int32_t), q->stream);
-        if (he != hipSuccess) return fail_hip(he, "hipMemsetAsync(count)");
-        hipLaunchKernelGGL(k_compact_mask, g, b, 0, q->stream, mask, q->N, q->wsi + IROW_IDX * q->N, q->wsi + IROW_COUNT * q->N);
-        rc = check_launch("k_compact_mask");
+    if (mask) {  // the T warm-up steps touch only the reset envs: they run on the compacted index list built right here
+        int32_t* counters = q->wsi + IROW_COUNT * q->N;  // [0], [1]: ping-pong list lengths (see k_reset)
+        const int cur = q->count_cur;
+        hipLaunchKernelGGL((k_reset<S, 1024>), dim3((unsigned)((q->N + 1023) / 1024)), dim3(1024), 0, q->stream, (S*)q->ws, q->wsi,
+                           q->N, (const S*)init, mask, smp, q->wsi + IROW_IDX * q->N, counters + cur, counters + (cur ^ 1));
+        rc = check_launch("k_reset(masked)");
         q->compact_valid = 1;
+        q->count_used = cur;
+        q->count_cur = cur ^ 1;
+    } else {
+        hipLaunchKernelGGL((k_reset<S, 256>), g, b, 0, q->stream, (S*)q->ws, q->wsi, q->N, (const S*)init, mask, smp,
+                           (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+        rc = check_launch("k_reset");
     }
     const Cfg<S> c = make_cfg<S>(q);
     if (mask && rc == 0 && !out_states && !out_actions) {
@@ -913,6 +938,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->warmup_push = 0;
     q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : -1;  // -1: automatic (see launch_rollout)
     q->robust = 0;
+    q->count_cur = 0; q->count_used = 0;
     q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
@@ -1028,6 +1054,15 @@ int qenv_reset(qenv_t q, const void* init_states, const uint8_t* mask, void* out
         return q->cfg.compute == QENV_COMPUTE_F32 ? do_reset<float, double>(q, init_states, mask, out_states, out_actions, push_window)
                                                   : do_reset<double, double>(q, init_states, mask, out_states, out_actions, push_window);
     return do_reset<float, float>(q, init_states, mask, out_states, out_actions, push_window);
+}
+
+int qenv_reset_sampled(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset, const uint8_t* mask, int push_window) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_reset_sampled: null handle");
+    const ResetSample smp{seed, episode, env_offset, 1};
+    if (q->cfg.dtype == QENV_F64)
+        return q->cfg.compute == QENV_COMPUTE_F32 ? do_reset<float, double>(q, nullptr, mask, nullptr, nullptr, push_window, &smp)
+                                                  : do_reset<double, double>(q, nullptr, mask, nullptr, nullptr, push_window, &smp);
+    return do_reset<float, float>(q, nullptr, mask, nullptr, nullptr, push_window, &smp);
 }
 
 int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, uint8_t* out_done, void* out_mask,

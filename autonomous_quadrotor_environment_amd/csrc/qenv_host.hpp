@@ -84,6 +84,7 @@ struct qenv_s {
     int32_t win_head;  // ring slot the next push writes
     int32_t warmup_push;    // the masked warm-up in progress also refills the observation ring
     int32_t compact_valid;  // the IDX/COUNT rows hold the compaction of the mask of the reset in progress
+    int32_t count_cur, count_used;  // ping-pong list-length counters: the one the next masked reset fills / the one in use
     int32_t packed;    // 1/0: force / forbid the two-envs-per-lane packed-fp32 rollout kernels; -1: automatic
     int32_t ang_ok;    // 1: no dynamics-only step since the last unmasked full step (see euler_update)
     hipStream_t stream;

@@ -417,34 +417,10 @@ __global__ __launch_bounds__(256) void k_sample_init(int64_t N, uint64_t seed, u
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= N) return;
     if (mask && mask[e] == 0) return;
-    const uint64_t g = (uint64_t)(env_offset + e);
-    float u[4], z[12];
-    for (int blk = 0; blk < 4; ++blk) {
-        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)episode, ((uint32_t)(episode >> 32) & 0x0FFFFFFFu) | ((uint32_t)blk << 28)};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x1417u);
-        if (blk == 0) {
+    float x[13];
+    sample_init_state(seed, episode, (uint64_t)(env_offset + e), x);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) u[k] = u01(c[k]);
-        } else {
-            box_muller(c[0], c[1], z[4 * (blk - 1)], z[4 * (blk - 1) + 1]);
-            box_muller(c[2], c[3], z[4 * (blk - 1) + 2], z[4 * (blk - 1) + 3]);
-        }
-    }
-    const float phi = u[0] - 0.5f, theta = u[1] - 0.5f, psi = u[2] - 0.5f;
-    float sp, cp, st_, ct, ss, cs;
-    sincosf(0.5f * phi, &sp, &cp); sincosf(0.5f * theta, &st_, &ct); sincosf(0.5f * psi, &ss, &cs);
-    float q[4] = {cp * ct * cs + sp * st_ * ss, sp * ct * cs - cp * st_ * ss, cp * st_ * cs + sp * ct * ss,
-                  cp * ct * ss - sp * st_ * cs};
-    const float inv = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    auto clip = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        out[(int64_t)(2 * k) * N + e] = (T)clip(2.0f * z[k], -2.5f, 2.5f);          // position
-        out[(int64_t)(2 * k + 1) * N + e] = (T)clip(2.0f * z[3 + k], -5.0f, 5.0f);  // velocity
-        out[(int64_t)(10 + k) * N + e] = (T)clip(2.0f * z[6 + k], -15.0f, 7.5f);    // body rates (sic: asymmetric, :445)
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[(int64_t)(6 + k) * N + e] = (T)(q[k] * inv);
+    for (int k = 0; k < 13; ++k) out[(int64_t)k * N + e] = (T)x[k];
 }
 
 // ---- sensor model, quadrotor_env.py:579-724 ------------------------------------------------------------

@@ -292,6 +292,7 @@ class PolicyRollout:
         assert env.direct_control_flag, "the PPO controller commands the four rotors (direct_control=1)"
         self.env, self.w, self.horizon = env, weights, int(horizon)
         self.auto_reset, self.seed, self.env_offset = bool(auto_reset), int(seed), int(env_offset)
+        self.keep_init = False  # True: auto-resets also leave the drawn initial states in `self.init`
         N, dev, dt, H = env.n_envs, env.device, env.dtype, self.horizon
         self.actions = torch.zeros(H, 4, N, device=dev, dtype=dt)
         self.logprobs = torch.zeros(H, 4, N, device=dev, dtype=dt)
@@ -331,10 +332,13 @@ class PolicyRollout:
         env.step(act, flags=L.STEP_NO_AUX, out=(None, self.rewards[t], self.done), out_mask=self.masks[t],
                  push_window=True)
         if self.auto_reset:  # worker loop: `while` episodes until the batch is full (ppo.py:232-262)
-            env.sample_init_states(self.seed, self.global_step + 1, self.env_offset, mask=self.done, out=self.init)
             if env.robust_control:
                 env.robust_params(None, self.seed, self.env_offset, mask=self.done)
-            env.reset(self.init, mask=self.done, return_history=False, push_window=True)
+            if self.keep_init:  # tests compare against a fresh twin reset to the same states
+                env.sample_init_states(self.seed, self.global_step + 1, self.env_offset, mask=self.done, out=self.init)
+                env.reset(self.init, mask=self.done, return_history=False, push_window=True)
+            else:  # one launch: states drawn inside the reset kernel from the same Philox streams
+                env.reset_sampled(self.seed, self.global_step + 1, self.env_offset, mask=self.done, push_window=True)
         self.t += 1
         self.global_step += 1
 

@@ -253,6 +253,13 @@ class BatchedQuad:
                                  int(bool(push_window))), "qenv_reset")
         return states, actions
 
+    def reset_sampled(self, seed, episode=0, env_offset=0, mask=None, push_window=False):
+        """Masked auto-reset with device-drawn initial states (sample_init_states + reset(mask) in one launch)."""
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._bind()
+        L.check(L.lib.qenv_reset_sampled(self._h, int(seed), int(episode), int(env_offset), L.ptr(m),
+                                         int(bool(push_window))), "qenv_reset_sampled")
+
     def step(self, action=None, flags=L.STEP_FULL, out=None, out_mask=None, push_window=False):
         """quad.step for all envs.  action [4, N] (or [N, 4]); None = zero_control.
         out: optional preallocated (obs [14, N] | None, reward [N] | None, done uint8 [N] | None);

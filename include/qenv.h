@@ -266,6 +266,13 @@ int qenv_sample_action(qenv_t q, const void *mean, double std, const void *noise
  * host replay for seed parity).  out [13][N]; only envs with mask != 0 are written (nullable). */
 int qenv_sample_init_states(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset,
                             const uint8_t *mask, void *out_states);
+/* qenv_sample_init_states + qenv_reset(mask) in one call and, for a masked reset, ONE launch before the warm-up
+ * rollout: the masked envs' initial states are drawn inside the reset kernel (the same Philox streams, nothing is
+ * written to a staging array), their episode return is banked and the list of reset envs is compacted there too.
+ * This is the auto-reset of the rollout worker loop (ppo.py:232-262, `while` episodes until the batch is full).
+ * mask nullable (all envs; then the T warm-up steps run as T step launches like qenv_reset). */
+int qenv_reset_sampled(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset, const uint8_t *mask,
+                       int push_window);
 
 /* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------
  * The reference hard-codes `self.robust_control = False` (:183) and a user flips the attribute; this is that

@@ -171,8 +171,9 @@ def test_auto_reset_keeps_rings_in_phase_and_banks_returns(aq):
             banked = env.last_return[done]
             assert torch.allclose(banked, (prev_ret + ro.rewards[k])[done], atol=1e-4)
             # fresh twin: same init states, reset with window push
+            # (the auto-reset draws the states inside the reset kernel; the separate sampler has the same streams)
             twin = aq.BatchedQuad(n, 0.01, 12, training=True, direct_control=1, T=T)
-            twin.reset(ro.init, push_window=True)
+            twin.reset(env.sample_init_states(5, k + 1), push_window=True)
             assert torch.equal(env.state[:, done], twin.state[:, done])
             assert torch.equal(env.i[done], twin.i[done]) and int(env.i[done].max()) == T
             # ring: env's slots are rotated by its head relative to the twin's (head 0)
