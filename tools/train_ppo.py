@@ -19,6 +19,7 @@ p.add_argument("--seed", type=int, default=1)
 p.add_argument("--integrator", default="rk45")
 p.add_argument("--robust", action="store_true", help="train under robust_control: a new perturbed plant per episode + gusts")
 p.add_argument("--eval-robust", action="store_true", help="evaluate on the perturbed plant as well (else nominal)")
+p.add_argument("--separate-reset", action="store_true", help="auto-reset through sample_init_states + reset(mask) instead of the fused launch")
 p.add_argument("--log", default="")
 a = p.parse_args()
 
@@ -27,6 +28,7 @@ w.std = 0.1
 env = aq.BatchedQuad(a.envs, 0.01, 1000, training=True, direct_control=1, T=5, integrator=a.integrator)
 env.robust_control = a.robust  # PolicyRollout then draws the episode parameters / gusts from Philox at every (re)start
 ro = aq.PolicyRollout(env, w, a.horizon, store_obs=True, auto_reset=True, seed=a.seed)
+ro.keep_init = a.separate_reset
 learner = aq.PpoLearner(w, lr=a.lr)
 ro.start()
 log = open(a.log, "w") if a.log else None
