@@ -816,6 +816,49 @@ def g20():
     save("g20_landing_baseline", **rec)
 
 
+def g21():
+    """PPO.update itself (environment/controller/ppo.py:143-209: get_advantages, K_epochs x {evaluate, clipped surrogate +
+    0.5 MSE - 0.006 entropy, Adam}) run by the reference's own classes.  ppo.py is a script (pool, training loop, file
+    writes at import), so `Memory` and `PPO` are taken out of it with ast and executed with the module globals they
+    close over; the memory is filled the way worker_f.work / the main loop do (:232-262, :371-385)."""
+    tree = ast.parse(open(os.path.join(REF, "environment/controller/ppo.py")).read())
+    ns = {"torch": torch, "nn": torch.nn, "np": np, "ActorCritic": ActorCritic, "device": torch.device("cpu"),
+          "network_size": 16, "FIXED_STD": True, "seed": "_golden_none"}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name in ("Memory", "PPO"):
+            exec(compile(ast.Module([node], []), "ppo." + node.name, "exec"), ns)
+    torch.manual_seed(21)
+    with quiet:
+        ppo = ns["PPO"](75, 4, 0.1, 5e-4, (0.9, 0.999), 0.99, 10, 0.2)
+    w0 = {k.replace(".", "_"): v.detach().clone().numpy() for k, v in ppo.policy.state_dict().items()}
+    rng = np.random.RandomState(121)
+    B = 96
+    worker_memory = ns["Memory"]()
+    obs = rng.normal(0, 0.5, (B, 75))
+    obs[:, 0:4] = np.clip(obs[:, 0:4], -1, 1)
+    for k in range(B):
+        ppo.select_action(obs[k], worker_memory)            # policy_old.act: appends state, action, logprob, value
+        worker_memory.rewards.append(float(rng.normal(0, 1)))
+        worker_memory.is_terminals.append(bool(k in (30, 61, 95)))
+    worker_memory.convert_memory()
+    memory = ns["Memory"]()
+    memory.states += worker_memory.states.tolist(); memory.logprobs += worker_memory.logprobs.tolist()
+    memory.rewards += worker_memory.rewards.tolist(); memory.is_terminals += worker_memory.is_terminals.tolist()
+    memory.values += worker_memory.values.tolist(); memory.actions += worker_memory.actions.tolist()
+    memory.values.append(torch.tensor([[0]]))
+    rec = dict(obs=np.array(memory.states)[:, 0], actions=np.array(memory.actions)[:, 0], logprobs=np.array(memory.logprobs)[:, 0],
+               values=np.array([float(np.asarray(v).ravel()[0]) for v in memory.values]), rewards=np.array(memory.rewards),
+               is_terminals=np.array(memory.is_terminals))
+    ret, adv = ppo.get_advantages(torch.Tensor(memory.values).type(torch.double), np.logical_not(memory.is_terminals),
+                                  np.array(memory.rewards))
+    rec["returns"], rec["adv"] = np.asarray(ret, dtype=float), np.asarray(adv, dtype=float)
+    ppo.update(memory)
+    w1 = {k.replace(".", "_"): v.detach().clone().numpy() for k, v in ppo.policy.state_dict().items()}
+    for k in w0:
+        rec["w0_" + k] = w0[k]; rec["w1_" + k] = w1[k]
+    save("g21_ppo_update", **rec)
+
+
 def g11():
     rng = np.random.RandomState(111)
     rows = []
@@ -844,6 +887,6 @@ def g11():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     for name in todo:
         globals()[name]()

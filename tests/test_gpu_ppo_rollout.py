@@ -350,3 +350,38 @@ def test_full_size_actor_in_loop_is_batch_position_independent_config4(aq):
     small, rs = run(n)
     assert torch.equal(rs.actions, rb.actions[:, :, :n]) and torch.equal(small.state, big.state[:, :n])
     assert float(rb.actions.abs().max()) <= 1.0 and bool(torch.isfinite(big.state).all())
+
+
+def test_ppo_update_against_the_reference_update(aq):
+    """PPO.update of the reference run by its own classes (g21: 96 collected samples, three episode ends, hidden 16,
+    K_epochs = 10, Adam lr 5e-4): GAE on the device reproduces its returns / normalised advantages, and ten epochs of
+    PpoLearner (fp32 kernels) land on the reference's fp64 weights.  Adam's first steps move every weight by ~lr
+    whatever the gradient's size, so a weight whose gradient is within fp32 noise of zero may differ by a few lr; the
+    bulk must agree to 1e-5."""
+    import types
+    g = golden("g21_ppo_update")
+    w = aq.ActorCriticWeights.from_state_dict({k[3:]: g[k] for k in g.files if k.startswith("w0_") and k != "w0_std"})
+    w.std = float(g["w0_std"])
+    B = g["obs"].shape[0]
+    dev = "cuda"
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, torch.float32)
+    values = f(g["values"]).reshape(B + 1, 1)
+    masks = f(1.0 - g["is_terminals"]).reshape(B, 1)
+    rewards = f(g["rewards"]).reshape(B, 1)
+    ret, adv = aq.gae(values, masks, rewards, ddof=0, group=False)
+    assert rel_err(_np(ret).ravel(), g["returns"], 1.0) < 2e-6
+    assert rel_err(_np(adv).ravel(), g["adv"], 1.0) < 2e-5
+    ro = types.SimpleNamespace(t=B, obs=f(g["obs"]).reshape(B, 75, 1), actions=f(g["actions"]).reshape(B, 4, 1),
+                               logprobs=f(g["logprobs"]).reshape(B, 4, 1))
+    learner = aq.PpoLearner(w, lr=5e-4, K_epochs=10, group=False)
+    learner.update(ro, ret, adv)
+    names = [f"{h}_{l}_{p}" for h in ("actor", "critic") for l in (0, 2, 4) for p in ("weight", "bias")]
+    got = np.concatenate([_np(t).ravel() for h in ("actor", "critic") for t in w.head(h)])
+    ref = np.concatenate([g["w1_" + n].ravel() for n in names])
+    start = np.concatenate([g["w0_" + n].ravel() for n in names])
+    d = np.abs(got - ref)
+    moved = np.abs(ref - start)
+    assert moved.max() > 4e-3                      # the update did move the weights by ~K lr
+    assert np.mean(d < 1e-5) > 0.97, np.mean(d < 1e-5)
+    assert d.max() < 2.5e-3, d.max()               # worst case: a near-zero gradient component flipping sign for some epochs
+    assert np.median(d) < 2e-6

@@ -415,3 +415,11 @@ def test_g20_landing_baseline(oracle, ep):
             break
         assert abs(r - g[pre + "reward"][k]) < 2e-3, k
     assert k + 1 == n and n_solved == int(g[pre + "n_solved"][0]) and r == g[pre + "reward"][-1]
+
+
+def test_g21_gae_of_the_reference_update(oracle):
+    """get_advantages as PPO.update calls it (ppo.py:162) on the collected memory of g21 (three episode ends)."""
+    g = golden("g21_ppo_update")
+    ret, adv = oracle.gae(g["values"], 1.0 - g["is_terminals"], g["rewards"], ddof=0)
+    # the reference carries the collected values through float32 torch tensors (Memory.convert_memory): fp32 resolution
+    assert rel_err(ret, g["returns"], 1.0) < 1e-6 and rel_err(adv, g["adv"], 1.0) < 1e-5
