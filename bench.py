@@ -272,22 +272,35 @@ def main():
             env.pid_reset()
         return env
 
-    if controller == "ppo_rollout":  # one call = one 128-step horizon + GAE + all-gather
-        chunk = args.chunk or (128 if args.steps % 128 == 0 and args.warmup % 128 == 0 else
-                               max(c for c in range(1, 129) if args.steps % c == 0 and args.warmup % c == 0))
-    else:
-        chunk = args.chunk or max(c for c in range(1, 251) if args.steps % c == 0 and (args.warmup % c == 0)
-                                  and (not ppo or c % 5 == 0 or args.no_graph))
-    if args.steps % chunk or args.warmup % chunk:
-        raise SystemExit("--chunk must divide --steps and --warmup")
+    # steps per call (fused launch / graph replay / rollout horizon): the largest divisor of the K timed steps, so the
+    # timed region is independent of W; the W warm-up steps run first through their own (same-kind) runner when W is not
+    # a multiple of it
+    def pick(total, cap, mult=1):
+        ok = [c for c in range(1, cap + 1) if total % c == 0 and c % mult == 0]
+        return max(ok) if ok else 0
+    cap = 128 if controller == "ppo_rollout" else 250
+    mult = 5 if (controller == "ppo_actor" and not args.no_graph) else 1  # a graph replay must bring the ring head back
+    chunk = args.chunk or pick(args.steps, cap, mult)
+    if not chunk:  # K has no multiple-of-5 divisor: eager launches instead of a graph replay
+        args.no_graph, mult = True, 1
+        chunk = pick(args.steps, cap)
+    if args.steps % chunk:
+        raise SystemExit("--chunk must divide --steps")
     env = build_env(args.integrator)
+
+    def runner(c):
+        if ppo:
+            return make_ppo_runner(env, controller, c, (not args.no_graph) and controller == "ppo_actor",
+                                   seed=4, env_offset=lo, n_global=n_global)
+        return make_runner(env, controller, flags, args.launch, c, not args.no_graph) + (None,)
     if ppo:
         args.launch = "step"
-        run, per_call, ro = make_ppo_runner(env, controller, chunk, (not args.no_graph) and controller == "ppo_actor",
-                                            seed=4, env_offset=lo, n_global=n_global)
-    else:
-        run, per_call = make_runner(env, controller, flags, args.launch, chunk, not args.no_graph)
-    time_region(run, per_call, args.warmup, world, dev)         # W untimed warm-up steps
+    run, per_call, ro = runner(chunk)
+    if args.warmup % chunk == 0:
+        time_region(run, per_call, args.warmup, world, dev)     # W untimed warm-up steps
+    elif args.warmup:
+        rw, pcw, _ = runner(pick(args.warmup, cap, mult) or pick(args.warmup, cap))
+        time_region(rw, pcw, args.warmup, world, dev)
     secs = time_region(run, per_call, args.steps, world, dev)   # exactly K timed steps
     value = n_global * args.steps / secs
     finite = bool(torch.isfinite(env.state).all())
@@ -335,7 +348,7 @@ def main():
         "dtype": {"f32": "f32", "f64": "f64", "mix": "f32 arithmetic on f64 state rows"}[args.dtype], "data": "synthetic",
         "config": {"workload": desc, "envs_per_gpu": hi - lo, "global_envs": n_global,
                    "integrator": args.integrator, "launch": args.launch, "controller": controller,
-                   "steps_per_graph_replay_or_launch": chunk, "hip_graph": (args.launch == "step" and not args.no_graph),
+                   "steps_per_graph_replay_or_launch": chunk, "hip_graph": (args.launch == "step" and not args.no_graph and controller != "ppo_rollout"),
                    "parallelism": f"env-sharded x{world}", "finite": finite},
         "roofline": roofline,
     }
