@@ -327,12 +327,12 @@ def main():
                 "kernel_us": k_us, "algorithmic_bytes_per_launch": algo_bytes,
                 "bytes_per_env_step": bytes_per_step * esz, "env_steps_per_launch": (hi - lo) * spl}
     if controller == "const" and args.launch == "fused" and args.integrator == "rk45" and args.dtype == "f32":
-        # what actually bounds this kernel: VALU issue.  1 460 instructions per env step and wave
-        # (ISA census of k_rollout<float,rk45,CONST>; config 2 takes one sub-step per env step), 4 issue cycles each,
+        # what actually bounds this kernel: VALU issue.  1 425 instructions per env step and wave
+        # (SQ_INSTS_VALU, profiles/r01_pmc_valu_headline.txt; the ISA census gives 1 460), 4 issue cycles each,
         # on 256 CUs x 4 SIMDs at the 2.4 GHz boost clock
         spw = (hi - lo) * spl / 64.0 / (k_us * 1e-6)   # wave-steps per second of this rank
-        roofline["valu"] = {"instructions_per_env_step_per_wave": 1460, "issue_cycles_per_instruction": 4,
-                            "simds": 1024, "clock_ghz": 2.4, "issue_frac": spw * 1460 * 4 / (1024 * 2.4e9)}
+        roofline["valu"] = {"instructions_per_env_step_per_wave": 1425, "issue_cycles_per_instruction": 4,
+                            "simds": 1024, "clock_ghz": 2.4, "issue_frac": spw * 1425 * 4 / (1024 * 2.4e9)}
     if ppo:  # the dominant kernel of the PPO workloads is the fp32-MFMA MLP forward
         heads = 2 if controller == "ppo_rollout" else 1
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
