@@ -638,18 +638,33 @@ __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* va
         const T gmma = T(0.99), lmbda = T(0.99);
         T gae = T(0);
         T v_next = values[(int64_t)n_steps * N + e];
-        for (int i = n_steps - 1; i >= 0; --i) {
-            const int64_t o = (int64_t)i * N + e;
-            const T v = values[o], mk = masks[o];
-            const T delta = rewards[o] + gmma * v_next * mk - v;
-            gae = delta + gmma * lmbda * mk * gae;
-            const T ret = gae + v;
-            returns[o] = ret;
-            const T ad = ret - v;
-            adv[o] = ad;
-            s1 += (double)ad;
-            s2 += (double)ad * (double)ad;
-            v_next = v;
+        // the recurrence is serial in time but its operands are not: 8 steps' worth of loads are issued back to back
+        // before the first one is consumed (a plain loop exposes one HBM round trip per step: 107 us for 128 steps)
+        constexpr int U = 8;
+        for (int i0 = n_steps - 1; i0 >= 0; i0 -= U) {
+            T v[U], mk[U], rw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 - u;
+                const int64_t o = (int64_t)(i >= 0 ? i : 0) * N + e;
+                v[u] = values[o]; mk[u] = masks[o]; rw[u] = rewards[o];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 - u;
+                if (i >= 0) {
+                    const int64_t o = (int64_t)i * N + e;
+                    const T delta = rw[u] + gmma * v_next * mk[u] - v[u];
+                    gae = delta + gmma * lmbda * mk[u] * gae;
+                    const T ret = gae + v[u];
+                    returns[o] = ret;
+                    const T ad = ret - v[u];
+                    adv[o] = ad;
+                    s1 += (double)ad;
+                    s2 += (double)ad * (double)ad;
+                    v_next = v[u];
+                }
+            }
         }
     }
     if (stats) {
