@@ -6,6 +6,12 @@ missing or a symbol cannot be bound, importing this module raises immediately.
 import ctypes as C
 import os
 
+# torch first: its wheel ships its own libamdhip64.so; libqenv.so must bind to THAT runtime instance (the one holding
+# the device context and the streams we are handed), which happens only if it is already loaded when CDLL resolves
+# libqenv.so's dependency.  Loaded the other way round, the process ends up with two HIP runtimes and every call
+# into libqenv.so fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 

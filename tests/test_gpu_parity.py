@@ -494,3 +494,18 @@ def test_auto_packed_rollout_is_bit_identical_at_size(aq, integrator):
         b.step(None)
     assert torch.equal(a.state, b.state) and torch.equal(a.episode_return, b.episode_return)
     assert torch.equal(a.ang_vel, b.ang_vel) and torch.equal(a.flags, b.flags)
+
+
+def test_package_imported_before_torch_still_finds_the_device():
+    """Regression: libqenv.so must bind to the HIP runtime torch ships (the one that owns the device context); a
+    process that imports this package first used to end up with two runtimes and 'no ROCm-capable device'."""
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    code = ("import autonomous_quadrotor_environment_amd as aq, numpy as np\\n"
+            "e = aq.BatchedQuad(64, 0.01, 100)\\n"
+            "e.reset(np.array([0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0])); e.step(None)\\n"
+            "print('ok', float(e.state.abs().max()))")
+    out = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-500:]
