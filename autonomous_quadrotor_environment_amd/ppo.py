@@ -17,6 +17,15 @@ from . import _lib as L
 from .quadrotor_env import BatchedQuad, quad
 
 
+def _stream(dev):
+    """The caller's current stream on `dev` as a C pointer; `dev` becomes the thread's current device (a kernel launched
+    into a stream of another device than the current one fails)."""
+    dev = torch.device(dev)
+    if dev.index is not None and torch.cuda.current_device() != dev.index:
+        torch.cuda.set_device(dev)
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
 class ActorCriticWeights:
     """float32 device copies of model.py's actor / critic Linear layers, torch layout
     ([out, in] row-major), read directly by the MFMA kernel."""
@@ -115,7 +124,7 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True):
     ret = torch.empty_like(rewards)
     adv = torch.empty_like(rewards)
     stats = torch.zeros(3, dtype=torch.float64, device=values.device)
-    stream = C.c_void_p(torch.cuda.current_stream(values.device).cuda_stream)
+    stream = _stream(values.device)
     L.check(L.lib.qenv_gae(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(ret), L.ptr(adv),
                            L.ptr(stats), stream), "qenv_gae")
     if not normalize:
@@ -136,7 +145,7 @@ def dense_tail(x, weights, final_tanh=True, out=None):
     assert W1.shape[1] == K and x.dtype == torch.float32
     x = x.contiguous()
     out = torch.empty(W3.shape[0], N, device=x.device, dtype=torch.float32) if out is None else out
-    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    stream = _stream(x.device)
     L.check(L.lib.qenv_dense_tail(N, K, W1.shape[0], W3.shape[0], int(bool(final_tanh)), L.ptr(x), L.ptr(W1), L.ptr(b1),
                                   L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), stream), "qenv_dense_tail")
     return out
@@ -154,7 +163,7 @@ def ppo_loss(mean, value, actions, old_logprob, adv, returns, std, eps_clip=0.2,
     sums = torch.zeros(4, dtype=torch.float64, device=mean.device)
     gm = torch.empty_like(mean) if with_grads else None
     gv = torch.empty_like(value) if with_grads else None
-    stream = C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream)
+    stream = _stream(mean.device)
     L.check(L.lib.qenv_ppo_loss(dt, B, L.ptr(mean), L.ptr(value), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
                                 L.ptr(returns), float(std), float(eps_clip), float(c_value), L.ptr(sums), L.ptr(gm),
                                 L.ptr(gv), stream), "qenv_ppo_loss")
@@ -207,7 +216,7 @@ class PpoLearner:
         dev, w = obs.device, self.w
         H = w.hidden
         b = self._buffers(H, n, N, dev)
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        stream = _stream(dev)
         f32 = lambda t: t.to(torch.float32).contiguous()
         obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
         # forward of both heads on the stored observations (the dense kernel takes feature-major chunks)
@@ -243,7 +252,7 @@ class PpoLearner:
         self.step += 1
         for (head, k), (g, m, v) in self._state.items():
             p = self.w.head(head)[k]
-            stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+            stream = _stream(p.device)
             L.check(L.lib.qenv_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), self.lr, self.betas[0],
                                          self.betas[1], self.eps, self.step, stream), "qenv_adam_step")
 
@@ -271,7 +280,7 @@ def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, an
     sh = torch.empty_like(rew)
     done = torch.empty(N, dtype=torch.uint8, device=pos.device)
     ns = torch.empty(N, dtype=torch.int32, device=pos.device)
-    stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+    stream = _stream(pos.device)
     L.check(L.lib.qenv_visual_reward(dt, N, int(total_steps), L.ptr(marker), L.ptr(pos), L.ptr(vel), L.ptr(control),
                                      L.ptr(last_shaping), L.ptr(step), L.ptr(ang), L.ptr(v_ang), L.ptr(rew), L.ptr(sh),
                                      L.ptr(done), L.ptr(ns), stream), "qenv_visual_reward")

@@ -122,6 +122,8 @@ class BatchedQuad:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BatchedQuad runs on the GPU only (device='cuda[:i]'); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.n_envs = int(n_envs)
         self.dtype = dtype
         self.t_step = t_step
@@ -163,6 +165,10 @@ class BatchedQuad:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _bind(self):
+        # the library launches on the caller's current stream of ITS device: make that device current for this thread
+        # (kernels launched into a stream of another device than the current one fail)
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
         L.check(L.lib.qenv_set_stream(self._h, self._stream()), "qenv_set_stream")
 
     def __del__(self):
