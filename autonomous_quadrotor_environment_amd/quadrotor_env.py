@@ -192,8 +192,8 @@ class BatchedQuad:
         """Accept [rows, N] (native) or [N, rows]; return a contiguous device tensor [rows, N]."""
         if x is None:
             return None
-        if isinstance(x, np.ndarray):
-            x = torch.from_numpy(np.ascontiguousarray(x))
+        if not isinstance(x, torch.Tensor):  # numpy arrays, lists, tuples
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
         x = x.to(device=self.device, dtype=self.dtype)
         if x.dim() == 1 and x.numel() == rows:
             x = x.view(rows, 1).expand(rows, self.n_envs)
