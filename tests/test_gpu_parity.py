@@ -509,3 +509,18 @@ def test_package_imported_before_torch_still_finds_the_device():
             "print('ok', float(e.state.abs().max()))")
     out = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-500:]
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """The binding stub of INTEGRATION.md section 3, executed verbatim (own CDLL handle, no package import)."""
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    start = md.index("```python\nimport ctypes as C, torch")
+    code = md[start + len("```python\n"):md.index("```", start + 10)]
+    # an exact hover under training=1 is "solved" at once: q0 stays 1, every env reports done with a finite reward
+    code += "\ntorch.cuda.synchronize(); assert float(obs[6].min()) > 0.99 and int(done.sum()) == 65536 and bool(torch.isfinite(rew).all()); print('stub ok')\n"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "stub ok" in out.stdout, (out.stdout[-300:], out.stderr[-800:])
