@@ -524,3 +524,19 @@ def test_integration_md_ctypes_stub_runs_as_written():
     code += "\ntorch.cuda.synchronize(); assert float(obs[6].min()) > 0.99 and int(done.sum()) == 65536 and bool(torch.isfinite(rew).all()); print('stub ok')\n"
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "stub ok" in out.stdout, (out.stdout[-300:], out.stderr[-800:])
+
+
+def test_c_host_drives_the_library_without_python(tmp_path):
+    """examples/host_rollout.c: hipMalloc'ed workspace, qenv_create / reset / rollout / field from plain C, linked
+    against the system HIP runtime -- the C-ABI carries no torch or Python dependency."""
+    import os
+    import subprocess
+    from .conftest import ROOT
+    libdir = os.path.join(ROOT, "autonomous_quadrotor_environment_amd")
+    exe = str(tmp_path / "host_rollout")
+    r = subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                        os.path.join(ROOT, "examples", "host_rollout.c"), "-L", libdir, "-lqenv", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        "-lm", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "finite=1" in r.stdout, (r.stdout, r.stderr[-500:])
