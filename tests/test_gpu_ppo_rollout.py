@@ -385,3 +385,26 @@ def test_ppo_update_against_the_reference_update(aq):
     assert np.mean(d < 1e-5) > 0.97, np.mean(d < 1e-5)
     assert d.max() < 2.5e-3, d.max()               # worst case: a near-zero gradient component flipping sign for some epochs
     assert np.median(d) < 2e-6
+
+
+@pytest.mark.parametrize("hidden", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("T,N", [(5, 4097), (5, 63), (3, 1000), (1, 1)])
+def test_mlp_forward_every_instantiation_vs_torch_fp64(aq, hidden, T, N):
+    """Every k_mlp instantiation (hidden 16..256; T = 5 takes the unrolled window path, other T the run-time one; ragged
+    and single-env batches; W2 streamed from L2 at hidden 256) against a torch fp64 MLP on the same window, actor
+    (tanh head) and critic, after the ring head has moved.  Tolerance 2e-6 abs: fp32 MFMA chains + the 1.2e-7 tanh."""
+    torch.manual_seed(hidden * 7 + T)
+    w = aq.ActorCriticWeights.random(hidden, 15 * T, 4, seed=hidden + T)
+    env = aq.BatchedQuad(N, 0.01, 1000, training=False, direct_control=1, T=T)
+    env.reset(aq.random_init_states(11, N).T.copy(), return_history=False, push_window=True)
+    for _ in range(T + 2):  # moves the ring head off slot 0
+        env.step(torch.randn(4, N, device="cuda").clamp(-1, 1), push_window=True)
+    obs = torch.empty(15 * T, N, device="cuda")
+    mean = env.mlp_forward(w, "actor", obs_store=obs)
+    val = env.mlp_forward(w, "critic")
+    act_net, cri_net = _torch_nets(w)
+    x = obs.t().double()
+    with torch.no_grad():
+        ref_m, ref_v = act_net(x).t(), cri_net(x).t()
+    assert float((mean.double() - ref_m).abs().max()) < 2e-6
+    assert float((val.double() - ref_v).abs().max()) < 5e-6 * max(1.0, float(ref_v.abs().max()))
