@@ -236,7 +236,7 @@ def _torch_nets(w, dtype=torch.float64):
     return net(w.actor, True), net(w.critic, False)
 
 
-@pytest.mark.parametrize("hidden", [16, 128])
+@pytest.mark.parametrize("hidden", [16, 32, 64, 128])
 def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden):
     """Backward pass (MFMA), weight/bias gradients (split-K GEMM) and the Adam step of PpoLearner against torch
     autograd + torch.optim.Adam on the reference's loss (ppo.py:185-203), fp64 torch as the yardstick."""
