@@ -256,14 +256,28 @@ class PpoLearner:
             L.check(L.lib.qenv_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), self.lr, self.betas[0],
                                          self.betas[1], self.eps, self.step, stream), "qenv_adam_step")
 
-    def update(self, rollout, returns, adv):
-        """K_epochs full-batch epochs (ppo.py:172-203; the reference's randperm of a full batch does not change
-        loss.mean()).  Returns the list of loss dicts."""
+    def update(self, rollout, returns, adv, minibatch=None, generator=None):
+        """K_epochs passes over the collected rollout, returning the list of loss dicts.
+        minibatch=None: full-batch epochs (ppo.py:172-203; the reference's randperm of a full batch does not change
+        loss.mean()).  minibatch=B: the schedule of visual_landing/ppo_trainer.py:187-196 -- every epoch walks a fresh
+        random permutation in batches of B samples, one Adam step per batch, the remainder as a last smaller batch;
+        here the permutation is over the stored time steps and a batch is the B // n_envs steps it covers (all envs
+        of a step stay together, so nothing is gathered sample by sample)."""
         n = rollout.t
         out = []
+        if minibatch is None:
+            for _ in range(self.K_epochs):
+                out.append(self.gradients(rollout.obs[:n], rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n]))
+                self.adam_step()
+            return out
+        N = rollout.obs.shape[2]
+        per = max(1, int(minibatch) // N)
         for _ in range(self.K_epochs):
-            out.append(self.gradients(rollout.obs[:n], rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n]))
-            self.adam_step()
+            perm = torch.randperm(n, device=rollout.obs.device, generator=generator)
+            for lo in range(0, n, per):
+                idx = perm[lo:lo + per]
+                out.append(self.gradients(rollout.obs[idx], rollout.actions[idx], rollout.logprobs[idx], adv[idx], returns[idx]))
+                self.adam_step()
         return out
 
 

@@ -408,3 +408,30 @@ def test_mlp_forward_every_instantiation_vs_torch_fp64(aq, hidden, T, N):
         ref_m, ref_v = act_net(x).t(), cri_net(x).t()
     assert float((mean.double() - ref_m).abs().max()) < 2e-6
     assert float((val.double() - ref_v).abs().max()) < 5e-6 * max(1.0, float(ref_v.abs().max()))
+
+
+def test_minibatch_schedule_of_the_landing_trainer(aq):
+    """ppo_trainer.py:187-196 on the MLP policy: K epochs x ceil(n / per) Adam steps over fresh permutations of the
+    stored steps; with one batch covering everything it degenerates to the full-batch update (same weights up to the
+    fp32 atomics' summation order), and the loss of the clipped objective falls over the epochs."""
+    torch.manual_seed(3)
+    w = aq.ActorCriticWeights.random(32, 75, 4, seed=5); w.std = 0.1
+    env = aq.BatchedQuad(64, 0.01, 200, training=True, direct_control=1, T=5)
+    ro = aq.PolicyRollout(env, w, 24, store_obs=True, auto_reset=True, seed=9)
+    ro.start()
+    for _ in range(24):
+        ro.step()
+    ret, adv = ro.finish(ddof=1, group=False)   # the trainer's ddof (ppo_trainer.py:148)
+    import copy
+    w2 = aq.ActorCriticWeights([t.clone() for t in w.actor], [t.clone() for t in w.critic]); w2.std = 0.1
+    full = aq.PpoLearner(w, lr=2e-5, K_epochs=5, c_entropy=0.01, group=False)
+    mini = aq.PpoLearner(w2, lr=2e-5, K_epochs=5, c_entropy=0.01, group=False)
+    a = full.update(ro, ret, adv)
+    b = mini.update(ro, ret, adv, minibatch=64 * 24)           # one batch = everything
+    assert len(a) == 5 and len(b) == 5
+    for x, y in zip(w.actor + w.critic, w2.actor + w2.critic):
+        assert torch.allclose(x, y, rtol=0, atol=5e-6)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    c = mini.update(ro, ret, adv, minibatch=64 * 5, generator=g)  # 24 steps in batches of 5 -> 5 batches (4 x 5 + 4)
+    assert len(c) == 5 * 5 and all(np.isfinite(float(l["loss"])) for l in c)
+    assert mini.step == 5 + 25
