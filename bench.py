@@ -372,6 +372,15 @@ def main():
                 s = time_region(r2, pc, args.steps, 1, dev)
                 extras[f"{integ}:{launch}"] = n_global * args.steps / s
             del e2
+        # config 2's unperturbed variant: at EXACT hover f0 = 0, scipy's select_initial_step takes its
+        # h0 = 1e-6 branch and every env step costs ~5 growing sub-steps although the state does not move
+        e3 = build_env("rk45")
+        hover = torch.zeros(13, e3.n_envs, device=dev, dtype=dt); hover[6] = 1
+        e3.reset(hover)
+        r3, pc = make_runner(e3, controller, flags, "fused", chunk, False)
+        time_region(r3, pc, chunk, 1, dev)
+        extras["rk45:fused:exact_hover"] = n_global * args.steps / time_region(r3, pc, args.steps, 1, dev)
+        del e3
         out["extras_env_steps_per_s"] = extras
         # the same operating points as a fraction of the 8 TB/s HBM peak on the algorithmic bytes per env step;
         # BASELINE.json words config 2 as "RK4 dynamics only": that operating point is extras["rk4:fused"]
