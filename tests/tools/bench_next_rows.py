@@ -3,7 +3,7 @@ on one MI355X, each next to the fp64 C oracle of the same thing on the host core
 HIP-event timing on the launch stream; algorithmic bytes / flops per unit stated in each line."""
 import json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import autonomous_quadrotor_environment_amd as aq
 from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states

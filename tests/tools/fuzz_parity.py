@@ -3,7 +3,7 @@
 saturating ones, full step with reward / done / solved / Euler rates / effort, several resets per case.
 Prints one line per case and a summary; exits non-zero on any mismatch above 1e-8 (scaled) or any flag mismatch."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import autonomous_quadrotor_environment_amd as aq
 from oracle import quad_oracle as O

@@ -1,8 +1,8 @@
 """GPU box: teacher-forced ONE-STEP error of the fp32 handle against the fp64 C oracle over random points of the
-configuration space (as tools/fuzz_parity.py): before every step the fp32 env's state rows are overwritten with the
+configuration space (as tests/tools/fuzz_parity.py): before every step the fp32 env's state rows are overwritten with the
 oracle's state, so each comparison isolates one step's arithmetic (north-star: 1e-5 on the scale-floored metric)."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import autonomous_quadrotor_environment_amd as aq
 from oracle import quad_oracle as O
