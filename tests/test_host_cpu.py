@@ -68,6 +68,20 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in src.lower() or f == "__init__.py" and "oracle" not in src, (f,)
 
 
+def test_only_the_allowed_places_load_the_oracle():
+    """oracle/ is test infrastructure: besides tests/ (incl. tests/tools), only __graft_entry__.smoke() and bench.py's
+    cpu_baseline leg may load it -- tools/, examples/ and the package never do."""
+    for sub in ("tools", "examples", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".c", ".h", ".hip")):
+                    assert "quad_oracle" not in open(os.path.join(dirpath, f)).read(), (sub, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("quad_oracle") == 1 and bench.index("quad_oracle") > bench.index("def cpu_baseline")
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert entry.index("def smoke") < entry.rindex("quad_oracle") or "oracle" in entry[:entry.index("def smoke")]  # build() compiles it
+
+
 def test_random_init_states_replay_reference_draw_order(built):
     g = golden("g5_reset")
     for seed in range(16):
