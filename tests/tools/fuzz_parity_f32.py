@@ -19,6 +19,8 @@ for case in range(n_cases):
     direct = int(rng.randint(2))
     clipped = bool(rng.randint(2))
     t_step = float(rng.choice([0.01, 0.005, 0.02]))
+    if len(sys.argv) > 3:
+        t_step = float(sys.argv[3])  # e.g. 0.01: the only step size the reference's scripts use
     N, S = 32, 25
     kw = dict(training=False, direct_control=direct, T=1, clipped=clipped, variant=variant, integrator=integ)
     env = aq.BatchedQuad(N, t_step, 10 ** 6, dtype=torch.float32, **kw)
