@@ -1,0 +1,62 @@
+"""GPU box: randomized differential run of the FUSED controller rollouts (one k_rollout launch: LQR, velocity PID,
+position PD, constant action) in fp64 against the oracle stepping the same controllers env by env, over random
+configurations (integrator x variant x clipped x training x T x episode length x initial-state scale)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import autonomous_quadrotor_environment_amd as aq
+from oracle import quad_oracle as O
+
+O.build()
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+SC = np.array([5, 10, 5, 10, 5, 10, 1, 1, 1, 1, 20, 20, 20.0])
+worst, bad = 0.0, 0
+for case in range(n_cases):
+    ctrl = ["lqr", "pid", "pidpos", "const"][rng.randint(4)]
+    integ = ["rk45", "dp5", "rk4"][rng.randint(3)]
+    variant = ["main", "opt"][rng.randint(2)]
+    clipped = bool(rng.randint(2)) or variant == "opt"
+    training = bool(rng.randint(2))
+    T = int(rng.choice([1, 5]))
+    n_max = int(rng.choice([40, 1000]))
+    N, S = 12, int(rng.choice([30, 80]))
+    kw = dict(training=training, direct_control=0, T=T, clipped=clipped, variant=variant, integrator=integ)
+    env = aq.BatchedQuad(N, 0.01, n_max, dtype=torch.float64, **kw)
+    x0 = aq.random_init_states(rng, N, variant) * rng.choice([0.1, 0.5])
+    x0[:, 6:10] /= np.linalg.norm(x0[:, 6:10], axis=1, keepdims=True)
+    env.reset(x0.T.copy())
+    target = np.r_[rng.normal(0, 0.5, 3), rng.normal(0, 0.2, 3), rng.normal(0, 0.3)]
+    act = np.array([1.03 * 9.82, 0, 0, 0]) + rng.normal(0, [1, 0.05, 0.05, 0.02])
+    if ctrl == "pid":
+        env.pid_reset(); env.rollout("pid", S, pid_first_action=True)
+    elif ctrl == "pidpos":
+        env.pid_reset(); env.rollout("pidpos", S, action=target)
+    elif ctrl == "const":
+        env.rollout("const", S, action=act)
+    else:
+        env.rollout("lqr", S)
+    got, ret, fl = env.state.cpu().numpy(), env.episode_return.cpu().numpy(), env.flags.cpu().numpy()
+    err, flags_ok = 0.0, True
+    for e in range(N):
+        r = O.OracleQuad(0.01, n_max, euler=0, **kw)
+        r.reset(x0[e])
+        c = {"lqr": lambda: O.OracleLqr(r, clipped), "pid": lambda: O.OraclePid(r, clipped), "pidpos": lambda: O.OraclePidPos(r),
+             "const": lambda: None}[ctrl]()
+        total = 0.0
+        a = np.array([1.03 * 9.82, 0, 0, 0])
+        for k in range(S):
+            if ctrl == "lqr": a = c.control()
+            elif ctrl == "pid": a = a if k == 0 else c.control(np.zeros(3), np.zeros(3), 0, 0)
+            elif ctrl == "pidpos": a = c.control(target[0:3], target[3:6], target[6], 0)
+            else: a = act
+            _, rew, d = r.step(a)
+            total += rew
+        err = max(err, np.max(np.abs(got[:, e] - r.state) / np.maximum(np.abs(r.state), 1e-3 * SC)))
+        flags_ok &= bool(fl[e] & 1) == bool(r.done) and bool(fl[e] & 2) == bool(r.solved)
+    ok = err < 1e-7 and flags_ok
+    worst = max(worst, err); bad += 0 if ok else 1
+    print(json.dumps(dict(case=case, ctrl=ctrl, integ=integ, variant=variant, clipped=clipped, training=training, T=T, n_max=n_max,
+                          S=S, err=float(err), flags_ok=bool(flags_ok), ok=bool(ok))), flush=True)
+print(json.dumps(dict(cases=n_cases, mismatching=bad, worst_scaled_err=float(worst))))
+sys.exit(1 if bad else 0)
