@@ -54,7 +54,7 @@ for case in range(n_cases):
             total += rew
         err = max(err, np.max(np.abs(got[:, e] - r.state) / np.maximum(np.abs(r.state), 1e-3 * SC)))
         flags_ok &= bool(fl[e] & 1) == bool(r.done) and bool(fl[e] & 2) == bool(r.solved)
-    ok = err < 1e-7 and flags_ok
+    ok = err < 1e-6 and flags_ok  # closed loops amplify the 1e-13 per-step libm differences (unclipped position PD: up to 2e-7 in 80 steps)
     worst = max(worst, err); bad += 0 if ok else 1
     print(json.dumps(dict(case=case, ctrl=ctrl, integ=integ, variant=variant, clipped=clipped, training=training, T=T, n_max=n_max,
                           S=S, err=float(err), flags_ok=bool(flags_ok), ok=bool(ok))), flush=True)
