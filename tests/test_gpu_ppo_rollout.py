@@ -435,3 +435,31 @@ def test_minibatch_schedule_of_the_landing_trainer(aq):
     c = mini.update(ro, ret, adv, minibatch=64 * 5, generator=g)  # 24 steps in batches of 5 -> 5 batches (4 x 5 + 4)
     assert len(c) == 5 * 5 and all(np.isfinite(float(l["loss"])) for l in c)
     assert mini.step == 5 + 25
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("hidden", [32, 128])
+def test_batched_critic_equals_per_step_critic(aq, dt, hidden):
+    """V(s_t) of the whole horizon in one launch over the stored observations at finish() (the default once the
+    observations are stored) against one critic launch per step: same values, returns and raw advantages, bitwise."""
+    w = aq.ActorCriticWeights.random(hidden, 75, 4, seed=3)
+    n, H = 777, 37
+    outs = []
+    for batched in (True, False):
+        env = aq.BatchedQuad(n, 0.01, 15, training=True, direct_control=1, T=5, dtype=dt)
+        ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=2)
+        assert ro.batched_critic
+        ro.batched_critic = batched
+        ro.start()
+        for _ in range(H):
+            ro.step()
+        if batched:
+            assert float(ro.values.abs().max()) == 0.0  # nothing evaluated during the rollout
+        ret, adv = ro.finish(ddof=0, group=False, bootstrap=True)
+        outs.append((ro.values.clone(), ret, adv, ro.obs.clone()))
+    assert float(outs[0][0].abs().max()) > 0
+    assert torch.equal(outs[0][3], outs[1][3]) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=0, atol=1e-5)  # normalisation moments: fp64 atomics
+    # no stored observations / another window length: one launch per step
+    env = aq.BatchedQuad(64, 0.01, 15, training=True, direct_control=1, T=5)
+    assert not aq.PolicyRollout(env, w, 4).batched_critic
