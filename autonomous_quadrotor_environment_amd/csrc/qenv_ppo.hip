@@ -226,9 +226,143 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     }
 }
 
+// ---- the same MLP for SMALL batches (a handful of 32-env tiles: the N = 1 drop-in, the 256-env training demo) ----
+// k_mlp's cost at that size is not arithmetic: one workgroup stages 119 KB of weights (which every wave then uses
+// exactly once) and each wave walks the 472 dependent MFMAs of its tile alone: 39 us for 256 envs.  Here a tile
+// belongs to NT = HP/32 waves, wave t computing output tile t of layers 1 and 2; the weights are read straight from
+// global memory (L2) in the A-operand layout -- no staging, each element is used once per tile -- and the activations
+// cross waves through LDS in the lane layout they already have (register j of lane l -> word (16 t + j) 64 + l, so
+// every wave reads tile ti's register j as ITS lane's B operand: conflict-free, and the k-pairs and their order are
+// those of k_mlp).  Layer 3 stays one 16 NT-MFMA chain on wave 0 so the accumulation order is k_mlp's too: the
+// results are bit-identical to k_mlp's.  Dependent MFMAs per tile: 38 + 16 NT + 16 NT instead of NT (38 + 16 NT + 16).
+template <int H, int TW>
+__global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpArgs a) {
+    constexpr int HP = H < 32 ? 32 : H;
+    constexpr int NT = HP / 32;
+    constexpr int K1 = 15 * TW, KS = (K1 + 1) / 2;
+    __shared__ float x1[NT * 16 * 64], x2[NT * 16 * 64];
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, t = threadIdx.x >> 6;
+    const int h = 32 * t + col;  // the hidden row this lane supplies as A operand
+    const bool h_ok = h < H, o_ok = col < a.n_out;
+    const float* __restrict__ w1 = a.W1 + (size_t)(h_ok ? h : 0) * K1;
+    const float* __restrict__ w2 = a.W2 + (size_t)(h_ok ? h : 0) * H;
+    const float* __restrict__ w3 = a.W3 + (size_t)(o_ok ? col : 0) * H;
+    const int64_t tiles_per_chunk = (a.N + 31) / 32;
+    const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
+    // this lane's A operands of all three layers, fetched ONCE (they do not depend on the tile) with back-to-back
+    // loads: a load in front of every MFMA would put an L2 round trip on the dependent chain 38 + 32 NT times
+    float a1[KS], a2[NT * 16], a3[NT * 16];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + half;
+        const float v = w1[k < K1 ? k : K1 - 1];
+        a1[s] = (h_ok && k < K1) ? v : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NT * 16; ++i) {
+        const int k = 32 * (i >> 4) + acc_row(i & 15, half);
+        const float v = w2[k < H ? k : 0];
+        a2[i] = (h_ok && k < H) ? v : 0.f;
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int i = 0; i < NT * 16; ++i) {
+            const int k = 32 * (i >> 4) + acc_row(i & 15, half);
+            const float v = w3[k < H ? k : 0];
+            a3[i] = (o_ok && k < H) ? v : 0.f;
+        }
+    }
+    float bias1[16], bias2[16], bias3[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = 32 * t + acc_row(j, half), r3 = acc_row(j, half);
+        bias1[j] = r < H ? a.b1[r] : 0.f;
+        bias2[j] = r < H ? a.b2[r] : 0.f;
+        bias3[j] = r3 < a.n_out ? a.b3[r3] : 0.f;
+    }
+    for (int64_t gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
+        const int64_t chunk = a.n_chunks > 1 ? gtile / tiles_per_chunk : 0;
+        const int64_t tile = gtile - chunk * tiles_per_chunk;
+        const float* __restrict__ winc = a.win + chunk * (int64_t)K1 * a.N;
+        const int64_t e = tile * 32 + col;
+        const bool valid = e < a.N;
+        const int64_t ec = valid ? e : a.N - 1;
+        float xs[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            int sl0 = a.head + k0 / 15, sl1 = a.head + k1 / 15;  // wave-uniform
+            if (sl0 >= TW) sl0 -= TW;
+            if (sl1 >= TW) sl1 -= TW;
+            const int r0 = sl0 * 15 + k0 % 15;
+            const int r1 = k1 < K1 ? sl1 * 15 + k1 % 15 : r0;
+            float x = winc[(int64_t)(half ? r1 : r0) * a.N + ec];
+            if (k1 >= K1) x = half ? 0.f : x;
+            xs[s] = x;
+        }
+        if (a.obs_store && valid && t == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k = 2 * s + half;
+                if (k < K1) a.obs_store[(int64_t)k * a.N + e] = xs[s];
+            }
+        }
+        f32x16 acc;
+        // layer 1, output tile t: k-step s pairs window elements 2s (lanes 0-31) and 2s+1 (lanes 32-63)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bias1[j];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], xs[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x1[(16 * t + j) * 64 + lane] = fast_tanh(acc[j]);
+        __syncthreads();
+        // layer 2, output tile t, over all NT input tiles
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bias2[j];
+#pragma unroll
+        for (int i = 0; i < NT * 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], x1[i * 64 + lane], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x2[(16 * t + j) * 64 + lane] = fast_tanh(acc[j]);
+        __syncthreads();  // also: every wave is done with x1 before the next tile overwrites it
+        if (t == 0) {     // layer 3 (n_out <= 4 rows in one zero-padded 32-row tile): one chain, k_mlp's order
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = bias3[j];
+#pragma unroll
+            for (int i = 0; i < NT * 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[i], x2[i * 64 + lane], acc, 0, 0, 0);
+            const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float v = acc[o];
+                if (a.final_tanh) v = tanhf(v);
+                if (valid && half == 0 && o < a.n_out) {
+                    if (a.out_f64) ((double*)a.out)[out_off + (int64_t)o * a.N + e] = (double)v;
+                    else ((float*)a.out)[out_off + (int64_t)o * a.N + e] = v;
+                }
+            }
+        }
+        // x2 is rewritten only after the next tile's first barrier, which wave 0 reaches after this layer 3
+    }
+}
+
+// tiles (32 envs) up to which the split kernel is used: measured crossover (tools/time_mlp_sizes.py)
+#ifndef QENV_MLP_SMALL_TILES
+#define QENV_MLP_SMALL_TILES 512
+#endif
+
+template <int H, int TW> static int launch_mlp_small(const MlpArgs& a, hipStream_t stream) {
+    constexpr int HP = H < 32 ? 32 : H;
+    const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
+    hipLaunchKernelGGL((k_mlp_small<H, TW>), dim3((unsigned)(n_tiles < 4096 ? n_tiles : 4096)), dim3(HP * 2), 0, stream, a);
+    return check_launch("k_mlp_small");
+}
+
 template <int H, int TW, int BLOCK, bool W2_LDS>
 static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
+    if constexpr (H >= 64 && H <= 128 && TW > 0) {  // >= 2 waves per tile to split over, the reference's window
+        static const int small_tiles = getenv("QENV_MLP_SMALL_TILES") ? atoi(getenv("QENV_MLP_SMALL_TILES")) : QENV_MLP_SMALL_TILES;
+        if (((a.N + 31) / 32) * a.n_chunks <= small_tiles) return launch_mlp_small<H, TW>(a, stream);
+    }
     const int K1P = (15 * T + 1) & ~1;
     const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 32 * HP + 2 * HP + 32);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");

@@ -463,3 +463,23 @@ def test_batched_critic_equals_per_step_critic(aq, dt, hidden):
     # no stored observations / another window length: one launch per step
     env = aq.BatchedQuad(64, 0.01, 15, training=True, direct_control=1, T=5)
     assert not aq.PolicyRollout(env, w, 4).batched_critic
+
+
+@pytest.mark.parametrize("hidden", [64, 128])
+@pytest.mark.parametrize("n_out,final_tanh", [(4, True), (1, False)])
+def test_small_batch_mlp_kernel_is_bit_identical_to_the_staged_kernel(aq, hidden, n_out, final_tanh):
+    """Up to 512 tiles of 32 envs the forward runs on k_mlp_small (a tile split over HP/32 waves, weights straight from
+    L2, activations exchanged through LDS), beyond that on the LDS-staged k_mlp: the same observations must give the
+    same bits whichever kernel their batch size selects (k-pairs and accumulation order are kept)."""
+    g = torch.Generator(device="cuda").manual_seed(hidden + n_out)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    W = [r(hidden, 75) * 0.2, r(hidden) * 0.1, r(hidden, hidden) * 0.15, r(hidden) * 0.1, r(n_out, hidden) * 0.2, r(n_out) * 0.1]
+    x = r(75, 40000)
+    big = aq.dense_tail(x, W, final_tanh=final_tanh)                      # 1250 tiles: k_mlp
+    for n in (1, 31, 1000, 16384):                                       # <= 512 tiles: k_mlp_small
+        small = aq.dense_tail(x[:, :n].contiguous(), W, final_tanh=final_tanh)
+        assert torch.equal(small, big[:, :n]), n
+    ref = torch.tanh(W[2].double() @ torch.tanh(W[0].double() @ x.double() + W[1].double()[:, None]) + W[3].double()[:, None])
+    ref = W[4].double() @ ref + W[5].double()[:, None]
+    ref = torch.tanh(ref) if final_tanh else ref
+    assert float((big.double() - ref).abs().max()) < 5e-6
