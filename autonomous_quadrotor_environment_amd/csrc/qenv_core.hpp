@@ -843,7 +843,9 @@ __device__ __forceinline__ void done_reward(const T y[13], const T act[4], const
         solved = 0;
     }
     bk.reward = reward;
-    bk.ep_return += reward;
+    // the worker's reward_sum (ppo.py:236,258): zeroed AFTER env.reset(), so the rewards of the reset's own T warm-up
+    // steps (i = 1..T) are not part of an episode's return
+    if (bk.i > cfg.warmup) bk.ep_return += reward;
     bk.flags = (done ? FLAG_DONE : 0) | (solved ? FLAG_SOLVED : 0) | FLAG_HAS_SHAPING | FLAG_ANG_OK;
     bk.abs_sum += m::sqrt((effort[0] * effort[0] + effort[1] * effort[1]) + (effort[2] * effort[2] + effort[3] * effort[3]));
 }

@@ -84,7 +84,7 @@ typedef enum {
     QENV_FIELD_PREV_SHAPING = 9,   /* [1][N]                                         */
     QENV_FIELD_REWARD = 10,        /* [1][N]                                         */
     QENV_FIELD_ABS_SUM = 11,       /* [1][N]   control-effort accumulator            */
-    QENV_FIELD_EP_RETURN = 12,     /* [1][N]   sum of rewards since reset            */
+    QENV_FIELD_EP_RETURN = 12,     /* [1][N]   sum of rewards since reset (the reset's own T warm-up steps excluded: the worker's reward_sum, ppo.py:236,258) */
     QENV_FIELD_PID = 13,           /* [15][N]  ix[6], x_old[6], ang_d_ant[3]         */
     QENV_FIELD_I = 14,             /* [1][N]   int32 step counter                    */
     QENV_FIELD_FLAGS = 15,         /* [1][N]   int32 bit0 done, bit1 solved,

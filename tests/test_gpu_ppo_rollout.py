@@ -483,3 +483,22 @@ def test_small_batch_mlp_kernel_is_bit_identical_to_the_staged_kernel(aq, hidden
     ref = W[4].double() @ ref + W[5].double()[:, None]
     ref = torch.tanh(ref) if final_tanh else ref
     assert float((big.double() - ref).abs().max()) < 5e-6
+
+
+def test_episode_return_is_the_workers_reward_sum(aq):
+    """ppo.py:236,258: reward_sum is zeroed AFTER env.reset() and sums the rewards env.step returned to the loop -- the
+    rewards of the reset's own T warm-up steps are not part of it (found by tests/tools/fuzz_policy_rollout.py)."""
+    n, T = 200, 5
+    env = aq.BatchedQuad(n, 0.01, 10, training=True, direct_control=1, T=T, dtype=torch.float64)
+    env.reset(env.sample_init_states(1, 0, 0), push_window=True)
+    assert int(env.i.min()) == T and float(env.reward.abs().max()) > 0      # warm-up steps did earn rewards ...
+    assert float(env.episode_return.abs().max()) == 0.0                     # ... which the episode does not count
+    total = torch.zeros(n, device="cuda", dtype=torch.float64)
+    act = torch.zeros(4, n, device="cuda", dtype=torch.float64)
+    for k in range(4):
+        _, r, d = env.step(act, push_window=True)
+        total += r
+        assert torch.equal(env.episode_return, total)
+        env.reset_sampled(1, k + 1, 0, mask=d, push_window=True)
+        assert torch.equal(env.last_return[d], total[d]) and float(env.episode_return[d].abs().max() if bool(d.any()) else 0.0) == 0.0
+        total[d] = 0
