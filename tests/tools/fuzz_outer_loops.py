@@ -1,0 +1,67 @@
+"""GPU box: the outer position loops evaluated inside the step kernel's window push (vel_pid on a mission table,
+pos_pi + clip towards per-env targets) in fp64 against the oracle, teacher-forced with random actions: velocity command,
+integrator state, the 75-float policy observation of every step and the trajectories, over random tables / gains /
+variants / integrators."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import autonomous_quadrotor_environment_amd as aq
+from oracle import quad_oracle as O
+
+O.build()
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+SC = np.array([5, 10, 5, 10, 5, 10, 1, 1, 1, 1, 20, 20, 20.0])
+w = aq.ActorCriticWeights.random(16, 75, 4, seed=1)  # only used to read the ring out in time order (obs_store)
+worst, bad = 0.0, 0
+for case in range(n_cases):
+    kind = ["velpid", "pospi"][rng.randint(2)]
+    integ = ["rk45", "dp5", "rk4"][rng.randint(3)]
+    N, S, T = 8, int(rng.choice([20, 60])), 5
+    kw = dict(training=False, direct_control=1, T=T, integrator=integ)
+    env = aq.BatchedQuad(N, 0.01, 100000, dtype=torch.float64, **kw)
+    x0 = aq.random_init_states(rng, N) * 0.3
+    x0[:, 6:10] /= np.linalg.norm(x0[:, 6:10], axis=1, keepdims=True)
+    n_rows = int(rng.choice([S // 2, S + 5]))  # shorter than the run: the last row is held
+    table = np.concatenate([rng.normal(0, 1.0, (n_rows, 3)), rng.normal(0, 0.5, (n_rows, 3)), np.zeros((n_rows, 1))], 1)
+    targets = rng.normal(0, 1.5, (3, N))
+    gains = (float(rng.uniform(1, 6)), float(rng.uniform(0, 1)), float(rng.choice([0.0, 0.8])))
+    if kind == "velpid":
+        env.outer_velpid(table)
+    else:
+        env.outer_pospi(targets, *gains)
+    env.outer_reset()
+    env.reset(x0.T.copy(), return_history=False, push_window=True)
+    refs, wins, loops = [], [], []
+    for e in range(N):
+        r = O.OracleQuad(0.01, 100000, euler=0, **kw)
+        s, a = r.reset(x0[e])
+        win = O.OracleWindow(T); win.dl_input(s, a)
+        refs.append(r); wins.append(win)
+        loops.append(O.OracleVelPid() if kind == "velpid" else O.OraclePosPi(*gains, 0.01))
+    obs_dev = torch.empty(15 * T, N, device="cuda", dtype=torch.float32)
+    err = 0.0
+    for k in range(S):
+        act = rng.uniform(-0.4, 0.4, (4, N))
+        env.step(act, push_window=True)
+        env.mlp_forward(w, "actor", obs_store=obs_dev)
+        OB, CMD, ST = obs_dev.cpu().numpy(), env.vel_cmd.cpu().numpy(), env.state.cpu().numpy()
+        for e, r in enumerate(refs):
+            q, _, _ = r.step(act[:, e])
+            off = np.zeros(14)
+            if kind == "velpid":
+                row = table[min(k, n_rows - 1)]
+                tg = np.zeros(14); tg[0:5:2] = row[0:3]; tg[1:6:2] = row[3:6]
+                pe = loops[e](r.state, tg)
+                off, cmd = tg + pe, pe[1:6:2]
+            else:
+                cmd = loops[e].vel_error(r.state[0:5:2], targets[:, e], r.state[1:6:2], np.zeros(3))
+                off[1:6:2] = cmd
+            ob = wins[e].dl_input(q - off[None, :], act[:, e][None, :])
+            err = max(err, float(np.max(np.abs(OB[:, e] - ob))), float(np.max(np.abs(CMD[:, e] - cmd))),
+                      float(np.max(np.abs(ST[:, e] - r.state) / np.maximum(np.abs(r.state), 1e-3 * SC))))
+    ok = err < 1e-6  # float32 observations of values up to ~10: 5e-7
+    worst = max(worst, err); bad += 0 if ok else 1
+    print(json.dumps(dict(case=case, kind=kind, integ=integ, S=S, rows=n_rows, gains=gains, err=err, ok=bool(ok))), flush=True)
+print(json.dumps(dict(cases=n_cases, mismatching=bad, worst_err=float(worst))))
+sys.exit(1 if bad else 0)
