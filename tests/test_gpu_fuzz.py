@@ -1,0 +1,32 @@
+"""GPU: a short run of every differential fuzzer under tests/tools (HIP path vs the oracle over random points of the
+configuration space; the long runs are recorded under profiles/r01_fuzz_*.jsonl).  The scripts are executed in this
+process (runpy), with a seed the recorded runs did not use."""
+import os
+import runpy
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOOLS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
+
+
+@pytest.mark.parametrize("script,args", [
+    ("fuzz_parity.py", ["101", "100"]),             # fp64 step/reset across variant x integrator x mode x T x ...
+    ("fuzz_parity_f32.py", ["101", "60", "0.01"]), # fp32 one-step error at the reference's step size
+    ("fuzz_controllers.py", ["101", "60"]),        # fused LQR / PID / position-PD / constant rollouts
+    ("fuzz_robust.py", ["101", "30"]),              # robust_control: perturbed plants + gust tables
+    ("fuzz_policy_rollout.py", ["101", "20"]),      # PPO worker loop with masked auto-reset
+    ("fuzz_outer_loops.py", ["101", "30"]),         # vel_pid / pos_pi inside the window push
+    ("fuzz_sensor.py", ["101", "30"]),              # sensor model
+])
+def test_fuzzer_short_run(script, args, capsys):
+    argv = sys.argv
+    sys.argv = [script] + args
+    try:
+        with pytest.raises(SystemExit) as ex:
+            runpy.run_path(os.path.join(TOOLS, script), run_name="__main__")
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out.strip().splitlines()
+    assert ex.value.code in (0, None), "\n".join(out[-5:])

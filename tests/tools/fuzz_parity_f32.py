@@ -49,3 +49,4 @@ for case in range(n_cases):
     worst = max(worst, err); hist.append(err)
     print(json.dumps(dict(case=case, variant=variant, integ=integ, direct=direct, clipped=clipped, t_step=t_step, one_step_scaled_err=float(err))), flush=True)
 print(json.dumps(dict(cases=n_cases, worst=float(worst), median=float(np.median(hist)), p95=float(np.percentile(hist, 95)))))
+sys.exit(1 if worst > 2e-5 else 0)  # 1.01e-5 is the worst seen at t_step = 0.01 (480 000 steps), 1.7e-5 at 0.02
