@@ -29,9 +29,9 @@ struct BwdArgs {
 // H = 128 keeps 2 x 64 activation registers + the gradient tile live: 256-thread workgroups (one wave per
 // SIMD, 512 registers) instead of spilling 1.6 KB/lane under the 256-register cap of 512 threads.
 template <int H>
-__global__ __launch_bounds__(H >= 128 ? 256 : 512) void k_mlp_bwd(const BwdArgs a) {
+__global__ __launch_bounds__(H >= 256 ? 256 : 512) void k_mlp_bwd(const BwdArgs a) {
     constexpr int HP = H < 32 ? 32 : H, NT = HP / 32, LD2 = HP + 1;
-    constexpr int BLOCK = H >= 128 ? 256 : 512, WPB = BLOCK / 64;
+    constexpr int BLOCK = H >= 256 ? 256 : 512, WPB = BLOCK / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K1 = a.K, K1P = (K1 + 1) & ~1;
     float* W1t = lds;                        // [K1P][HP]
@@ -199,7 +199,7 @@ struct WgradArgs {
 // conflict free); each of the 4 waves owns up to MT*NT/4 of the 32x32 output tiles in registers for the
 // whole walk and adds them to C once at the end.
 template <int MT, int NTN>
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 256 VGPRs: two workgroups per CU (2 waves per SIMD), or one wave alone exposes every LDS / barrier wait
     constexpr int LD = 65, TPW = (MT * NTN + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                 // [MT*32][65]
@@ -211,20 +211,31 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
     for (int q = 0; q < TPW; ++q)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
-    float rs = 0.f;  // thread r < M accumulates row r's sum
+    // bias gradients = row sums of A: every thread already holds, in `pre`, the elements of rows wave + 4 i at its own
+    // sample, so it accumulates them in registers (no LDS reads, the four waves stay balanced) and the 64 samples of a
+    // row are folded across the wave once, after the walk
+    float rsum[8 * MT];
+#pragma unroll
+    for (int i = 0; i < 8 * MT; ++i) rsum[i] = 0.f;
     // Every thread carries its share of the NEXT 64-sample tile in registers: the global loads are issued right after
     // the current tile has been copied to LDS and land while its MFMAs run (the staging latency used to be exposed
     // between two barriers).  PER = elements per thread and tile.
     constexpr int PER = (MT + NTN) * 32 * 64 / 256;
     float pre[PER];
+    // element i of a thread is row wave + 4 i of the combined [A rows | B rows] image at sample lane: rows
+    // 0..MT*32-1 = A (i < 8 MT), the rest = B -- one 64-bit base per operand and tile, then 32-bit row strides
     auto fetch = [&](int64_t tile) {
-        const int64_t c = tile / tiles_per_chunk, e0 = (tile % tiles_per_chunk) * 64;
+        const int64_t c = tile / tiles_per_chunk, e0 = (tile % tiles_per_chunk) * 64;  // block-uniform
+        const bool inb = e0 + lane < a.N;
+        const float* __restrict__ pa = a.A + ((size_t)c * a.M) * a.N + e0 + lane;
+        const float* __restrict__ pb = a.B + ((size_t)c * a.Nn) * a.N + e0 + lane;
+        uint32_t n32 = (uint32_t)a.N;
+        asm volatile("" : "+s"(n32));  // opaque per tile: LICM would otherwise keep all PER row offsets live across the walk
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int idx = threadIdx.x + 256 * i, r = idx >> 6, sidx = idx & 63;  // rows 0..MT*32-1 = A, the rest = B
-            const bool inb = e0 + sidx < a.N;
-            if (r < MT * 32) pre[i] = (r < a.M && inb) ? a.A[((size_t)c * a.M + r) * a.N + e0 + sidx] : 0.f;
-            else pre[i] = ((r - MT * 32) < a.Nn && inb) ? a.B[((size_t)c * a.Nn + (r - MT * 32)) * a.N + e0 + sidx] : 0.f;
+            const int r = wave + 4 * i;
+            if (i < 8 * MT) pre[i] = (r < a.M && inb) ? pa[(uint32_t)r * n32] : 0.f;
+            else pre[i] = ((r - MT * 32) < a.Nn && inb) ? pb[(uint32_t)(r - MT * 32) * n32] : 0.f;
         }
     };
     // the tiles a wave owns are consecutive; when they all sit in one row of output tiles the A operand of a k-step is
@@ -240,14 +251,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
             lds[r * LD + sidx] = pre[i];  // As and Bs are contiguous: row r of the combined [ (MT+NTN)*32 ][65] image
         }
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
-        if (a.rowsum && (int)threadIdx.x < a.M) {
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int sidx = 0; sidx < 64; ++sidx) sacc += As[threadIdx.x * LD + sidx];
-            rs += sacc;
+        if (a.rowsum) {
+#pragma unroll
+            for (int i = 0; i < 8 * MT; ++i) rsum[i] += pre[i];
         }
-#pragma unroll 4
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+#pragma unroll 2
         for (int ks = 0; ks < 32; ++ks) {
             const int sidx = 2 * ks + half;
             float a0 = 0.f;
@@ -275,7 +284,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs a) {
             }
         }
     }
-    if (a.rowsum && (int)threadIdx.x < a.M) atomicAdd(&a.rowsum[threadIdx.x], rs);
+    if (a.rowsum) {
+#pragma unroll
+        for (int i = 0; i < 8 * MT; ++i) {
+            float v = rsum[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+            const int r = wave + 4 * i;
+            if (lane == 0 && r < a.M) atomicAdd(&a.rowsum[r], v);
+        }
+    }
 }
 
 template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
@@ -331,7 +349,7 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
     case HH:                                                                                                                 \
         e = hipFuncSetAttribute((const void*)k_mlp_bwd<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd)");                                           \
-        hipLaunchKernelGGL((k_mlp_bwd<HH>), dim3((unsigned)blocks), dim3(HH >= 128 ? 256 : 512), lds, (hipStream_t)stream, a);                 \
+        hipLaunchKernelGGL((k_mlp_bwd<HH>), dim3((unsigned)blocks), dim3(HH >= 256 ? 256 : 512), lds, (hipStream_t)stream, a);                 \
         break;
     switch (hidden) {
         QENV_BWD_CASE(16) QENV_BWD_CASE(32) QENV_BWD_CASE(64) QENV_BWD_CASE(128)
@@ -346,6 +364,8 @@ int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const
     if (!A || !B || !C) return fail(QENV_ERR_ARG, "qenv_weight_grad: null argument");
     if (n_envs <= 0 || n_chunks <= 0 || m_rows < 1 || m_rows > 128 || n_rows < 1 || n_rows > 128)
         return fail(QENV_ERR_ARG, "qenv_weight_grad: rows must be 1..128");
+    if ((int64_t)128 * n_envs >= ((int64_t)1 << 32))
+        return fail(QENV_ERR_ARG, "qenv_weight_grad: 128*n_envs must stay below 2^32 (32-bit row offsets inside a chunk)");
     WgradArgs a;
     a.N = n_envs; a.n_chunks = n_chunks; a.M = m_rows; a.Nn = n_rows; a.A = A; a.B = B; a.C = C; a.rowsum = rowsum;
     const int mt = (m_rows + 31) / 32, nt = (n_rows + 31) / 32;
