@@ -83,6 +83,7 @@ SYMBOLS = {
     "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 13),
     "qenv_ppo_loss": (_i, [_i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "qenv_mlp_backward": (_i, [_i64, _i, _i, _i, _i, _i] + [_vp] * 14),
+    "qenv_mlp_backward_ppo": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 5 + [C.c_double] * 3 + [_i64] + [_vp] * 13),
     "qenv_weight_grad": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adam_step": (_i, [_i64, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp]),
     "qenv_debug_copy_rows": (_i, [_i, _vp, _vp, _i, _i64, _vp]),

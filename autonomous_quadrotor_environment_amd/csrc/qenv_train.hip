@@ -18,6 +18,13 @@ struct BwdArgs {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     float *h1, *h2, *dz2, *dz1;  // [c][H][N] each
     float* dz3;                  // [c][4][N]
+    // loss fused into the backward pass (qenv_mlp_backward_ppo): the seed d loss / d output is computed right here
+    // from the recomputed forward output instead of being read -- no separate forward launch, no loss launch
+    int32_t loss_mode;           // 0: seed given; 1: clipped surrogate of the actor (ppo.py:185-196); 2: c_value * MSE of the critic
+    const float *actions, *old_logprob;  // [c][4][N]
+    const float *adv, *returns;          // [c][N]
+    float inv_var, log_norm, eps_clip, c_value, inv_B;
+    double* sums;                // qenv_ppo_loss's {B, sum actor, sum (V - ret)^2, entropy * B}: [1] (mode 1) or [2] (mode 2) accumulated
 };
 
 // Forward (recomputed) + backward through the activations for one 32-sample tile per wave:
@@ -28,10 +35,10 @@ struct BwdArgs {
 // transposed backward read (stride H+1) are bank-conflict free.
 // H = 128 keeps 2 x 64 activation registers + the gradient tile live: 256-thread workgroups (one wave per
 // SIMD, 512 registers) instead of spilling 1.6 KB/lane under the 256-register cap of 512 threads.
-template <int H>
-__global__ __launch_bounds__(H >= 256 ? 256 : 512) void k_mlp_bwd(const BwdArgs a) {
+template <int H, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
     constexpr int HP = H < 32 ? 32 : H, NT = HP / 32, LD2 = HP + 1;
-    constexpr int BLOCK = H >= 256 ? 256 : 512, WPB = BLOCK / 64;
+    constexpr int WPB = BLOCK / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K1 = a.K, K1P = (K1 + 1) & ~1;
     float* W1t = lds;                        // [K1P][HP]
@@ -63,6 +70,7 @@ __global__ __launch_bounds__(H >= 256 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
     const int64_t tiles_per_chunk = (a.N + 31) / 32, n_tiles = tiles_per_chunk * a.n_chunks;
+    double loss_acc = 0.0;  // this lane's share of the loss sum (fused-loss modes), folded once after the walk
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         asm volatile("" ::: "memory");  // keep the (tile-invariant) LDS reads inside the loop (see k_mlp)
         // chunk index and chunk bases are wave-uniform (SGPRs); everything per lane is a 32-bit element offset
@@ -124,14 +132,46 @@ __global__ __launch_bounds__(H >= 256 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
             }
         }
         // ---- output and its pre-activation gradient (made available to both lane halves)
-        float dz3[4];
+        float dz3[4], outv[4], sd[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             float v = half == 0 ? acc3[o] : 0.f;   // output row o lives in register o of the lower lane half
             v += __shfl_xor(v, 32);
             if (a.final_tanh) v = tanhf(v);
-            const float sd = o < a.n_out ? (a.seed + (size_t)c * a.n_out * a.N)[(uint32_t)o * N32 + ec] : 0.f;
-            dz3[o] = a.final_tanh ? sd * (1.f - v * v) : sd;
+            outv[o] = v;
+            sd[o] = 0.f;
+        }
+        if (a.loss_mode == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < a.n_out) sd[o] = (a.seed + (size_t)c * a.n_out * a.N)[(uint32_t)o * N32 + ec];
+        } else if (a.loss_mode == 1) {  // k_ppo_loss, actor part, same operation order
+            const float* ac = a.actions + (size_t)c * 4 * a.N;
+            const float* lo = a.old_logprob + (size_t)c * 4 * a.N;
+            float lp = 0.f, lp_old = 0.f, d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = ac[(uint32_t)k * N32 + ec] - outv[k];
+                lp += -0.5f * d[k] * d[k] * a.inv_var + a.log_norm;
+                lp_old += lo[(uint32_t)k * N32 + ec];
+            }
+            const float ratio = (float)exp((double)(lp - lp_old));
+            const float A = (a.adv + (size_t)c * a.N)[ec];
+            const float clipped = fminf(fmaxf(ratio, 1.f - a.eps_clip), 1.f + a.eps_clip);
+            const float s1 = ratio * A, s2 = clipped * A;
+            const bool use1 = s1 <= s2;  // torch.min picks surr1 on ties
+            const bool live = use1 || (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sd[k] = live ? -A * ratio * d[k] * a.inv_var * a.inv_B : 0.f;
+            if (valid && half == 0) loss_acc += -(double)(use1 ? s1 : s2);
+        } else {  // critic: c_value * (V - ret)^2
+            const float err = outv[0] - (a.returns + (size_t)c * a.N)[ec];
+            sd[0] = 2.f * a.c_value * err * a.inv_B;
+            if (valid && half == 0) loss_acc += (double)err * (double)err;
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            dz3[o] = a.final_tanh ? sd[o] * (1.f - outv[o] * outv[o]) : sd[o];
             if (valid && half == 0) (a.dz3 + (size_t)c * 4 * a.N)[(uint32_t)o * N32 + ec] = dz3[o];
         }
         // ---- store H1, H2; dZ2 = (W3^T dz3) (1 - H2^2) in place of H2
@@ -183,6 +223,11 @@ __global__ __launch_bounds__(H >= 256 ? 256 : 512) void k_mlp_bwd(const BwdArgs 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (a.loss_mode != 0) {  // one atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_xor(loss_acc, off);
+        if (lane == 0) atomicAdd(&a.sums[a.loss_mode], loss_acc);
+    }
 }
 
 // ---- weight gradients: C[M][Nn] += sum over samples A[m][s] * B[n][s]  (+ row sums of A = bias gradients)
@@ -199,7 +244,7 @@ struct WgradArgs {
 // conflict free); each of the 4 waves owns up to MT*NT/4 of the 32x32 output tiles in registers for the
 // whole walk and adds them to C once at the end.
 template <int MT, int NTN>
-__global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 256 VGPRs: two workgroups per CU (2 waves per SIMD), or one wave alone exposes every LDS / barrier wait
+__global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 256 VGPRs: two workgroups per CU (2 waves per SIMD), or one wave alone exposes every LDS / barrier wait  // <= 256 VGPRs: two workgroups per CU (2 waves per SIMD), or one wave alone exposes every LDS / barrier wait
     constexpr int LD = 65, TPW = (MT * NTN + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                 // [MT*32][65]
@@ -256,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 25
             for (int i = 0; i < 8 * MT; ++i) rsum[i] += pre[i];
         }
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
-#pragma unroll 2
+#pragma unroll 4
         for (int ks = 0; ks < 32; ++ks) {
             const int sidx = 2 * ks + half;
             float a0 = 0.f;
@@ -284,15 +329,17 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 25
             }
         }
     }
-    if (a.rowsum) {
+    if (a.rowsum) {  // lane i ends up with the total of row wave + 4 i: ONE atomic instruction per wave (a single-lane
+        float mine = 0.f;  // atomic per row is 32 requests per wave on 128 hot addresses: +50 us on a 25 us launch)
 #pragma unroll
         for (int i = 0; i < 8 * MT; ++i) {
             float v = rsum[i];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-            const int r = wave + 4 * i;
-            if (lane == 0 && r < a.M) atomicAdd(&a.rowsum[r], v);
+            if (lane == i) mine = v;
         }
+        const int r = wave + 4 * lane;
+        if (lane < 8 * MT && r < a.M) atomicAdd(&a.rowsum[r], mine);
     }
 }
 
@@ -324,6 +371,8 @@ using namespace qenv;
 
 extern "C" {
 
+static int launch_bwd(BwdArgs& a, int hidden, void* stream);
+
 int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_out, int final_tanh, const float* obs,
                       const float* seed, const float* W1, const float* b1, const float* W2, const float* b2,
                       const float* W3, const float* b3, float* h1, float* h2, float* dz2, float* dz1, float* dz3,
@@ -331,25 +380,66 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
     if (!obs || !seed || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !h1 || !h2 || !dz2 || !dz1 || !dz3)
         return fail(QENV_ERR_ARG, "qenv_mlp_backward: null argument");
     if (n_envs <= 0 || n_chunks <= 0 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_backward: bad sizes");
-    if ((int64_t)(hidden > k_in ? hidden : k_in) * n_envs >= ((int64_t)1 << 31))
-        return fail(QENV_ERR_ARG, "qenv_mlp_backward: rows*n_envs per chunk must stay below 2^31 (32-bit offsets)");
     BwdArgs a;
     a.N = n_envs; a.n_chunks = n_chunks; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh;
     a.obs = obs; a.seed = seed; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
     a.h1 = h1; a.h2 = h2; a.dz2 = dz2; a.dz1 = dz1; a.dz3 = dz3;
+    a.loss_mode = 0; a.actions = a.old_logprob = a.adv = a.returns = nullptr; a.sums = nullptr;
+    a.inv_var = a.log_norm = a.eps_clip = a.c_value = a.inv_B = 0.f;
+    return launch_bwd(a, hidden, stream);
+}
+
+int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float* obs,
+                          const float* actions, const float* old_logprob, const float* adv, const float* returns,
+                          double std, double eps_clip, double c_value, int64_t batch, double* sums, const float* W1,
+                          const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* h1,
+                          float* h2, float* dz2, float* dz1, float* dz3, void* stream) {
+    if (!obs || !sums || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !h1 || !h2 || !dz2 || !dz1 || !dz3)
+        return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: null argument");
+    if (head != 0 && head != 1) return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: head must be 0 (actor) or 1 (critic)");
+    if (head == 0 && (!actions || !old_logprob || !adv)) return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: the actor needs actions, old_logprob, adv");
+    if (head == 1 && !returns) return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: the critic needs returns");
+    if (n_envs <= 0 || n_chunks <= 0 || k_in <= 0 || batch <= 0) return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: bad sizes");
+    if (!(std > 0)) return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: std must be positive");
+    BwdArgs a;
+    a.N = n_envs; a.n_chunks = n_chunks; a.K = k_in; a.n_out = head == 0 ? 4 : 1; a.final_tanh = head == 0;
+    a.obs = obs; a.seed = nullptr; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+    a.h1 = h1; a.h2 = h2; a.dz2 = dz2; a.dz1 = dz1; a.dz3 = dz3;
+    a.loss_mode = head == 0 ? 1 : 2; a.actions = actions; a.old_logprob = old_logprob; a.adv = adv; a.returns = returns;
+    a.inv_var = (float)(1.0 / (std * std)); a.log_norm = (float)(-std::log(std) - 0.9189385332046727);
+    a.eps_clip = (float)eps_clip; a.c_value = (float)c_value; a.inv_B = 1.f / (float)batch;
+    a.sums = sums;
+    return launch_bwd(a, hidden, stream);
+}
+
+static int launch_bwd(BwdArgs& a, int hidden, void* stream) {
+    const int64_t n_envs = a.N;
+    const int n_chunks = a.n_chunks, k_in = a.K;
+    if ((int64_t)(hidden > k_in ? hidden : k_in) * n_envs >= ((int64_t)1 << 31))
+        return fail(QENV_ERR_ARG, "qenv_mlp_backward: rows*n_envs per chunk must stay below 2^31 (32-bit offsets)");
     const int HP = hidden < 32 ? 32 : hidden, K1P = (k_in + 1) & ~1;
     const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)HP * (HP + 1) + 32 * HP + 4 * HP + 2 * HP + 32);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_backward: weights do not fit the 160 KiB LDS");
     const int64_t n_tiles = ((n_envs + 31) / 32) * n_chunks;
-    const int wpb = hidden >= 128 ? 4 : 8;
+    // two waves per SIMD (512 threads) overlap one wave's tanh / stores / LDS waits with the other's MFMAs once every
+    // wave has several tiles; with at most one tile per wave they only share the pipe (a 256-env x 32-step update:
+    // 60 us with 256 threads, 84 us with 512), so small batches keep one wave per SIMD on twice as many CUs
+    const bool wide = n_tiles > 1024;
+    const int wpb = wide ? 8 : 4;
     int64_t blocks = (n_tiles + wpb - 1) / wpb;
     if (blocks > 256) blocks = 256;
     hipError_t e;
 #define QENV_BWD_CASE(HH)                                                                                                   \
     case HH:                                                                                                                 \
-        e = hipFuncSetAttribute((const void*)k_mlp_bwd<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd)");                                           \
-        hipLaunchKernelGGL((k_mlp_bwd<HH>), dim3((unsigned)blocks), dim3(HH >= 256 ? 256 : 512), lds, (hipStream_t)stream, a);                 \
+        if (wide) {                                                                                                          \
+            e = hipFuncSetAttribute((const void*)k_mlp_bwd<HH, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd)");                                       \
+            hipLaunchKernelGGL((k_mlp_bwd<HH, 512>), dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, a);        \
+        } else {                                                                                                             \
+            e = hipFuncSetAttribute((const void*)k_mlp_bwd<HH, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd)");                                       \
+            hipLaunchKernelGGL((k_mlp_bwd<HH, 256>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);        \
+        }                                                                                                                    \
         break;
     switch (hidden) {
         QENV_BWD_CASE(16) QENV_BWD_CASE(32) QENV_BWD_CASE(64) QENV_BWD_CASE(128)

@@ -193,6 +193,7 @@ class PpoLearner:
         self.eps_clip, self.c_value, self.c_entropy, self.K_epochs = eps_clip, c_value, c_entropy, K_epochs
         self.step = 0
         self.group = group
+        self.fused_loss = weights.hidden in (16, 32, 64, 128)  # False: forward, qenv_ppo_loss and backward as separate launches
         from .distributed import GradBucket
         keys = [(head, k) for head in ("actor", "critic") for k in range(6)]
         self.bucket = GradBucket([weights.head(h)[k] for h, k in keys])  # every .grad is a slice of one flat buffer
@@ -219,6 +220,8 @@ class PpoLearner:
         stream = _stream(dev)
         f32 = lambda t: t.to(torch.float32).contiguous()
         obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
+        if self.fused_loss:
+            return self._gradients_fused(obs, actions, old_logprob, adv, returns, b)
         # forward of both heads on the stored observations (the dense kernel takes feature-major chunks)
         for head, out, ft in (("actor", b["mean"], True), ("critic", b["value"], False)):
             W = w.head(head)  # all n stored steps in one launch
@@ -247,6 +250,38 @@ class PpoLearner:
                         "qenv_weight_grad")
         self.bucket.all_reduce_mean_(self.group)
         return loss
+
+    def _gradients_fused(self, obs, actions, old_logprob, adv, returns, b):
+        """The same update with the loss inside the backward kernel: per head one backward launch (which recomputes
+        the forward anyway and derives d loss / d output from it) + three weight-gradient launches; no forward launch,
+        no loss launch, no [n, r, N] <-> [r, n N] copies."""
+        n, K, N = obs.shape
+        w, H, stream = self.w, self.w.hidden, _stream(obs.device)
+        sums = torch.zeros(4, dtype=torch.float64, device=obs.device)
+        std = float(w.std)
+        for hid, head in enumerate(("actor", "critic")):
+            W = w.head(head)
+            n_out = W[4].shape[0]
+            L.check(L.lib.qenv_mlp_backward_ppo(N, n, K, H, hid, L.ptr(obs), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
+                                                L.ptr(returns), std, float(self.eps_clip), float(self.c_value), n * N,
+                                                L.ptr(sums), *[L.ptr(x) for x in W], L.ptr(b["h1"]), L.ptr(b["h2"]),
+                                                L.ptr(b["dz2"]), L.ptr(b["dz1"]), L.ptr(b["dz3"]), stream),
+                    "qenv_mlp_backward_ppo")
+            g = [self._state[(head, k)][0] for k in range(6)]
+            for t in g:
+                t.zero_()
+            dz3 = b["dz3"] if n_out == 4 else b["dz3"][:, :n_out].contiguous()
+            for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
+                                                 (b["dz1"], H, obs, K, g[0], g[1])):
+                L.check(L.lib.qenv_weight_grad(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb), stream),
+                        "qenv_weight_grad")
+        self.bucket.all_reduce_mean_(self.group)
+        B = float(n * N)
+        actor = sums[1] / B
+        critic = self.c_value * sums[2] / B
+        entropy = torch.full((), -self.c_entropy * 4.0 * (0.5 + 0.9189385332046727 + float(np.log(std))), dtype=torch.float64,
+                             device=obs.device)
+        return {"loss": actor + critic + entropy, "actor": actor, "critic": critic, "entropy": entropy}
 
     def adam_step(self):
         self.step += 1

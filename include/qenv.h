@@ -357,6 +357,18 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
                       const float *obs, const float *seed, const float *W1, const float *b1,
                       const float *W2, const float *b2, const float *W3, const float *b3, float *h1,
                       float *h2, float *dz2, float *dz1, float *dz3, void *stream);
+/* qenv_mlp_backward with the PPO loss of one head fused in (ppo.py:185-199): the seed d loss.mean() / d output is
+ * computed inside the backward kernel from the forward it recomputes anyway, so an update needs neither a separate
+ * forward launch nor qenv_ppo_loss.  head 0 = actor (75-H-H-4, tanh; clipped surrogate from actions / old_logprob
+ * [c][4][N] and adv [c][N]; adds the surrogate sum to sums[1]), head 1 = critic (75-H-H-1; c_value * MSE against
+ * returns [c][N]; adds the sum of squared errors to sums[2]).  batch = number of samples the loss is averaged over
+ * (n_chunks * n_envs on one learner).  sums as in qenv_ppo_loss (caller zeroes; [0] and [3] are the caller's).
+ * Same arithmetic and operation order as qenv_ppo_loss + qenv_mlp_backward. */
+int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float *obs,
+                          const float *actions, const float *old_logprob, const float *adv, const float *returns,
+                          double std, double eps_clip, double c_value, int64_t batch, double *sums, const float *W1,
+                          const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                          float *h1, float *h2, float *dz2, float *dz1, float *dz3, void *stream);
 int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float *A, const float *B,
                      float *C, float *rowsum, void *stream);
 int qenv_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, double lr, double beta1,

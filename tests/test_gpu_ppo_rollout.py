@@ -236,10 +236,13 @@ def _torch_nets(w, dtype=torch.float64):
     return net(w.actor, True), net(w.critic, False)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("hidden", [16, 32, 64, 128])
-def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden):
+def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden, fused):
     """Backward pass (MFMA), weight/bias gradients (split-K GEMM) and the Adam step of PpoLearner against torch
-    autograd + torch.optim.Adam on the reference's loss (ppo.py:185-203), fp64 torch as the yardstick."""
+    autograd + torch.optim.Adam on the reference's loss (ppo.py:185-203), fp64 torch as the yardstick.  fused: the
+    loss evaluated inside the backward kernel (qenv_mlp_backward_ppo, the default) or forward / qenv_ppo_loss /
+    backward as separate launches."""
     torch.manual_seed(0)
     n, N, K = 3, 200, 75
     w = aq.ActorCriticWeights.random(hidden, K, 4, seed=3)
@@ -253,7 +256,10 @@ def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden):
     old_lp = old_lp.permute(0, 2, 1).float().contiguous()
     adv = torch.randn(n, N, device="cuda"); rets = 2 * torch.randn(n, N, device="cuda")
     learner = aq.PpoLearner(w, K_epochs=1)
+    assert learner.fused_loss
+    learner.fused_loss = fused
     loss = learner.gradients(obs, actions, old_lp, adv, rets)
+    assert abs(float(loss["loss"]) - float(loss["actor"] + loss["critic"] + loss["entropy"])) < 1e-12
     # torch reference of the same loss
     x = obs.permute(0, 2, 1).double()
     mean = act_net(x); value = cri_net(x).squeeze(-1)
