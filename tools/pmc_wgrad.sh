@@ -2,7 +2,7 @@
 # GPU box: SQ counters of k_wgrad / k_mlp_bwd at config-5 scale (tools/time_wgrad.py).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_wgrad; rm -rf $OUT; mkdir -p $OUT
-ARGS="tools/time_wgrad.py"
+ARGS="${1:-tools/time_wgrad.py}"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1 || echo "a failed"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/b -- python3 $ARGS > $OUT/b.log 2>&1 || echo "b failed"
 python3 - <<'PY'
