@@ -241,34 +241,40 @@ struct WgradArgs {
 
 // One workgroup walks a strided set of 64-sample tiles: both operand tiles are staged in LDS ([row][65]: the
 // 64-sample rows are written coalesced, the MFMA operands -- 32 rows at a fixed sample -- read stride 65,
-// conflict free); each of the 4 waves owns up to MT*NT/4 of the 32x32 output tiles in registers for the
-// whole walk and adds them to C once at the end.
-template <int MT, int NTN>
-__global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 256 VGPRs: two workgroups per CU (2 waves per SIMD), or one wave alone exposes every LDS / barrier wait  // <= 256 VGPRs: two workgroups per CU (2 waves per SIMD), or one wave alone exposes every LDS / barrier wait
-    constexpr int LD = 65, TPW = (MT * NTN + 3) / 4;
+// conflict free); each of the NW waves owns up to ceil(MT*NT/NW) of the 32x32 output tiles in registers for the
+// whole walk and adds them to C once at the end.  Two workgroups per CU (NW/2 waves per SIMD): a wave's staging,
+// barrier and LDS waits are covered by the MFMAs of the other (one workgroup of 4 waves per CU: matrix pipe 44 %
+// busy; two: 60 %).
+template <int MT, int NTN, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) {  // NW/2 waves per SIMD = two workgroups per CU
+    constexpr int LD = 65, ROWS = (MT + NTN) * 32, TPW = (MT * NTN + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                 // [MT*32][65]
     float* Bs = As + MT * 32 * LD;   // [NTN*32][65]
-    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    // Tile ownership from the wave index in an SGPR: as a VGPR value every MFMA of the k loop sat in its own exec-masked
+    // basic block with its LDS operand read issued right in front of it (s_waitcnt lgkmcnt(0)).  Worth 0 / 5 / 4 % on
+    // dW2 / dW1 / dW3 (the matrix loop is not what limits the kernel); the prefetch / staging addressing keeps the VGPR
+    // copy -- with the scalar one its 64 per-row predicates become scalar branches and the kernel is 15 % SLOWER (A/B).
+    const int wave = (int)(threadIdx.x >> 6);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    constexpr bool FULL = (MT * NTN) % NW == 0;  // every wave owns exactly TPW tiles
     const int64_t tiles_per_chunk = (a.N + 63) / 64, n_tiles = tiles_per_chunk * a.n_chunks;
     f32x16 acc[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
-    // bias gradients = row sums of A: every thread already holds, in `pre`, the elements of rows wave + 4 i at its own
-    // sample, so it accumulates them in registers (no LDS reads, the four waves stay balanced) and the 64 samples of a
-    // row are folded across the wave once, after the walk
-    float rsum[8 * MT];
-#pragma unroll
-    for (int i = 0; i < 8 * MT; ++i) rsum[i] = 0.f;
     // Every thread carries its share of the NEXT 64-sample tile in registers: the global loads are issued right after
-    // the current tile has been copied to LDS and land while its MFMAs run (the staging latency used to be exposed
-    // between two barriers).  PER = elements per thread and tile.
-    constexpr int PER = (MT + NTN) * 32 * 64 / 256;
+    // the current tile has been copied to LDS and land while its MFMAs run.  Element i of a thread is row wave + NW i
+    // of the combined [A rows | B rows] image at sample `lane` (the A / B decision is wave-uniform).
+    constexpr int PER = (ROWS + NW - 1) / NW, PER_A = (MT * 32 + NW - 1) / NW;
     float pre[PER];
-    // element i of a thread is row wave + 4 i of the combined [A rows | B rows] image at sample lane: rows
-    // 0..MT*32-1 = A (i < 8 MT), the rest = B -- one 64-bit base per operand and tile, then 32-bit row strides
+    // bias gradients = row sums of A: accumulated from `pre` in registers (no LDS reads, the waves stay balanced);
+    // the 64 samples of a row are folded across the wave once, after the walk
+    float rsum[PER_A];
+#pragma unroll
+    for (int i = 0; i < PER_A; ++i) rsum[i] = 0.f;
     auto fetch = [&](int64_t tile) {
         const int64_t c = tile / tiles_per_chunk, e0 = (tile % tiles_per_chunk) * 64;  // block-uniform
         const bool inb = e0 + lane < a.N;
@@ -278,50 +284,61 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 25
         asm volatile("" : "+s"(n32));  // opaque per tile: LICM would otherwise keep all PER row offsets live across the walk
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int r = wave + 4 * i;
-            if (i < 8 * MT) pre[i] = (r < a.M && inb) ? pa[(uint32_t)r * n32] : 0.f;
-            else pre[i] = ((r - MT * 32) < a.Nn && inb) ? pb[(uint32_t)(r - MT * 32) * n32] : 0.f;
+            const int r = wave + NW * i;
+            if (r < MT * 32) pre[i] = (r < a.M && inb) ? pa[(uint32_t)r * n32] : 0.f;
+            else pre[i] = (r < ROWS && (r - MT * 32) < a.Nn && inb) ? pb[(uint32_t)(r - MT * 32) * n32] : 0.f;
         }
     };
-    // the tiles a wave owns are consecutive; when they all sit in one row of output tiles the A operand of a k-step is
-    // read once for all of them (5 LDS reads per 4 MFMAs instead of 8)
+    // the tiles a wave owns are consecutive in row-major order when they then share a row of output tiles (one A
+    // operand read per k-step for all of them), else in column-major order when that makes them share a column (B)
     constexpr bool SAME_A = (NTN % TPW) == 0;
-    const int tid0 = wave * TPW;
+    constexpr bool SAME_B = !SAME_A && (MT % TPW) == 0;
+    const int tid0 = wave_s * TPW;
+    auto tile_of = [&](int tid, int& tm, int& tn) {
+        if (SAME_B) { tm = tid % MT; tn = tid / MT; }
+        else { tm = tid / NTN; tn = tid % NTN; }
+    };
     if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();  // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int idx = threadIdx.x + 256 * i, r = idx >> 6, sidx = idx & 63;
-            lds[r * LD + sidx] = pre[i];  // As and Bs are contiguous: row r of the combined [ (MT+NTN)*32 ][65] image
+            const int r = wave + NW * i;
+            if (r < ROWS) lds[r * LD + lane] = pre[i];  // As and Bs are contiguous: row r of the combined [ROWS][65] image
         }
         __syncthreads();
         if (a.rowsum) {
 #pragma unroll
-            for (int i = 0; i < 8 * MT; ++i) rsum[i] += pre[i];
+            for (int i = 0; i < PER_A; ++i) rsum[i] += (wave + NW * i < MT * 32) ? pre[i] : 0.f;
         }
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        int tm0, tn0;
+        tile_of(tid0, tm0, tn0);
 #pragma unroll 4
         for (int ks = 0; ks < 32; ++ks) {
             const int sidx = 2 * ks + half;
-            float a0 = 0.f;
-            if (SAME_A) a0 = As[(32 * (tid0 / NTN) + col) * LD + sidx];
+            float a0 = 0.f, b0 = 0.f;
+            if (SAME_A) a0 = As[(32 * tm0 + col) * LD + sidx];
+            if (SAME_B) b0 = Bs[(32 * tn0 + col) * LD + sidx];
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
                 const int tid = tid0 + q;
-                if (tid < MT * NTN) {
-                    const int tm = tid / NTN, tn = tid % NTN;
+                if (FULL || tid < MT * NTN) {
+                    int tm, tn;
+                    tile_of(tid, tm, tn);
                     const float av = SAME_A ? a0 : As[(32 * tm + col) * LD + sidx];
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[(32 * tn + col) * LD + sidx], acc[q], 0, 0, 0);
+                    const float bv = SAME_B ? b0 : Bs[(32 * tn + col) * LD + sidx];
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
                 }
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int tid = wave * TPW + q;
-        if (tid < MT * NTN) {
-            const int tm = tid / NTN, tn = tid % NTN;
+        const int tid = wave_s * TPW + q;
+        if (FULL || tid < MT * NTN) {
+            int tm, tn;
+            tile_of(tid, tm, tn);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int m = 32 * tm + acc_row(j, half), n = 32 * tn + col;
@@ -329,27 +346,30 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {  // <= 25
             }
         }
     }
-    if (a.rowsum) {  // lane i ends up with the total of row wave + 4 i: ONE atomic instruction per wave (a single-lane
+    if (a.rowsum) {  // lane i ends up with the total of row wave + NW i: ONE atomic instruction per wave (a single-lane
         float mine = 0.f;  // atomic per row is 32 requests per wave on 128 hot addresses: +50 us on a 25 us launch)
 #pragma unroll
-        for (int i = 0; i < 8 * MT; ++i) {
+        for (int i = 0; i < PER_A; ++i) {
             float v = rsum[i];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
             if (lane == i) mine = v;
         }
-        const int r = wave + 4 * lane;
-        if (lane < 8 * MT && r < a.M) atomicAdd(&a.rowsum[r], mine);
+        const int r = wave + NW * lane;
+        if (lane < PER_A && r < MT * 32 && r < a.M) atomicAdd(&a.rowsum[r], mine);
     }
 }
 
 template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+    // NW = 8 / 6 (4 / 3 waves per SIMD with two workgroups per CU) was measured and is NOT used: under the 128 / 168 VGPR cap
+    // hipcc shuttles the accumulator tiles between VGPRs and AGPRs around every MFMA (dW2 3.0 -> 4.9 ms, dW1 2.4 -> 5.8 ms)
+    constexpr int NW = 4;
     const size_t lds = sizeof(float) * (size_t)(MT + NTN) * 32 * 65;
-    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<MT, NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_wgrad)");
     const int64_t n_tiles = ((a.N + 63) / 64) * a.n_chunks;
     const int64_t blocks = n_tiles < 512 ? n_tiles : 512;
-    hipLaunchKernelGGL((k_wgrad<MT, NTN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<MT, NTN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_wgrad)");
+    hipLaunchKernelGGL((k_wgrad<MT, NTN, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
     return check_launch("k_wgrad");
 }
 
