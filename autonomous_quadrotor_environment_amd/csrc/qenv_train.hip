@@ -27,6 +27,19 @@ struct BwdArgs {
     double* sums;                // qenv_ppo_loss's {B, sum actor, sum (V - ret)^2, entropy * B}: [1] (mode 1) or [2] (mode 2) accumulated
 };
 
+// Stores of a tile go through raw buffer instructions: a lane beyond the chunk (e >= N in the last tile of a chunk) or a
+// padded hidden row gets the offset 0xFFFFFFFF and the hardware's range check drops it -- no exec-masked branch per
+// store between the MFMAs (the predicated global stores put 130 branches into a tile's instruction stream), and
+// no address VGPRs: one per-lane offset register serves every store of the tile, the row offset is scalar.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(float* base, uint32_t rows, uint32_t n32) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows * n32 * 4u), 0x00020000);
+}
+// voff: the lane's byte offset inside a row pair (or 2^31 for a lane that must not store: with rows*N*4 < 2^31 the
+// sum stays beyond num_records without wrapping); soff: the row's byte offset, wave-uniform (SALU, no VGPR per store)
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);  // b32 = an integer operand: a float would be CONVERTED
+}
+
 // Forward (recomputed) + backward through the activations for one 32-sample tile per wave:
 //   H1 = tanh(W1 x + b1), H2 = tanh(W2 H1 + b2), out = [tanh](W3 H2 + b3)
 //   dz3 = seed * (1 - out^2 | 1), dZ2 = (W3^T dz3) * (1 - H2^2), dZ1 = (W2^T dZ2) * (1 - H1^2)
@@ -132,6 +145,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
             }
         }
         // ---- output and its pre-activation gradient (made available to both lane halves)
+        const __amdgpu_buffer_rsrc_t r_dz3 = rows_rsrc(a.dz3 + (size_t)c * 4 * a.N, 4, N32);
         float dz3[4], outv[4], sd[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -172,13 +186,14 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             dz3[o] = a.final_tanh ? sd[o] * (1.f - outv[o] * outv[o]) : sd[o];
-            if (valid && half == 0) (a.dz3 + (size_t)c * 4 * a.N)[(uint32_t)o * N32 + ec] = dz3[o];
+            bstore(r_dz3, (valid && half == 0) ? ec * 4u : 0x80000000u, (uint32_t)o * N32 * 4u, dz3[o]);
         }
         // ---- store H1, H2; dZ2 = (W3^T dz3) (1 - H2^2) in place of H2
-        float* const h1c = a.h1 + (size_t)c * H * a.N;
-        float* const h2c = a.h2 + (size_t)c * H * a.N;
-        float* const dz2c = a.dz2 + (size_t)c * H * a.N;
-        float* const dz1c = a.dz1 + (size_t)c * H * a.N;
+        const uint32_t voff = valid ? (ec + 4u * (uint32_t)half * N32) * 4u : 0x80000000u;  // rows r and r + 4 share a register
+        const __amdgpu_buffer_rsrc_t h1c = rows_rsrc(a.h1 + (size_t)c * H * a.N, H, N32);
+        const __amdgpu_buffer_rsrc_t h2c = rows_rsrc(a.h2 + (size_t)c * H * a.N, H, N32);
+        const __amdgpu_buffer_rsrc_t dz2c = rows_rsrc(a.dz2 + (size_t)c * H * a.N, H, N32);
+        const __amdgpu_buffer_rsrc_t dz1c = rows_rsrc(a.dz1 + (size_t)c * H * a.N, H, N32);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             // dH2 tile = W3^T dz3: A[i = h][k = o] = W3[o][h], B[k = o][env] = dz3[o]; k-step s pairs o = 2s | 2s+1
@@ -191,12 +206,11 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int h = 32 * t + acc_row(j, half);
-                if (valid && h < H) {
-                    h1c[(uint32_t)h * N32 + ec] = h1[t][j];
-                    h2c[(uint32_t)h * N32 + ec] = h2[t][j];
-                }
+                const bool row_ok = 32 * t + 8 * (j >> 2) < H;  // compile time: a group of 8 rows is padding as a whole
+                const uint32_t soff = (uint32_t)(32 * t + 8 * (j >> 2) + (j & 3)) * N32 * 4u;
+                if (row_ok) { bstore(h1c, voff, soff, h1[t][j]); bstore(h2c, voff, soff, h2[t][j]); }
                 h2[t][j] = g[j] * (1.f - h2[t][j] * h2[t][j]);
-                if (valid && h < H) dz2c[(uint32_t)h * N32 + ec] = h2[t][j];
+                if (row_ok) bstore(dz2c, voff, soff, h2[t][j]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
             for (int j = 0; j < 16; ++j) {
                 const int h = 32 * t + acc_row(j, half);
                 const float g = d[j] * (1.f - h1[t][j] * h1[t][j]);
-                if (valid && h < H) dz1c[(uint32_t)h * N32 + ec] = g;
+                if (32 * t + 8 * (j >> 2) < H) bstore(dz1c, voff, (uint32_t)(32 * t + 8 * (j >> 2) + (j & 3)) * N32 * 4u, g);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -435,8 +449,8 @@ int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, in
 static int launch_bwd(BwdArgs& a, int hidden, void* stream) {
     const int64_t n_envs = a.N;
     const int n_chunks = a.n_chunks, k_in = a.K;
-    if ((int64_t)(hidden > k_in ? hidden : k_in) * n_envs >= ((int64_t)1 << 31))
-        return fail(QENV_ERR_ARG, "qenv_mlp_backward: rows*n_envs per chunk must stay below 2^31 (32-bit offsets)");
+    if ((int64_t)(hidden > k_in ? hidden : k_in) * n_envs >= ((int64_t)1 << 29))
+        return fail(QENV_ERR_ARG, "qenv_mlp_backward: rows*n_envs per chunk must stay below 2^29 (32-bit byte offsets, range-checked stores)");
     const int HP = hidden < 32 ? 32 : hidden, K1P = (k_in + 1) & ~1;
     const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)HP * (HP + 1) + 32 * HP + 4 * HP + 2 * HP + 32);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_backward: weights do not fit the 160 KiB LDS");
