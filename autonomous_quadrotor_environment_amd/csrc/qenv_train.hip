@@ -289,18 +289,29 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) { 
     float rsum[PER_A];
 #pragma unroll
     for (int i = 0; i < PER_A; ++i) rsum[i] = 0.f;
+    // Range-checked raw buffer loads: one per-lane offset register (the sample; 2^31 for a lane beyond the chunk), the
+    // row offset in soffset (scalar), rows >= M / Nn and parked lanes come back as 0 from the hardware's range check --
+    // no predicate, no branch and no address VGPR per load (the predicated global loads were 64 exec-masked blocks).
     auto fetch = [&](int64_t tile) {
         const int64_t c = tile / tiles_per_chunk, e0 = (tile % tiles_per_chunk) * 64;  // block-uniform
-        const bool inb = e0 + lane < a.N;
-        const float* __restrict__ pa = a.A + ((size_t)c * a.M) * a.N + e0 + lane;
-        const float* __restrict__ pb = a.B + ((size_t)c * a.Nn) * a.N + e0 + lane;
         uint32_t n32 = (uint32_t)a.N;
-        asm volatile("" : "+s"(n32));  // opaque per tile: LICM would otherwise keep all PER row offsets live across the walk
+        asm volatile("" : "+s"(n32));  // opaque per tile: keeps LICM from carrying per-row values across the walk
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + ((size_t)c * a.M) * a.N), 0,
+                                                                            (int)((uint32_t)a.M * n32 * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + ((size_t)c * a.Nn) * a.N), 0,
+                                                                            (int)((uint32_t)a.Nn * n32 * 4u), 0x00020000);
+        const uint32_t voff = (e0 + lane < a.N) ? (uint32_t)(e0 + lane) * 4u : 0x80000000u;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int r = wave + NW * i;
-            if (r < MT * 32) pre[i] = (r < a.M && inb) ? pa[(uint32_t)r * n32] : 0.f;
-            else pre[i] = (r < ROWS && (r - MT * 32) < a.Nn && inb) ? pb[(uint32_t)(r - MT * 32) * n32] : 0.f;
+            const int r = wave_s + NW * i;  // scalar
+            if (NW * i + NW - 1 < MT * 32)  // compile time: every wave's element i is an A row
+                pre[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, voff, (uint32_t)r * n32 * 4u, 0));
+            else if (NW * i >= MT * 32)     // ... a B row
+                pre[i] = r < ROWS ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, voff, (uint32_t)(r - MT * 32) * n32 * 4u, 0)) : 0.f;
+            else if (r < MT * 32)
+                pre[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, voff, (uint32_t)r * n32 * 4u, 0));
+            else
+                pre[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, voff, (uint32_t)(r - MT * 32) * n32 * 4u, 0));
         }
     };
     // the tiles a wave owns are consecutive in row-major order when they then share a row of output tiles (one A
@@ -488,8 +499,8 @@ int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const
     if (!A || !B || !C) return fail(QENV_ERR_ARG, "qenv_weight_grad: null argument");
     if (n_envs <= 0 || n_chunks <= 0 || m_rows < 1 || m_rows > 128 || n_rows < 1 || n_rows > 128)
         return fail(QENV_ERR_ARG, "qenv_weight_grad: rows must be 1..128");
-    if ((int64_t)128 * n_envs >= ((int64_t)1 << 32))
-        return fail(QENV_ERR_ARG, "qenv_weight_grad: 128*n_envs must stay below 2^32 (32-bit row offsets inside a chunk)");
+    if ((int64_t)128 * n_envs >= ((int64_t)1 << 29))
+        return fail(QENV_ERR_ARG, "qenv_weight_grad: 128*n_envs must stay below 2^29 (32-bit byte offsets, range-checked loads)");
     WgradArgs a;
     a.N = n_envs; a.n_chunks = n_chunks; a.M = m_rows; a.Nn = n_rows; a.A = A; a.B = B; a.C = C; a.rowsum = rowsum;
     const int mt = (m_rows + 31) / 32, nt = (n_rows + 31) / 32;
