@@ -85,6 +85,10 @@ SYMBOLS = {
     "qenv_mlp_backward": (_i, [_i64, _i, _i, _i, _i, _i] + [_vp] * 14),
     "qenv_mlp_backward_ppo": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 5 + [C.c_double] * 3 + [_i64] + [_vp] * 13),
     "qenv_weight_grad": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_weight_grad_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "qenv_weight_grad_deterministic": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_gae_workspace_bytes": (C.c_size_t, [_i64]),
+    "qenv_gae_deterministic": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adam_step": (_i, [_i64, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp]),
     "qenv_debug_copy_rows": (_i, [_i, _vp, _vp, _i, _i64, _vp]),
 }

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void k_sensor_read(int64_t N, T* ws, T* sens, 
 // with wavefront shuffles and one double atomicAdd pair per wave.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* values, const T* masks, const T* rewards,
-                                             T* returns, T* adv, double* stats) {
+                                             T* returns, T* adv, double* stats, double* partials) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
     if (e < N) {
@@ -808,10 +808,34 @@ __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* va
             s2 += __shfl_xor(s2, off);
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&stats[1], s1);
-            atomicAdd(&stats[2], s2);
+            if (partials) {  // deterministic mode: this wave's moments to their own slot, summed in a fixed order afterwards
+                const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+                partials[2 * wv] = s1; partials[2 * wv + 1] = s2;
+            } else {
+                atomicAdd(&stats[1], s1);
+                atomicAdd(&stats[2], s2);
+            }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (double)N * (double)n_steps);
+    }
+}
+
+// out[j] += sum over i of partials[i][j], j < width, always in the same order: thread t of the single workgroup adds
+// slots t, t + 1024, ... sequentially, then a fixed LDS tree folds the 1024 partial sums
+template <typename A>
+__global__ __launch_bounds__(1024) void k_sum_slots(const A* partials, int64_t n_slots, int width, A* out) {
+    __shared__ A sh[1024];
+    for (int j = 0; j < width; ++j) {
+        A acc = A(0);
+        for (int64_t i = threadIdx.x; i < n_slots; i += 1024) acc += partials[i * width + j];
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int d = 512; d > 0; d >>= 1) {
+            if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[j] += sh[0];
+        __syncthreads();
     }
 }
 
@@ -1052,19 +1076,37 @@ int qenv_sensor_read(qenv_t q, void* sens, const void* z27, uint64_t seed, uint6
     return check_launch("k_sensor_read");
 }
 
-int qenv_gae(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,
-             void* returns, void* adv, double* stats, void* stream) {
+static int gae_impl(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,
+                    void* returns, void* adv, double* stats, double* partials, void* stream) {
     if (!values || !masks || !rewards || !returns || !adv) return fail(QENV_ERR_ARG, "qenv_gae: null argument");
     if (n_envs <= 0 || n_steps <= 0) return fail(QENV_ERR_ARG, "qenv_gae: n_envs and n_steps must be positive");
     const dim3 g((unsigned)((n_envs + 255) / 256)), b(256);
     if (dtype == QENV_F64)
         hipLaunchKernelGGL((k_gae<double>), g, b, 0, (hipStream_t)stream, n_envs, n_steps, (const double*)values,
-                           (const double*)masks, (const double*)rewards, (double*)returns, (double*)adv, stats);
+                           (const double*)masks, (const double*)rewards, (double*)returns, (double*)adv, stats, partials);
     else if (dtype == QENV_F32)
         hipLaunchKernelGGL((k_gae<float>), g, b, 0, (hipStream_t)stream, n_envs, n_steps, (const float*)values,
-                           (const float*)masks, (const float*)rewards, (float*)returns, (float*)adv, stats);
+                           (const float*)masks, (const float*)rewards, (float*)returns, (float*)adv, stats, partials);
     else return fail(QENV_ERR_ARG, "qenv_gae: bad dtype");
-    return check_launch("k_gae");
+    int rc = check_launch("k_gae");
+    if (rc == 0 && partials && stats) {
+        hipLaunchKernelGGL((k_sum_slots<double>), dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, (int64_t)g.x * 4, 2, stats + 1);
+        rc = check_launch("k_sum_slots");
+    }
+    return rc;
+}
+
+int qenv_gae(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,
+             void* returns, void* adv, double* stats, void* stream) {
+    return gae_impl(dtype, n_envs, n_steps, values, masks, rewards, returns, adv, stats, nullptr, stream);
+}
+
+size_t qenv_gae_workspace_bytes(int64_t n_envs) { return n_envs > 0 ? (size_t)((n_envs + 255) / 256) * 4 * 2 * sizeof(double) : 0; }
+
+int qenv_gae_deterministic(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks,
+                           const void* rewards, void* returns, void* adv, double* stats, void* workspace, void* stream) {
+    if (!stats || !workspace) return fail(QENV_ERR_ARG, "qenv_gae_deterministic: stats and workspace are required");
+    return gae_impl(dtype, n_envs, n_steps, values, masks, rewards, returns, adv, stats, (double*)workspace, stream);
 }
 
 int qenv_adv_normalize(int dtype, int64_t n, void* adv, const double* stats, int ddof, void* stream) {

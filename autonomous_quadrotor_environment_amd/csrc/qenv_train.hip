@@ -251,7 +251,8 @@ struct WgradArgs {
     const float *A, *B;  // chunked [c][M][N], [c][Nn][N]
     float* C;            // [M][Nn] row-major, accumulated with atomics
     float* rowsum;       // [M] or null
-};
+    float* partial;      // null, or [blocks][M*Nn + M]: every workgroup stores its sums there (deterministic mode) ...
+};                       // ... and k_sum_slots adds the slots in a fixed order
 
 // One workgroup walks a strided set of 64-sample tiles: both operand tiles are staged in LDS ([row][65]: the
 // 64-sample rows are written coalesced, the MFMA operands -- 32 rows at a fixed sample -- read stride 65,
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) { 
             }
         }
     }
+    const size_t slot = (size_t)a.M * a.Nn + a.M;
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int tid = wave_s * TPW + q;
@@ -367,7 +369,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) { 
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int m = 32 * tm + acc_row(j, half), n = 32 * tn + col;
-                if (m < a.M && n < a.Nn) atomicAdd(&a.C[(size_t)m * a.Nn + n], acc[q][j]);
+                if (m < a.M && n < a.Nn) {
+                    if (a.partial) a.partial[(size_t)blockIdx.x * slot + (size_t)m * a.Nn + n] = acc[q][j];
+                    else atomicAdd(&a.C[(size_t)m * a.Nn + n], acc[q][j]);
+                }
             }
         }
     }
@@ -381,8 +386,21 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) { 
             if (lane == i) mine = v;
         }
         const int r = wave + NW * lane;
-        if (lane < PER_A && r < MT * 32 && r < a.M) atomicAdd(&a.rowsum[r], mine);
+        if (lane < PER_A && r < MT * 32 && r < a.M) {
+            if (a.partial) a.partial[(size_t)blockIdx.x * slot + (size_t)a.M * a.Nn + r] = mine;
+            else atomicAdd(&a.rowsum[r], mine);
+        }
     }
+}
+
+// deterministic mode, second pass: element j of C (then of rowsum) = sum over the workgroups' slots in slot order
+__global__ __launch_bounds__(256) void k_sum_wgrad_slots(const float* partial, int n_slots, int64_t mn, int64_t m, float* C, float* rowsum) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= mn + m) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_slots; ++b) acc += partial[(size_t)b * (mn + m) + j];
+    if (j < mn) C[j] += acc;
+    else if (rowsum) rowsum[j - mn] += acc;
 }
 
 template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
@@ -395,7 +413,14 @@ template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream
     hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<MT, NTN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_wgrad)");
     hipLaunchKernelGGL((k_wgrad<MT, NTN, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
-    return check_launch("k_wgrad");
+    int rc = check_launch("k_wgrad");
+    if (rc == 0 && a.partial) {
+        const int64_t mn = (int64_t)a.M * a.Nn, tot = mn + a.M;
+        hipLaunchKernelGGL(k_sum_wgrad_slots, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, a.partial, (int)blocks, mn,
+                           (int64_t)a.M, a.C, a.rowsum);
+        rc = check_launch("k_sum_wgrad_slots");
+    }
+    return rc;
 }
 
 // torch.optim.Adam (ppo.py:105: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay)
@@ -494,15 +519,33 @@ static int launch_bwd(BwdArgs& a, int hidden, void* stream) {
     return check_launch("k_mlp_bwd");
 }
 
+static int wgrad_impl(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float* A, const float* B, float* C,
+                      float* rowsum, float* partial, void* stream);
+
 int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float* A, const float* B, float* C,
                      float* rowsum, void* stream) {
+    return wgrad_impl(n_envs, n_chunks, m_rows, n_rows, A, B, C, rowsum, nullptr, stream);
+}
+
+size_t qenv_weight_grad_workspace_bytes(int m_rows, int n_rows) {
+    return (m_rows < 1 || n_rows < 1) ? 0 : (size_t)512 * ((size_t)m_rows * n_rows + m_rows) * sizeof(float);
+}
+
+int qenv_weight_grad_deterministic(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float* A, const float* B,
+                                   float* C, float* rowsum, void* workspace, void* stream) {
+    if (!workspace) return fail(QENV_ERR_ARG, "qenv_weight_grad_deterministic: workspace is required");
+    return wgrad_impl(n_envs, n_chunks, m_rows, n_rows, A, B, C, rowsum, (float*)workspace, stream);
+}
+
+static int wgrad_impl(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float* A, const float* B, float* C,
+                      float* rowsum, float* partial, void* stream) {
     if (!A || !B || !C) return fail(QENV_ERR_ARG, "qenv_weight_grad: null argument");
     if (n_envs <= 0 || n_chunks <= 0 || m_rows < 1 || m_rows > 128 || n_rows < 1 || n_rows > 128)
         return fail(QENV_ERR_ARG, "qenv_weight_grad: rows must be 1..128");
     if ((int64_t)128 * n_envs >= ((int64_t)1 << 29))
         return fail(QENV_ERR_ARG, "qenv_weight_grad: 128*n_envs must stay below 2^29 (32-bit byte offsets, range-checked loads)");
     WgradArgs a;
-    a.N = n_envs; a.n_chunks = n_chunks; a.M = m_rows; a.Nn = n_rows; a.A = A; a.B = B; a.C = C; a.rowsum = rowsum;
+    a.N = n_envs; a.n_chunks = n_chunks; a.M = m_rows; a.Nn = n_rows; a.A = A; a.B = B; a.C = C; a.rowsum = rowsum; a.partial = partial;
     const int mt = (m_rows + 31) / 32, nt = (n_rows + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
 #define QENV_WG(MT_, NT_) if (mt == MT_ && nt == NT_) return launch_wgrad<MT_, NT_>(a, s);

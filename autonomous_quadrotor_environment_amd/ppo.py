@@ -111,12 +111,13 @@ class dl_in_gen:
         return self.deep_learning_input
 
 
-def gae(values, masks, rewards, ddof=0, group=None, normalize=True):
+def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministic=False):
     """PPO.get_advantages (ppo.py:125-141 ddof=0; ppo_trainer.py:133-148 ddof=1) on a
     time-major rollout: values [n+1, N], masks [n, N], rewards [n, N] device tensors.
     Returns (returns [n, N], normalised advantages [n, N]).  With `group`
     (torch.distributed) the normalisation moments are all-reduced so every shard uses the
-    global mean/std, exactly like a single learner."""
+    global mean/std, exactly like a single learner.  deterministic: the moments are summed in a fixed order instead
+    of with double-precision atomics."""
     n, N = rewards.shape
     assert values.shape == (n + 1, N) and masks.shape == (n, N)
     dt = L.F64 if values.dtype == torch.float64 else L.F32
@@ -125,8 +126,13 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True):
     adv = torch.empty_like(rewards)
     stats = torch.zeros(3, dtype=torch.float64, device=values.device)
     stream = _stream(values.device)
-    L.check(L.lib.qenv_gae(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(ret), L.ptr(adv),
-                           L.ptr(stats), stream), "qenv_gae")
+    if deterministic:  # moments summed in a fixed order (run-to-run identical normalised advantages)
+        ws = torch.empty(int(L.lib.qenv_gae_workspace_bytes(N)), dtype=torch.uint8, device=values.device)
+        L.check(L.lib.qenv_gae_deterministic(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(ret), L.ptr(adv),
+                                             L.ptr(stats), L.ptr(ws), stream), "qenv_gae_deterministic")
+    else:
+        L.check(L.lib.qenv_gae(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(ret), L.ptr(adv),
+                               L.ptr(stats), stream), "qenv_gae")
     if not normalize:
         return ret, adv
     if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized() \
@@ -184,7 +190,7 @@ class PpoLearner:
     Gradients of the weights are fp32-atomic sums over the batch (order not deterministic to the last bit)."""
 
     def __init__(self, weights: ActorCriticWeights, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, eps_clip=0.2, c_value=0.5,
-                 c_entropy=0.006, K_epochs=10, group=None):
+                 c_entropy=0.006, K_epochs=10, group=None, deterministic=False):
         """group: torch.distributed group of the data-parallel learners (None = the default group if one is
         initialised, False = never reduce).  Each rank holds an equal shard of the batch; gradients are averaged
         with one bucketed all-reduce per epoch, so every rank applies the same Adam step."""
@@ -194,6 +200,10 @@ class PpoLearner:
         self.step = 0
         self.group = group
         self.fused_loss = weights.hidden in (16, 32, 64, 128)  # False: forward, qenv_ppo_loss and backward as separate launches
+        # True: weight / bias gradients summed in a fixed order (per-workgroup slots + an ordered second pass) instead of
+        # fp32 atomics -- with gae(deterministic=True) a training run is bit-reproducible; ~3 % slower at 8.4 M samples
+        self.deterministic = bool(deterministic)
+        self._wg_ws = {}
         from .distributed import GradBucket
         keys = [(head, k) for head in ("actor", "critic") for k in range(6)]
         self.bucket = GradBucket([weights.head(h)[k] for h, k in keys])  # every .grad is a slice of one flat buffer
@@ -246,10 +256,21 @@ class PpoLearner:
             dz3 = b["dz3"] if n_out == 4 else b["dz3"][:, :n_out].contiguous()
             for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
-                L.check(L.lib.qenv_weight_grad(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb), stream),
-                        "qenv_weight_grad")
+                self._weight_grad(N, n, rows_a, rows_b, A, Bm, gw, gb, stream)
         self.bucket.all_reduce_mean_(self.group)
         return loss
+
+    def _weight_grad(self, N, n, rows_a, rows_b, A, Bm, gw, gb, stream):
+        if not self.deterministic:
+            L.check(L.lib.qenv_weight_grad(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb), stream),
+                    "qenv_weight_grad")
+            return
+        key = (rows_a, rows_b, A.device)
+        if key not in self._wg_ws:
+            self._wg_ws[key] = torch.empty(int(L.lib.qenv_weight_grad_workspace_bytes(rows_a, rows_b)), dtype=torch.uint8,
+                                           device=A.device)
+        L.check(L.lib.qenv_weight_grad_deterministic(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb),
+                                                     L.ptr(self._wg_ws[key]), stream), "qenv_weight_grad_deterministic")
 
     def _gradients_fused(self, obs, actions, old_logprob, adv, returns, b):
         """The same update with the loss inside the backward kernel: per head one backward launch (which recomputes
@@ -273,8 +294,7 @@ class PpoLearner:
             dz3 = b["dz3"] if n_out == 4 else b["dz3"][:, :n_out].contiguous()
             for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
-                L.check(L.lib.qenv_weight_grad(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb), stream),
-                        "qenv_weight_grad")
+                self._weight_grad(N, n, rows_a, rows_b, A, Bm, gw, gb, stream)
         self.bucket.all_reduce_mean_(self.group)
         B = float(n * N)
         actor = sums[1] / B
@@ -422,7 +442,7 @@ class PolicyRollout:
             self.values[:n].copy_(out)
         return self.values[:n]
 
-    def finish(self, ddof=0, group=False, bootstrap=False):
+    def finish(self, ddof=0, group=False, bootstrap=False, deterministic=False):
         """GAE over the collected steps.  bootstrap=False appends V=0 like the reference
         (ppo.py:385); True evaluates the critic on the final window."""
         n = self.t
@@ -432,4 +452,4 @@ class PolicyRollout:
             self.env.mlp_forward(self.w, "critic", out=self.values[n:n + 1])
         else:
             self.values[n].zero_()
-        return gae(self.values[:n + 1], self.masks[:n], self.rewards[:n], ddof=ddof, group=group)
+        return gae(self.values[:n + 1], self.masks[:n], self.rewards[:n], ddof=ddof, group=group, deterministic=deterministic)

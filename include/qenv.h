@@ -326,6 +326,13 @@ int qenv_outer_reset(qenv_t q, const uint8_t *mask);
  * Independent of any handle; n_envs envs scanned in parallel along time. */
 int qenv_gae(int dtype, int64_t n_envs, int n_steps, const void *values, const void *masks,
              const void *rewards, void *returns, void *adv, double *stats, void *stream);
+/* qenv_gae with run-to-run reproducible moments: each wavefront stores its partial sums in `workspace`
+ * (qenv_gae_workspace_bytes(n_envs) bytes, no initialisation needed) and a second launch adds them to stats[1..2] in a
+ * fixed order, instead of double-precision atomics whose order varies (the last bit of the normalised advantages). */
+size_t qenv_gae_workspace_bytes(int64_t n_envs);
+int qenv_gae_deterministic(int dtype, int64_t n_envs, int n_steps, const void *values, const void *masks,
+                           const void *rewards, void *returns, void *adv, double *stats, void *workspace,
+                           void *stream);
 int qenv_adv_normalize(int dtype, int64_t n_elems, void *adv, const double *stats, int ddof,
                        void *stream);
 
@@ -371,6 +378,12 @@ int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, in
                           float *h1, float *h2, float *dz2, float *dz1, float *dz3, void *stream);
 int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float *A, const float *B,
                      float *C, float *rowsum, void *stream);
+/* qenv_weight_grad with a fixed summation order (bit-reproducible gradients, hence training runs): every workgroup
+ * stores its partial C / rowsum in `workspace` (qenv_weight_grad_workspace_bytes(m_rows, n_rows) bytes, no
+ * initialisation needed) and a second launch adds the slots in slot order. */
+size_t qenv_weight_grad_workspace_bytes(int m_rows, int n_rows);
+int qenv_weight_grad_deterministic(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float *A,
+                                   const float *B, float *C, float *rowsum, void *workspace, void *stream);
 int qenv_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, double lr, double beta1,
                    double beta2, double eps, int step, void *stream);
 

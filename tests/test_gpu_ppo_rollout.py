@@ -508,3 +508,28 @@ def test_episode_return_is_the_workers_reward_sum(aq):
         env.reset_sampled(1, k + 1, 0, mask=d, push_window=True)
         assert torch.equal(env.last_return[d], total[d]) and float(env.episode_return[d].abs().max() if bool(d.any()) else 0.0) == 0.0
         total[d] = 0
+
+
+def test_deterministic_training_is_bit_reproducible(aq):
+    """PpoLearner(deterministic=True) + finish(deterministic=True): weight / bias gradients and the advantage moments are
+    summed in a fixed order instead of with atomics -- two runs of rollout -> GAE -> K epochs end with identical
+    weights, and the deterministic gradients agree with the atomic ones to summation-order noise."""
+    def run(det):
+        w = aq.ActorCriticWeights.random(64, 75, 4, seed=9)
+        env = aq.BatchedQuad(1000, 0.01, 60, training=True, direct_control=1, T=5)
+        ro = aq.PolicyRollout(env, w, 20, store_obs=True, auto_reset=True, seed=3)
+        ln = aq.PpoLearner(w, K_epochs=3, deterministic=det)
+        ro.start()
+        for _ in range(3):
+            ro.t = 0
+            for _ in range(20):
+                ro.step()
+            ret, adv = ro.finish(bootstrap=True, deterministic=det)
+            ln.update(ro, ret, adv)
+        return [t.clone() for t in w.actor + w.critic], [ln._state[k][0].clone() for k in ln._state]
+    w1, g1 = run(True)
+    w2, g2 = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(w1, w2)) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    w3, g3 = run(False)
+    for a, b in zip(w1, w3):
+        assert float((a - b).abs().max()) < 1e-3  # three Adam steps of K = 3 epochs apart by atomics noise only

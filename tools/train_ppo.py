@@ -20,6 +20,8 @@ p.add_argument("--integrator", default="rk45")
 p.add_argument("--robust", action="store_true", help="train under robust_control: a new perturbed plant per episode + gusts")
 p.add_argument("--eval-robust", action="store_true", help="evaluate on the perturbed plant as well (else nominal)")
 p.add_argument("--separate-reset", action="store_true", help="auto-reset through sample_init_states + reset(mask) instead of the fused launch")
+p.add_argument("--deterministic", action="store_true", help="fixed-order gradient / moment sums: the run is bit-reproducible")
+p.add_argument("--digest", action="store_true", help="print a SHA-256 of the final weights (two --deterministic runs must agree)")
 p.add_argument("--log", default="")
 a = p.parse_args()
 
@@ -29,7 +31,7 @@ env = aq.BatchedQuad(a.envs, 0.01, 1000, training=True, direct_control=1, T=5, i
 env.robust_control = a.robust  # PolicyRollout then draws the episode parameters / gusts from Philox at every (re)start
 ro = aq.PolicyRollout(env, w, a.horizon, store_obs=True, auto_reset=True, seed=a.seed)
 ro.keep_init = a.separate_reset
-learner = aq.PpoLearner(w, lr=a.lr)
+learner = aq.PpoLearner(w, lr=a.lr, deterministic=a.deterministic)
 ro.start()
 log = open(a.log, "w") if a.log else None
 t0 = time.time()
@@ -38,7 +40,7 @@ for u in range(1, a.updates + 1):
     ro.t = 0
     for _ in range(a.horizon):
         ro.step()
-    ret, adv = ro.finish(ddof=0, group=False, bootstrap=True)  # horizon-truncated episodes bootstrap from the critic
+    ret, adv = ro.finish(ddof=0, group=False, bootstrap=True, deterministic=a.deterministic)  # horizon-truncated episodes bootstrap from the critic
     losses = learner.update(ro, ret, adv)
     total_steps += a.envs * a.horizon
     rec = dict(update=u, env_steps=total_steps, wall_s=round(time.time() - t0, 2), mean_reward=float(ro.rewards.mean()),
@@ -59,3 +61,9 @@ for u in range(1, a.updates + 1):
     print(line, flush=True)
     if log:
         log.write(line + "\n"); log.flush()
+if a.digest:
+    import hashlib
+    h = hashlib.sha256()
+    for t in w.actor + w.critic:
+        h.update(t.detach().cpu().numpy().tobytes())
+    print(json.dumps(dict(weights_sha256=h.hexdigest(), deterministic=a.deterministic)))
