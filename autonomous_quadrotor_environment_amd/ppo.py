@@ -206,11 +206,22 @@ class PpoLearner:
         self._wg_ws = {}
         from .distributed import GradBucket
         keys = [(head, k) for head in ("actor", "critic") for k in range(6)]
+        # parameters, gradients and both Adam moments each live in ONE flat buffer (the weight tensors become views of
+        # it): one zeroing launch and one Adam launch per step instead of twelve of each, one all-reduce bucket
+        params = [weights.head(h)[k] for h, k in keys]
+        self.flat_p = torch.cat([p.reshape(-1) for p in params]).contiguous()
+        off = 0
+        for (h, k), p in zip(keys, params):
+            weights.head(h)[k] = self.flat_p[off:off + p.numel()].view_as(p)
+            off += p.numel()
         self.bucket = GradBucket([weights.head(h)[k] for h, k in keys])  # every .grad is a slice of one flat buffer
+        self.flat_m, self.flat_v = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
         self._state = {}
+        off = 0
         for key, g in zip(keys, self.bucket.views):
-            p = weights.head(key[0])[key[1]]
-            self._state[key] = (g, torch.zeros_like(p), torch.zeros_like(p))  # grad, m, v
+            n = g.numel()
+            self._state[key] = (g, self.flat_m[off:off + n].view_as(g), self.flat_v[off:off + n].view_as(g))  # grad, m, v
+            off += n
         self._buf = None
 
     def _buffers(self, H, n, N, dev):
@@ -230,6 +241,7 @@ class PpoLearner:
         stream = _stream(dev)
         f32 = lambda t: t.to(torch.float32).contiguous()
         obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
+        self.bucket.zero_()
         if self.fused_loss:
             return self._gradients_fused(obs, actions, old_logprob, adv, returns, b)
         # forward of both heads on the stored observations (the dense kernel takes feature-major chunks)
@@ -251,8 +263,6 @@ class PpoLearner:
                                             L.ptr(b["h1"]), L.ptr(b["h2"]), L.ptr(b["dz2"]), L.ptr(b["dz1"]), L.ptr(b["dz3"]),
                                             stream), "qenv_mlp_backward")
             g = [self._state[(head, k)][0] for k in range(6)]
-            for t in g:
-                t.zero_()
             dz3 = b["dz3"] if n_out == 4 else b["dz3"][:, :n_out].contiguous()
             for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
@@ -289,8 +299,6 @@ class PpoLearner:
                                                 L.ptr(b["dz2"]), L.ptr(b["dz1"]), L.ptr(b["dz3"]), stream),
                     "qenv_mlp_backward_ppo")
             g = [self._state[(head, k)][0] for k in range(6)]
-            for t in g:
-                t.zero_()
             dz3 = b["dz3"] if n_out == 4 else b["dz3"][:, :n_out].contiguous()
             for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
@@ -305,11 +313,10 @@ class PpoLearner:
 
     def adam_step(self):
         self.step += 1
-        for (head, k), (g, m, v) in self._state.items():
-            p = self.w.head(head)[k]
-            stream = _stream(p.device)
-            L.check(L.lib.qenv_adam_step(p.numel(), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), self.lr, self.betas[0],
-                                         self.betas[1], self.eps, self.step, stream), "qenv_adam_step")
+        p = self.flat_p
+        L.check(L.lib.qenv_adam_step(p.numel(), L.ptr(p), L.ptr(self.bucket.flat), L.ptr(self.flat_m), L.ptr(self.flat_v),
+                                     self.lr, self.betas[0], self.betas[1], self.eps, self.step, _stream(p.device)),
+                "qenv_adam_step")
 
     def update(self, rollout, returns, adv, minibatch=None, generator=None):
         """K_epochs passes over the collected rollout, returning the list of loss dicts.
