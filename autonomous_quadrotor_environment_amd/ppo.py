@@ -187,7 +187,10 @@ class PpoLearner:
     critic of model.py: K_epochs full-batch passes of { forward, clipped-surrogate loss, backward (fp32 MFMA),
     Adam } over a `PolicyRollout` collected with store_obs=True.  FIXED_STD as in the reference (:301).
 
-    Gradients of the weights are fp32-atomic sums over the batch (order not deterministic to the last bit)."""
+    Gradients of the weights are fp32-atomic sums over the batch (order not deterministic to the last bit) unless
+    deterministic=True.  The learner moves the parameters into one flat buffer: `weights.actor[i]` / `.critic[i]`
+    become views of it (same values), so read the tensors through the `ActorCriticWeights` object after constructing
+    the learner -- a tensor taken from the lists before that no longer follows the updates."""
 
     def __init__(self, weights: ActorCriticWeights, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, eps_clip=0.2, c_value=0.5,
                  c_entropy=0.006, K_epochs=10, group=None, deterministic=False):
