@@ -1,5 +1,5 @@
-"""GPU: a short run of every differential fuzzer under tests/tools (HIP path vs the oracle over random points of the
-configuration space; the long runs are recorded under profiles/r01_fuzz_*.jsonl).  The scripts are executed in this
+"""GPU: a short run of every differential fuzzer under tests/tools (HIP path vs the oracle -- the learner: vs torch autograd
+in fp64 -- over random points of the configuration space; the long runs are recorded under profiles/r01_fuzz_*.jsonl).  The scripts are executed in this
 process (runpy), with a seed the recorded runs did not use."""
 import os
 import runpy
@@ -19,6 +19,7 @@ TOOLS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
     ("fuzz_policy_rollout.py", ["101", "20"]),      # PPO worker loop with masked auto-reset
     ("fuzz_outer_loops.py", ["101", "30"]),         # vel_pid / pos_pi inside the window push
     ("fuzz_sensor.py", ["101", "30"]),              # sensor model
+    ("fuzz_learner.py", ["101", "30"]),             # learner gradients vs torch autograd (fp64), random batch shapes
 ])
 def test_fuzzer_short_run(script, args, capsys):
     argv = sys.argv

@@ -1,0 +1,65 @@
+"""GPU box: the learner's gradients (loss fused into the backward kernel, weight / bias gradients; atomic and ordered
+sums) against torch autograd in fp64 on the reference's loss (ppo.py:185-203), over random batch shapes -- env counts
+that leave partial 32- and 64-sample tiles (the range-checked buffer loads / stores), 1..6 steps, every hidden size,
+random std / clip / value coefficient, advantages with both signs and ratios on both sides of the clip."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch, torch.nn as nn
+import autonomous_quadrotor_environment_amd as aq
+
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+torch.manual_seed(int(rng.randint(1 << 30)))
+worst, bad = 0.0, 0
+
+
+def net(ws, final_tanh):
+    W1, b1, W2, b2, W3, b3 = ws
+    m = nn.Sequential(nn.Linear(W1.shape[1], W1.shape[0]), nn.Tanh(), nn.Linear(W2.shape[1], W2.shape[0]), nn.Tanh(),
+                      nn.Linear(W3.shape[1], W3.shape[0]), *([nn.Tanh()] if final_tanh else [])).to("cuda", torch.float64)
+    with torch.no_grad():
+        for lin, (W, b) in zip([m[0], m[2], m[4]], ((W1, b1), (W2, b2), (W3, b3))):
+            lin.weight.copy_(W.double()); lin.bias.copy_(b.double())
+    return m
+
+for case in range(n_cases):
+    hidden = int(rng.choice([16, 32, 64, 128]))
+    n = int(rng.randint(1, 7))
+    N = int(rng.choice([1, 31, 32, 33, 63, 64, 65, 100, 257, 700, int(rng.randint(1, 1500))]))
+    std = float(rng.choice([0.1, 0.3])); eps_clip = float(rng.choice([0.1, 0.2])); c_value = float(rng.choice([0.5, 1.0]))
+    det = bool(rng.randint(2))
+    w = aq.ActorCriticWeights.random(hidden, 75, 4, seed=int(rng.randint(1 << 30)))
+    w.std = std
+    obs = torch.randn(n, 75, N, device="cuda")
+    ln = aq.PpoLearner(w, K_epochs=1, eps_clip=eps_clip, c_value=c_value, deterministic=det)
+    act_net, cri_net = net(w.actor, True), net(w.critic, False)
+    x = obs.permute(0, 2, 1).double()
+    with torch.no_grad():
+        mean0 = act_net(x)
+    actions = (mean0 + std * torch.randn_like(mean0)).permute(0, 2, 1).float().contiguous()
+    old_lp = torch.distributions.Normal(mean0 + 0.5 * std * torch.randn_like(mean0), std).log_prob(actions.permute(0, 2, 1).double())
+    old_lp = old_lp.permute(0, 2, 1).float().contiguous()
+    adv = torch.randn(n, N, device="cuda"); rets = 2 * torch.randn(n, N, device="cuda")
+    loss = ln.gradients(obs, actions, old_lp, adv, rets)
+    mean = act_net(x); value = cri_net(x).squeeze(-1)
+    dist = torch.distributions.Normal(mean, std)
+    lp = dist.log_prob(actions.permute(0, 2, 1).double()).sum(-1)
+    ratio = torch.exp(lp - old_lp.permute(0, 2, 1).double().sum(-1))
+    a_ = adv.double()
+    total = (-torch.min(ratio * a_, torch.clamp(ratio, 1 - eps_clip, 1 + eps_clip) * a_)).mean() \
+        + c_value * ((value - rets.double()) ** 2).mean() - 0.006 * dist.entropy().sum(-1).mean()
+    total.backward()
+    err = abs(float(loss["loss"]) - float(total.detach())) / max(1.0, abs(float(total.detach())))
+    refs = {"actor": [p.grad for l in (act_net[0], act_net[2], act_net[4]) for p in (l.weight, l.bias)],
+            "critic": [p.grad for l in (cri_net[0], cri_net[2], cri_net[4]) for p in (l.weight, l.bias)]}
+    for head in ("actor", "critic"):
+        for k in range(6):
+            g = ln._state[(head, k)][0].double(); r = refs[head][k]
+            err = max(err, float((g - r).abs().max()) / (float(r.abs().max()) + 1e-9))
+    clipped_frac = float(((ratio < 1 - eps_clip) | (ratio > 1 + eps_clip)).double().mean())
+    ok = err < 5e-4
+    worst = max(worst, err); bad += 0 if ok else 1
+    print(json.dumps(dict(case=case, hidden=hidden, n=n, N=N, std=std, eps_clip=eps_clip, deterministic=det,
+                          clipped_frac=round(clipped_frac, 3), err=err, ok=bool(ok))), flush=True)
+print(json.dumps(dict(cases=n_cases, mismatching=bad, worst_rel_err=float(worst))))
+sys.exit(1 if bad else 0)
