@@ -7,10 +7,8 @@ Both read the env's state / Euler angles / finite-difference Euler rates from th
 and write the [F, Mx, My, Mz] request; `BatchedQuad.rollout('lqr'|'pid', n)` fuses them with
 the env step in one launch.
 """
-import numpy as np
-import torch
 
-from .quadrotor_env import BatchedQuad, quad
+from .quadrotor_env import quad
 
 
 def _batched(env):

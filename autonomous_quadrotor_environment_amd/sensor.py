@@ -3,11 +3,10 @@ evaluated as visual_landing/rl_worker.py:164-175 (`sensor_sp`) does after every 
 white noise, GPS, TRIAD attitude, dead-reckoning integrators.  Noise comes from Philox streams keyed by (seed; global env
 index, step) or from injected standard normals (the reference's draw order), so runs are reproducible and
 shard-invariant."""
-import numpy as np
 import torch
 
 from . import _lib as L
-from .quadrotor_env import BatchedQuad, quad
+from .quadrotor_env import quad
 
 
 class BatchedSensor:
