@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 2
+QENV_ABI_VERSION = 3
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2

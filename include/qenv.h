@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define QENV_ABI_VERSION 2
+/* 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
+ *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
+#define QENV_ABI_VERSION 3
 
 typedef struct qenv_s *qenv_t;
 
