@@ -70,6 +70,7 @@ SYMBOLS = {
     "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_dense_tail_chunks": (_i, [_i64, C.c_int32, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
+    "qenv_policy_act": (_i, [_vp, _i] + [_vp] * 6 + [C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_reset_sampled": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i]),
     "qenv_outer_velpid": (_i, [_vp, _vp, C.c_int32]),

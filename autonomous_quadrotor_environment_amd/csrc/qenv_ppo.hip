@@ -47,12 +47,49 @@ struct MlpArgs {
     int32_t out_f64;
     float* obs_store;   // null or [15*T][N]: the window in time order
     int32_t n_chunks;   // > 1: win = [n_chunks][15*T][N] stored observations (head 0), out = [n_chunks][n_out][N]
+    // SAMPLE instantiations (qenv_policy_act): ActorCritic.act's sampling in the epilogue of the actor forward
+    const void* noise;  // null (Philox) or injected [4][N] standard normals in the handle's dtype
+    uint64_t seed, step;
+    int64_t env_offset;
+    double std, log_norm;
+    void *out_action, *out_logprob;  // [4][N] in the handle's dtype; logprob nullable
 };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1);
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1);
+
+// k_sample_action for the env of this lane, from the four means the lane holds (same streams, same arithmetic)
+__device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const float mean[4]) {
+    float z[4];
+    if (a.noise) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            z[k] = a.out_f64 ? (float)((const double*)a.noise)[(int64_t)k * a.N + e] : ((const float*)a.noise)[(int64_t)k * a.N + e];
+    } else {
+        const uint64_t g = (uint64_t)(a.env_offset + e);
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)a.step, (uint32_t)(a.step >> 32)};
+        philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32) ^ 0xAC710Du);
+        box_muller(c[0], c[1], z[0], z[1]);
+        box_muller(c[2], c[3], z[2], z[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (a.out_f64) {
+            const double eps = (double)z[k];
+            ((double*)a.out_action)[(int64_t)k * a.N + e] = (double)mean[k] + a.std * eps;
+            if (a.out_logprob) ((double*)a.out_logprob)[(int64_t)k * a.N + e] = -0.5 * eps * eps + a.log_norm;
+        } else {
+            const float eps = z[k];
+            ((float*)a.out_action)[(int64_t)k * a.N + e] = mean[k] + (float)a.std * eps;
+            if (a.out_logprob) ((float*)a.out_logprob)[(int64_t)k * a.N + e] = -0.5f * eps * eps + (float)a.log_norm;
+        }
+    }
+}
 
 // K1 = 15*T window elements; TW > 0: compile-time window length (the whole observation of a tile
 // is prefetched into registers with back-to-back global loads before the first MFMA, and every
 // loop is unrolled so hipcc hoists the LDS operand reads ahead of the MFMAs); TW == 0: run-time T.
-template <int H, int TW, int BLOCK, bool W2_LDS>
+template <int H, int TW, int BLOCK, bool W2_LDS, bool SAMPLE = false>
 __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     constexpr int HP = H < 32 ? 32 : H;  // hidden rows padded to the 32-row MFMA tile
     constexpr int NT = HP / 32;
@@ -214,14 +251,19 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                 if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        float outv[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             float v = acc3[o];  // output row o = acc_row(o, 0): held by the lower lane half
             if (a.final_tanh) v = tanhf(v);  // the 4 outputs keep the exact tanh
-            if (valid && half == 0 && o < a.n_out) {
+            outv[o] = v;
+            if (valid && half == 0 && o < a.n_out && a.out) {
                 if (a.out_f64) ((double*)a.out)[out_off + (int64_t)o * a.N + e] = (double)v;
                 else ((float*)a.out)[out_off + (int64_t)o * a.N + e] = v;
             }
+        }
+        if constexpr (SAMPLE) {
+            if (valid && half == 0) sample_store(a, e, outv);
         }
     }
 }
@@ -235,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
 // every wave reads tile ti's register j as ITS lane's B operand: conflict-free, and the k-pairs and their order are
 // those of k_mlp).  Layer 3 stays one 16 NT-MFMA chain on wave 0 so the accumulation order is k_mlp's too: the
 // results are bit-identical to k_mlp's.  Dependent MFMAs per tile: 38 + 16 NT + 16 NT instead of NT (38 + 16 NT + 16).
-template <int H, int TW>
+template <int H, int TW, bool SAMPLE = false>
 __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpArgs a) {
     constexpr int HP = H < 32 ? 32 : H;
     constexpr int NT = HP / 32;
@@ -330,14 +372,19 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
 #pragma unroll
             for (int i = 0; i < NT * 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[i], x2[i * 64 + lane], acc, 0, 0, 0);
             const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
+            float outv[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 float v = acc[o];
                 if (a.final_tanh) v = tanhf(v);
-                if (valid && half == 0 && o < a.n_out) {
+                outv[o] = v;
+                if (valid && half == 0 && o < a.n_out && a.out) {
                     if (a.out_f64) ((double*)a.out)[out_off + (int64_t)o * a.N + e] = (double)v;
                     else ((float*)a.out)[out_off + (int64_t)o * a.N + e] = v;
                 }
+            }
+            if constexpr (SAMPLE) {
+                if (valid && half == 0) sample_store(a, e, outv);
             }
         }
         // x2 is rewritten only after the next tile's first barrier, which wave 0 reaches after this layer 3
@@ -349,24 +396,24 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
 #define QENV_MLP_SMALL_TILES 512
 #endif
 
-template <int H, int TW> static int launch_mlp_small(const MlpArgs& a, hipStream_t stream) {
+template <int H, int TW, bool SAMPLE = false> static int launch_mlp_small(const MlpArgs& a, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
     const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
-    hipLaunchKernelGGL((k_mlp_small<H, TW>), dim3((unsigned)(n_tiles < 4096 ? n_tiles : 4096)), dim3(HP * 2), 0, stream, a);
+    hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE>), dim3((unsigned)(n_tiles < 4096 ? n_tiles : 4096)), dim3(HP * 2), 0, stream, a);
     return check_launch("k_mlp_small");
 }
 
-template <int H, int TW, int BLOCK, bool W2_LDS>
+template <int H, int TW, int BLOCK, bool W2_LDS, bool SAMPLE = false>
 static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
     if constexpr (H >= 64 && H <= 128 && TW > 0) {  // >= 2 waves per tile to split over, the reference's window
         static const int small_tiles = getenv("QENV_MLP_SMALL_TILES") ? atoi(getenv("QENV_MLP_SMALL_TILES")) : QENV_MLP_SMALL_TILES;
-        if (((a.N + 31) / 32) * a.n_chunks <= small_tiles) return launch_mlp_small<H, TW>(a, stream);
+        if (((a.N + 31) / 32) * a.n_chunks <= small_tiles) return launch_mlp_small<H, TW, SAMPLE>(a, stream);
     }
     const int K1P = (15 * T + 1) & ~1;
     const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 32 * HP + 2 * HP + 32);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
     if (TW && (int64_t)15 * TW * a.N >= ((int64_t)1 << 31))
         return fail(QENV_ERR_ARG, "qenv_mlp_forward: 15*T*n_envs must stay below 2^31 (32-bit ring offsets)");
@@ -374,7 +421,7 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     const int wpb = BLOCK / 64;
     int64_t blocks = (n_tiles + wpb - 1) / wpb;
     if (blocks > 256) blocks = 256;  // one resident workgroup per CU; waves grid-stride over env tiles
-    hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
     return check_launch("k_mlp");
 }
 
@@ -984,6 +1031,30 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
         case 128: return t5 ? launch_mlp<128, 5, 512, true>(a, 5, q->stream) : launch_mlp<128, 0, 512, true>(a, q->cfg.T, q->stream);
         case 256: return launch_mlp<256, 0, 256, false>(a, q->cfg.T, q->stream);
         default: return fail(QENV_ERR_ARG, "qenv_mlp_forward: hidden must be one of 16, 32, 64, 128, 256");
+    }
+}
+
+int qenv_policy_act(qenv_t q, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                    const float* b3, double std, const void* noise, uint64_t seed, uint64_t step, int64_t env_offset,
+                    void* out_mean, void* out_action, void* out_logprob, float* obs_store) {
+    if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out_action) return fail(QENV_ERR_ARG, "qenv_policy_act: null argument");
+    if (!(std > 0)) return fail(QENV_ERR_ARG, "qenv_policy_act: std must be positive");
+    MlpArgs a;
+    a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = 4; a.final_tanh = 1;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out_mean;
+    a.out_f64 = q->cfg.dtype == QENV_F64;
+    a.obs_store = obs_store; a.n_chunks = 1;
+    a.noise = noise; a.seed = seed; a.step = step; a.env_offset = env_offset;
+    a.std = std; a.log_norm = -std::log(std) - 0.9189385332046727;  // -log(std) - 0.5 log(2 pi)
+    a.out_action = out_action; a.out_logprob = out_logprob;
+    const bool t5 = q->cfg.T == 5;
+    switch (hidden) {
+        case 16: return t5 ? launch_mlp<16, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<16, 0, 512, true, true>(a, q->cfg.T, q->stream);
+        case 32: return t5 ? launch_mlp<32, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<32, 0, 512, true, true>(a, q->cfg.T, q->stream);
+        case 64: return t5 ? launch_mlp<64, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<64, 0, 512, true, true>(a, q->cfg.T, q->stream);
+        case 128: return t5 ? launch_mlp<128, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<128, 0, 512, true, true>(a, q->cfg.T, q->stream);
+        case 256: return launch_mlp<256, 0, 256, false, true>(a, q->cfg.T, q->stream);
+        default: return fail(QENV_ERR_ARG, "qenv_policy_act: hidden must be one of 16, 32, 64, 128, 256");
     }
 }
 

@@ -387,6 +387,7 @@ class PolicyRollout:
         self.batched_critic = bool(store_obs and weights.critic is not None and env.T == 5
                                    and weights.hidden in (16, 32, 64, 128))
         self._values_f32 = None
+        self.fused_act = True  # actor forward and Gaussian sampling as one launch (qenv_policy_act); False: two launches
         N, dev, dt, H = env.n_envs, env.device, env.dtype, self.horizon
         self.actions = torch.zeros(H, 4, N, device=dev, dtype=dt)
         self.logprobs = torch.zeros(H, 4, N, device=dev, dtype=dt)
@@ -417,6 +418,9 @@ class PolicyRollout:
         store = None if self.obs is None else self.obs[t]
         if deterministic:  # mean action, as ppo_quad_eval.py:55
             act = env.mlp_forward(w, "actor", out=self.actions[t], obs_store=store)
+        elif self.fused_act:  # forward + sample in one launch
+            act = env.policy_act(w, noise, self.seed, self.global_step + 1, self.env_offset, out=self.actions[t],
+                                 logprob=self.logprobs[t], obs_store=store)
         else:
             env.mlp_forward(w, "actor", out=self.mean, obs_store=store)
             act = env.sample_action(self.mean, w.std, noise, self.seed, self.global_step + 1, self.env_offset,

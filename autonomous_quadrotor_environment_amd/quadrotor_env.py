@@ -355,6 +355,19 @@ class BatchedQuad:
                 "qenv_mlp_forward")
         return out
 
+    def policy_act(self, weights, noise=None, seed=0, step=0, env_offset=0, out=None, logprob=None, mean=None,
+                   obs_store=None):
+        """ActorCritic.act (model.py:52-72) in one launch: actor forward on the observation ring + Normal(mean, std)
+        sample + per-dimension log-prob (mlp_forward followed by sample_action, bit for bit)."""
+        W1, b1, W2, b2, W3, b3 = weights.head("actor")
+        out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        nz = None if noise is None else self._as_rows(noise, 4, "noise")
+        self._bind()
+        L.check(L.lib.qenv_policy_act(self._h, W1.shape[0], L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3),
+                                      float(weights.std), L.ptr(nz), int(seed), int(step), int(env_offset), L.ptr(mean),
+                                      L.ptr(out), L.ptr(logprob), L.ptr(obs_store)), "qenv_policy_act")
+        return out
+
     def sample_action(self, mean, std, noise=None, seed=0, step=0, env_offset=0, out=None, logprob=None):
         """ActorCritic.act sampling (model.py:62-68): mean + std*eps and the per-dimension log-prob.
         noise: injected standard-normal [4, N] (for CPU/GPU parity runs); otherwise Philox keyed by

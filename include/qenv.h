@@ -262,6 +262,15 @@ int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, in
 int qenv_sample_action(qenv_t q, const void *mean, double std, const void *noise, uint64_t seed,
                        uint64_t step, int64_t env_offset, void *out_action, void *out_logprob);
 
+/* ActorCritic.act in ONE launch (model.py:52-72): qenv_mlp_forward of the actor (75-H-H-4, tanh) with
+ * qenv_sample_action in its epilogue -- the same means, the same Philox streams / injected noise, the same
+ * arithmetic, bit-identical actions and log-probs.  out_mean nullable [4][N]; out_action [4][N]; out_logprob
+ * nullable [4][N]; obs_store as in qenv_mlp_forward; arrays other than obs_store in the handle's dtype. */
+int qenv_policy_act(qenv_t q, int hidden, const float *W1, const float *b1, const float *W2, const float *b2,
+                    const float *W3, const float *b3, double std, const void *noise, uint64_t seed,
+                    uint64_t step, int64_t env_offset, void *out_mean, void *out_action, void *out_logprob,
+                    float *obs_store);
+
 /* Random branch of quad.reset (quadrotor_env.py:440-445) on the device: Euler angles U(-.5,.5),
  * pos/vel/body-rate N(0,2) clipped to +-2.5 / +-5 / [-15, 7.5], quaternion by euler_quat.  Same
  * distributions as the reference, Philox streams instead of its MT19937 draw order (use the

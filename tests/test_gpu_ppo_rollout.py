@@ -533,3 +533,28 @@ def test_deterministic_training_is_bit_reproducible(aq):
     w3, g3 = run(False)
     for a, b in zip(w1, w3):
         assert float((a - b).abs().max()) < 1e-3  # three Adam steps of K = 3 epochs apart by atomics noise only
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("hidden,N,T", [(128, 1000, 5), (128, 40000, 5), (64, 777, 5), (32, 300, 5), (128, 500, 3), (256, 200, 5)])
+def test_policy_act_equals_forward_then_sample(aq, dt, hidden, N, T):
+    """qenv_policy_act (ActorCritic.act in one launch: the sampling runs in the epilogue of the actor forward) against
+    qenv_mlp_forward + qenv_sample_action: means, actions, log-probs and the stored observation, bit for bit, with the
+    Philox streams and with injected noise, across the kernel variants (k_mlp_small, k_mlp, run-time T, hidden 256)."""
+    w = aq.ActorCriticWeights.random(hidden, 15 * T, 4, seed=4)
+    w.std = 0.3
+    env = aq.BatchedQuad(N, 0.01, 1000, training=False, direct_control=1, T=T, dtype=dt)
+    env.reset(env.sample_init_states(2, 0, 0), return_history=False, push_window=True)
+    env.step(torch.zeros(4, N, device="cuda", dtype=dt), push_window=True)  # ring head off zero
+    for noise in (None, torch.randn(4, N, device="cuda", dtype=dt)):
+        mean = env.mlp_forward(w, "actor")
+        lp = torch.empty(4, N, device="cuda", dtype=dt)
+        act = env.sample_action(mean, w.std, noise, seed=9, step=17, env_offset=123, logprob=lp)
+        lp2, mean2 = torch.empty_like(lp), torch.empty_like(mean)
+        obs = torch.empty(15 * T, N, device="cuda")
+        act2 = env.policy_act(w, noise, seed=9, step=17, env_offset=123, logprob=lp2, mean=mean2, obs_store=obs)
+        assert torch.equal(mean, mean2) and torch.equal(act, act2) and torch.equal(lp, lp2)
+        obs_ref = torch.empty_like(obs)
+        env.mlp_forward(w, "actor", obs_store=obs_ref)
+        assert torch.equal(obs, obs_ref)
+        assert float((act - mean).abs().max()) > 0.1
