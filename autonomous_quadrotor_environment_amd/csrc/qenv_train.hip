@@ -46,8 +46,9 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 // Same operand orientation as k_mlp (accumulator tile = next B operand); W2 is kept ONCE in LDS as
 // [k = input][h = output] with rows padded by one word so both the forward read (32 consecutive h) and the
 // transposed backward read (stride H+1) are bank-conflict free.
-// H = 128 keeps 2 x 64 activation registers + the gradient tile live: 256-thread workgroups (one wave per
-// SIMD, 512 registers) instead of spilling 1.6 KB/lane under the 256-register cap of 512 threads.
+// H = 128 keeps 2 x 64 activation registers + the gradient tile live (223 VGPRs).  BLOCK = 512 (two waves per SIMD, the
+// large-batch choice: one wave's tanh / stores / LDS waits under the other's MFMAs) or 256 (one wave per SIMD on twice
+// as many CUs when there is at most one tile per wave) -- launch_bwd picks.
 template <int H, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
     constexpr int HP = H < 32 ? 32 : H, NT = HP / 32, LD2 = HP + 1;
