@@ -471,28 +471,51 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc1[t][j] = 0.f;
+        // the NEXT chunk of W1 travels in registers: its global loads are issued right after the current chunk has been
+        // copied to LDS and land while the chunk's MFMAs run (the load latency used to sit between the two barriers)
+        constexpr int WPT = KC * HP / 256;
+        float wpre[WPT];
+        auto fetch_w1 = [&](int kc) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int idx = threadIdx.x + 256 * i, h = idx / KC, k = idx % KC;  // global reads run along k (coalesced)
+                wpre[i] = ((kc + k) < a.K && h < H) ? a.W1[(size_t)h * a.K + kc + k] : 0.f;
+            }
+        };
+        fetch_w1(0);
+        auto load_x = [&](int k0, float (&dst)[8]) {  // 8 k-steps from input feature k0: k = k0 + 2 s + half
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int k = k0 + 2 * s + half;
+                const uint32_t kk = (uint32_t)(k < a.K ? k : a.K - 1);
+                const float v = xc[kk * N32 + e32];
+                dst[s] = k < a.K ? v : 0.f;
+            }
+        };
+        float xs[8];
+        load_x(0, xs);
         for (int kc = 0; kc < a.K; kc += KC) {
             __syncthreads();  // every wave is done with the previous chunk (and with the one-off staging above)
-            for (int idx = threadIdx.x; idx < KC * HP; idx += 256) {
-                const int h = idx / KC, k = idx % KC;  // global reads run along k (coalesced), LDS writes stride HP+1 words
-                W1c[k * LDW + h] = ((kc + k) < a.K && h < H) ? a.W1[(size_t)h * a.K + kc + k] : 0.f;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int idx = threadIdx.x + 256 * i, h = idx / KC, k = idx % KC;
+                W1c[k * LDW + h] = wpre[i];  // LDS writes stride HP+1 words
             }
             __syncthreads();
+            if (kc + KC < a.K) fetch_w1(kc + KC);
 #pragma unroll
             for (int s0 = 0; s0 < KC / 2; s0 += 8) {
-                float xs[8];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {  // 8 k-steps of activations in flight before the first MFMA needs one
-                    const int k = kc + 2 * (s0 + s) + half;
-                    const uint32_t kk = (uint32_t)(k < a.K ? k : a.K - 1);
-                    const float v = xc[kk * N32 + e32];
-                    xs[s] = k < a.K ? v : 0.f;
-                }
+                // the activations of the NEXT group of 8 k-steps are requested before this group's MFMAs are issued: a
+                // group's 8 NT dependent MFMAs (512 cycles per chain) are shorter than an HBM round trip
+                float xn[8];
+                load_x(kc + 2 * (s0 + 8), xn);
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1c[(2 * (s0 + s) + half) * LDW + 32 * t + col], xs[s], acc1[t], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) xs[s] = xn[s];
             }
         }
 #pragma unroll
