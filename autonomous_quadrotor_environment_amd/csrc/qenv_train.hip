@@ -99,14 +99,19 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) h1[t][j] = b1s[32 * t + acc_row(j, half)];
-        for (int s0 = 0; s0 < K1P / 2; s0 += 8) {
-            float xs[8];
+        auto load_x = [&](int s0, float (&dst)[8]) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int k = 2 * (s0 + s) + half;
                 const float v = x[(uint32_t)(k < K1 ? k : K1 - 1) * N32 + ec];
-                xs[s] = (k < K1 && 2 * (s0 + s) < K1P) ? v : 0.f;
+                dst[s] = (k < K1 && 2 * (s0 + s) < K1P) ? v : 0.f;
             }
+        };
+        float xs[8];
+        load_x(0, xs);
+        for (int s0 = 0; s0 < K1P / 2; s0 += 8) {
+            float xn[8];  // the next group's observations are requested before this group's MFMAs are issued
+            load_x(s0 + 8, xn);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int kk = 2 * (s0 + s) + half;
@@ -116,6 +121,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
                         h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[kk * HP + 32 * t + col], xs[s], h1[t], 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) xs[s] = xn[s];
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
