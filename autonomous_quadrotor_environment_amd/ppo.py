@@ -420,7 +420,7 @@ class PolicyRollout:
             act = env.mlp_forward(w, "actor", out=self.actions[t], obs_store=store)
         elif self.fused_act:  # forward + sample in one launch
             act = env.policy_act(w, noise, self.seed, self.global_step + 1, self.env_offset, out=self.actions[t],
-                                 logprob=self.logprobs[t], obs_store=store)
+                                 logprob=self.logprobs[t], mean=self.mean, obs_store=store)
         else:
             env.mlp_forward(w, "actor", out=self.mean, obs_store=store)
             act = env.sample_action(self.mean, w.std, noise, self.seed, self.global_step + 1, self.env_offset,
