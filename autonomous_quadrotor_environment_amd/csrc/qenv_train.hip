@@ -198,6 +198,10 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
         }
         // ---- store H1, H2; dZ2 = (W3^T dz3) (1 - H2^2) in place of H2
         const uint32_t voff = valid ? (ec + 4u * (uint32_t)half * N32) * 4u : 0x80000000u;  // rows r and r + 4 share a register
+        // the B operand of the two k-steps of W3^T dz3 (k = output o: lanes 0-31 supply o = 0 | 2, lanes 32-63 o = 1 | 3),
+        // picked with compile-time indices: written as dz3[2 s + half] hipcc spilled the four values to scratch and
+        // indexed them there (a scratch store + two dependent scratch loads on every tile's critical path)
+        const float dzs0 = half ? dz3[1] : dz3[0], dzs1 = half ? dz3[3] : dz3[2];
         const __amdgpu_buffer_rsrc_t h1c = rows_rsrc(a.h1 + (size_t)c * H * a.N, H, N32);
         const __amdgpu_buffer_rsrc_t h2c = rows_rsrc(a.h2 + (size_t)c * H * a.N, H, N32);
         const __amdgpu_buffer_rsrc_t dz2c = rows_rsrc(a.dz2 + (size_t)c * H * a.N, H, N32);
@@ -208,9 +212,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
             f32x16 g;
 #pragma unroll
             for (int j = 0; j < 16; ++j) g[j] = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                g = __builtin_amdgcn_mfma_f32_32x32x2f32(W3r[(2 * s2 + half) * HP + 32 * t + col], half ? dz3[2 * s2 + 1] : dz3[2 * s2], g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x2f32(W3r[half * HP + 32 * t + col], dzs0, g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x2f32(W3r[(2 + half) * HP + 32 * t + col], dzs1, g, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int h = 32 * t + acc_row(j, half);
