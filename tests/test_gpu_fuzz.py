@@ -19,6 +19,7 @@ TOOLS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
     ("fuzz_policy_rollout.py", ["101", "20"]),      # PPO worker loop with masked auto-reset
     ("fuzz_outer_loops.py", ["101", "30"]),         # vel_pid / pos_pi inside the window push
     ("fuzz_sensor.py", ["101", "30"]),              # sensor model
+    ("fuzz_visual_reward.py", ["101", "30"]),       # landing reward around its decision boundaries
     ("fuzz_quad_dropin.py", ["101", "25"]),         # the N = 1 numpy-in / numpy-out class over random API sequences
     ("fuzz_mlp.py", ["101", "50"]),                 # every MLP forward path vs torch fp64 (ring phases, T, hidden, K, N)
     ("fuzz_gae.py", ["101", "60"]),                 # GAE + normalisation, atomic and ordered moments
