@@ -385,6 +385,23 @@ def main():
         # the same operating points as a fraction of the 8 TB/s HBM peak on the algorithmic bytes per env step;
         # BASELINE.json words config 2 as "RK4 dynamics only": that operating point is extras["rk4:fused"]
         out["extras_hbm_frac"] = {k: round(v * bytes_per_step * esz / 1e9 / HBM_PEAK_GBPS, 4) for k, v in extras.items()}
+        # the denominator measured on this box: a row copy with the env kernels' access shape (13 SoA rows,
+        # one lane per env), 872 MB read + 872 MB written per launch, far beyond the 256 MiB Infinity Cache
+        from autonomous_quadrotor_environment_amd import _lib as L
+        import ctypes as C
+        n_c = 16 * 1024 * 1024
+        src = torch.rand(13, n_c, device=dev, dtype=torch.float32); dst = torch.empty_like(src)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        copy = lambda: L.check(L.lib.qenv_debug_copy_rows(L.F32, L.ptr(dst), L.ptr(src), 13, n_c, st), "copy")
+        for _ in range(3):
+            copy()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a_.record()
+        for _ in range(10):
+            copy()
+        b_.record(); torch.cuda.synchronize()
+        out["roofline"]["measured_row_copy_GBps"] = round(2 * 13 * n_c * 4 * 10 / (a_.elapsed_time(b_) * 1e-3) / 1e9, 1)
+        del src, dst
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.integrator, args.cpu_seconds)
