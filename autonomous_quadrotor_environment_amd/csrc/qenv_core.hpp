@@ -38,6 +38,10 @@ template <> struct Mth<float> {
         return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
     }
     static __device__ __forceinline__ float div_ctl(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    static __device__ __forceinline__ float div(float a, float b) { return a / b; }
+    static __device__ __forceinline__ float rcp_ctl(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float sqrt_ctl(float x) { return __fsqrt_rn(x); }
+    static constexpr bool lean = false;
     // nextafter(t, +inf) - t for finite t >= 0
     static __device__ __forceinline__ float ulp_up(float t) { return __uint_as_float(__float_as_uint(t) + 1u) - t; }
 };
@@ -56,8 +60,80 @@ template <> struct Mth<double> {
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
     static __device__ __forceinline__ double pow_ctl(double x, double y) { return ::pow(x, y); }
     static __device__ __forceinline__ double div_ctl(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double rcp_ctl(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double sqrt_ctl(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double ulp_up(double t) { return nextafter(t, (double)INFINITY) - t; }
+    static constexpr bool lean = false;
+};
+
+// "Lean" fp64 (QENV_COMPUTE_LEAN): every operation that touches the STATE is an fp64 multiply-add -- on gfx950 a wave
+// alone on its SIMD issues v_fma_f64 at the rate of v_fma_f32 (tools/ubench/valu_rate.hip: 5.1 vs 5.1 cycles) -- while
+// what made the plain fp64 handle twice as slow as fp32 is replaced:
+//   * IEEE divisions / square roots (15-30 instructions each from the compiler's correctly-rounded expansions) by the
+//     hardware seed (v_rcp_f64 / v_rsq_f64, 2^-23 relative) + two Newton steps: <= 2 ulp, 9 instructions;
+//   * the step-size CONTROL (scaled error norm, select_initial_step, growth factor) by the raw hardware seeds and fp32
+//     log/exp: a control quantity only scales a step size that is then clamped to the rest of the interval; the one
+//     decision that selects between different results -- accept/reject at err = 1 -- is re-evaluated with exact
+//     divisions whenever the fast norm lands within 1e-5 of the threshold (dp5_step), so the accepted sub-steps are
+//     those of the fp64 handle.
+struct MthLean {
+    static constexpr bool lean = true;
+    static __device__ __forceinline__ double rsqrt(double x) {
+        double r = __builtin_amdgcn_rsq(x);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double t = x * r;
+            const double e = fma(-t, r, 1.0);
+            r = fma(0.5 * r, e, r);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ double sqrt(double x) {  // x >= 0 (0 -> 0); negative -> NaN like ::sqrt
+        const double xs = x == 0.0 ? 1.0 : x;
+        double r = __builtin_amdgcn_rsq(xs);
+        double g = xs * r, h = 0.5 * r;
+        double e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        e = fma(-h, g, 0.5);
+        g = fma(g, e, g); h = fma(h, e, h);
+        const double d = fma(-g, g, xs);
+        g = fma(d, h, g);
+        return x == 0.0 ? 0.0 : g;
+    }
+    static __device__ __forceinline__ double rcp(double x) {
+        double r = __builtin_amdgcn_rcp(x);
+        double e = fma(-x, r, 1.0);
+        r = fma(r, e, r);
+        e = fma(-x, r, 1.0);
+        r = fma(r, e, r);
+        return r;
+    }
+    static __device__ __forceinline__ double div(double a, double b) {
+        const double r = rcp(b);
+        const double q = a * r;
+        return fma(fma(-b, q, a), r, q);
+    }
+    static __device__ __forceinline__ double abs(double x) { return fabs(x); }
+    static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
+    static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double tan(double x) { return ::tan(x); }
+    static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    // control only
+    static __device__ __forceinline__ double pow_ctl(double x, double y) {
+        return (double)__builtin_amdgcn_exp2f((float)y * __builtin_amdgcn_logf((float)x));
+    }
+    static __device__ __forceinline__ double rcp_ctl(double x) { return __builtin_amdgcn_rcp(x); }
+    static __device__ __forceinline__ double div_ctl(double a, double b) { return a * __builtin_amdgcn_rcp(b); }
+    static __device__ __forceinline__ double sqrt_ctl(double x) { return __builtin_amdgcn_sqrt(x); }
     static __device__ __forceinline__ double ulp_up(double t) { return nextafter(t, (double)INFINITY) - t; }
 };
+template <typename T, bool LEAN> struct MathSel { using type = Mth<T>; };
+template <> struct MathSel<double, true> { using type = MthLean; };
 
 // Two envs per lane: every add/mul/fma of the integrator becomes ONE packed instruction
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) working on both.  Measured on MI355X: a wave64 fp32
@@ -71,6 +147,8 @@ template <> struct Mth<F2> {
     static __device__ __forceinline__ F2 abs(F2 x) { return __builtin_elementwise_abs(x); }
     static __device__ __forceinline__ F2 max(F2 a, F2 b) { return __builtin_elementwise_max(a, b); }
     static __device__ __forceinline__ F2 min(F2 a, F2 b) { return __builtin_elementwise_min(a, b); }
+    static __device__ __forceinline__ F2 rcp_ctl(F2 x) { return rcp(x); }
+    static constexpr bool lean = false;
 };
 
 // ---- physical constants (quadrotor_env.py:30-81), folded at compile time ----------------
@@ -114,14 +192,16 @@ template <typename T> struct Act {
 // The plant the RHS integrates.  Nominal: the constants above plus the variant's drag-moment coefficients.
 // Robust (robust_control, quadrotor_env.py:84-109, flag :183): the episode's perturbed thrust coefficients, mass,
 // rotor inertias and body inertia, and the gust process -- per env, in registers for the whole step.
-template <typename T, bool ROBUST> struct Plant;
-template <typename T> struct Plant<T, false> {
+template <typename T, bool ROBUST, bool LEAN = false> struct Plant;
+template <typename T, bool LEAN> struct Plant<T, false, LEAN> {
     static constexpr bool robust = false;
+    using math = typename MathSel<T, LEAN>::type;
     T cm_xy, cm_z;
 };
 constexpr int GUST_PERIOD = 500;  // robust_control.gust_period (:94)
-template <typename T> struct Plant<T, true> {
+template <typename T, bool LEAN> struct Plant<T, true, LEAN> {
     static constexpr bool robust = true;
+    using math = typename MathSel<T, LEAN>::type;
     T cm_xy, cm_z;
     T kf[4];           // episode_kf: fraction of thrust lost per rotor (:98)
     T ir[4];           // I_R (1 + episode_ir) (:342)
@@ -222,8 +302,8 @@ __device__ __noinline__ Gust3<T> draw_gust(const void* table, int32_t f64, int32
 }
 
 // robust_control.wind(i) as the k-th RHS evaluation of a step sees it (:102-108)
-template <typename T>
-__device__ __forceinline__ void next_wind(Plant<T, true>& pl, T wd[3]) {
+template <typename T, bool LEAN>
+__device__ __forceinline__ void next_wind(Plant<T, true, LEAN>& pl, T wd[3]) {
     if (pl.redraw) {
         const Gust3<T> g = draw_gust<T>(pl.table, pl.table_f64, pl.table_E, pl.table_K, pl.epoch, pl.k, pl.N, pl.e,
                                         pl.key0, pl.key1, pl.ctr0, pl.ctr1, pl.episode);
@@ -240,8 +320,8 @@ __device__ __forceinline__ void next_wind(Plant<T, true>& pl, T wd[3]) {
 
 // Start of a step with step counter i (already incremented, :467): decide redraw / interpolate the wind.
 // linear_wind_change = np.linspace(last_gust, gust, 500); wind(i) returns row (i % 500) - 1, row -1 = the end.
-template <typename T>
-__device__ __forceinline__ void begin_step_wind(Plant<T, true>& pl, int32_t i) {
+template <typename T, bool LEAN>
+__device__ __forceinline__ void begin_step_wind(Plant<T, true, LEAN>& pl, int32_t i) {
     const int r = i % GUST_PERIOD;
     pl.redraw = (r == 1);
     pl.k = 0;
@@ -266,7 +346,7 @@ __device__ __forceinline__ void begin_step_wind(Plant<T, true>& pl, int32_t i) {
 // f2F, quadrotor_env.py:247-272 (direct mode).  a = clipped action in [-1,1].
 template <typename T, typename P>
 __device__ __forceinline__ void mix_direct(const T a[4], const P& pl, T w[4], Act<T>& u) {
-    using m = Mth<T>;
+    using m = typename P::math;
     const T c = T(phys::M * phys::G) * T(phys::T2WR / 8.0);  // fl(M G)/4: four hover rotors sum to fl(M G) exactly
     T f[4];
 #pragma unroll
@@ -288,7 +368,7 @@ __device__ __forceinline__ void mix_direct(const T a[4], const P& pl, T w[4], Ac
 template <typename T, typename P>
 __device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool opt, const P& pl, T w[4], T effort[4],
                                              T cl[4], Act<T>& u) {
-    using m = Mth<T>;
+    using m = typename P::math;
     const T a = act[0] * T(1.0 / (4 * phys::K_F));
     const T bx = act[1] * T(1.0 / (2 * phys::D * phys::K_F));
     const T by = act[2] * T(1.0 / (2 * phys::D * phys::K_F));
@@ -319,7 +399,7 @@ __device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool 
 // `acc` returns the inertial acceleration (self.accel side output).
 template <typename T, typename P>
 __device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, P& pl, T dy[13]) {
-    using m = Mth<T>;
+    using m = typename P::math;
     const T cm_xy = pl.cm_xy, cm_z = pl.cm_z;
     const T vx = y[1], vy = y[3], vz = y[5];
     const T wx = y[10], wy = y[11], wz = y[12];
@@ -388,7 +468,7 @@ constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 
 template <typename T, bool WITH_ERR, typename P>
 __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T>& u, P& pl, T h,
                                       T yn[13], T k7[13], T inc[13]) {
-    using m = Mth<T>;
+    using m = typename P::math;
     T k2[13], k3[13], k4[13], k5[13], k6[13], ys[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A21) * k1[i]);
@@ -422,8 +502,23 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
             const T e = h * (T(dp::E1) * k1[i] + T(dp::E3) * k3[i] + T(dp::E4) * k4[i] + T(dp::E5) * k5[i] +
                              T(dp::E6) * k6[i] + T(dp::E7) * k7[i]);
             const T sc = T(1e-6) + m::max(m::abs(y[i]), m::abs(yn[i])) * T(1e-3);
-            const T r = e * m::rcp(sc);
+            const T r = e * m::rcp_ctl(sc);
             err2 += r * r;
+        }
+        if constexpr (m::lean) {
+            // the hardware reciprocal is good to 2^-23: whenever the fast norm cannot decide err < 1 with a wide margin,
+            // form it again with full-precision quotients (rare: the branch is taken by ~1e-5 of the attempts)
+            if (m::abs(err2 - T(13)) < T(13e-5)) {
+                err2 = T(0);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    const T e = h * (T(dp::E1) * k1[i] + T(dp::E3) * k3[i] + T(dp::E4) * k4[i] + T(dp::E5) * k5[i] +
+                                     T(dp::E6) * k6[i] + T(dp::E7) * k7[i]);
+                    const T sc = T(1e-6) + m::max(m::abs(y[i]), m::abs(yn[i])) * T(1e-3);
+                    const T r = m::div(e, sc);
+                    err2 += r * r;
+                }
+            }
         }
     }
     return err2;  // = 13 * error_norm^2
@@ -438,7 +533,7 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
 template <typename T, typename P>
 __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, T tb, T kq[13], T dy[13],
                                                bool have_f0 = false) {
-    using m = Mth<T>;
+    using m = typename P::math;
     // scipy has no cap; the nominal plant needs 1-4 attempts per env step.  A robust redraw step (a new gust at every
     // RHS evaluation) legitimately takes hundreds of rejected sub-steps, so its cap is far higher; either way every
     // lane leaves the loop after a bounded number of attempts.
@@ -460,12 +555,12 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, 
         T isc[13];
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
-            isc[i] = m::rcp(T(1e-6) + m::abs(y[i]) * T(1e-3));
+            isc[i] = m::rcp_ctl(T(1e-6) + m::abs(y[i]) * T(1e-3));
             const T a = y[i] * isc[i], b = k1[i] * isc[i];
             d0 += a * a;
             d1 += b * b;
         }
-        d0 = m::sqrt(d0 * T(1.0 / 13)); d1 = m::sqrt(d1 * T(1.0 / 13));
+        d0 = m::sqrt_ctl(d0 * T(1.0 / 13)); d1 = m::sqrt_ctl(d1 * T(1.0 / 13));
         T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : m::div_ctl(T(0.01) * d0, d1);
         h0 = m::min(h0, tb);
         T y1[13], f1[13];
@@ -478,7 +573,7 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, 
             const T a = (f1[i] - k1[i]) * isc[i];
             d2 += a * a;
         }
-        d2 = m::div_ctl(m::sqrt(d2 * T(1.0 / 13)), h0);
+        d2 = m::div_ctl(m::sqrt_ctl(d2 * T(1.0 / 13)), h0);
         T h1;
         if (d1 <= T(1e-15) && d2 <= T(1e-15)) h1 = m::max(T(1e-6), h0 * T(1e-3));
         else h1 = m::pow_ctl(m::div_ctl(T(0.01), m::max(d1, d2)), T(0.2));
@@ -496,8 +591,9 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, 
         h_abs = h;
         T yn[13], k7[13], inc[13];
         const T err2 = dp5_step<T, true>(y, k1, u, pl, h, yn, k7, inc);
-        const T err = m::sqrt(err2 * T(1.0 / 13));
-        if (err < T(1)) {
+        const T err = m::sqrt_ctl(err2 * T(1.0 / 13));
+        // lean: decided on the (guard-banded) sum itself, sqrt_ctl is a hardware approximation there
+        if (m::lean ? (err2 < T(13)) : (err < T(1))) {
             T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow_ctl(err, T(-0.2)));
             if (rejected) factor = m::min(T(1), factor);
             h_abs *= factor;
@@ -707,17 +803,17 @@ constexpr int FLAG_DONE = 1, FLAG_SOLVED = 2, FLAG_HAS_SHAPING = 4, FLAG_ANG_OK 
 // quaternion increment dq:  phi = atan2(n, d)  =>  dphi = atan2(dn*d0 - dd*n0, d1*d0 + n1*n0),
 // with dn, dd expanded in products of dq (relative accuracy 1e-7 OF THE INCREMENT), plus the
 // 2*pi wrap the plain difference would contain.  In fp64 the plain difference is kept.
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __device__ __forceinline__ void euler_update(const T q_old[4], const T y[13], const T dy[13], bool inc_ok,
                                              const Cfg<T>& cfg, Book<T>& bk) {
-    using m = Mth<T>;
+    using m = M;
     const T inv = m::rsqrt(y[6] * y[6] + y[7] * y[7] + y[8] * y[8] + y[9] * y[9]);
     const T q0 = y[6] * inv, q1 = y[7] * inv, q2 = y[8] * inv, q3 = y[9] * inv;
     T ang[3];
     ang[0] = m::atan2(T(2) * (q0 * q1 + q2 * q3), T(1) - T(2) * (q1 * q1 + q2 * q2));
     ang[1] = m::asin(T(2) * (q0 * q2 - q3 * q1));
     ang[2] = m::atan2(T(2) * (q0 * q3 + q1 * q2), T(1) - T(2) * (q2 * q2 + q3 * q3));
-    const T inv_dt = T(1) / cfg.t_step;
+    const T inv_dt = m::div(T(1), cfg.t_step);
     T dang[3] = {T(0), T(0), T(0)};
     const bool use_inc = (sizeof(T) == 4) && inc_ok;
     if (use_inc) {
@@ -773,10 +869,10 @@ __device__ __forceinline__ void euler_update(const T q_old[4], const T y[13], co
 // done_condition + reward_function + control_effort, quadrotor_env.py:500-577 /
 // quadrotor_env_opt.py:410-484.  `act` is self.action: the clipped
 // [-1,1] command (direct) or the RAW [F,M] request (indirect, quirk Q5).
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __device__ __forceinline__ void done_reward(const T y[13], const T act[4], const T effort[4], const Cfg<T>& cfg,
                                             Book<T>& bk) {
-    using m = Mth<T>;
+    using m = M;
     const T v0 = y[1], v1 = y[3], v2 = y[5];
     const T* ang = bk.ang;
     bool done = (bk.flags & FLAG_DONE) != 0;
@@ -855,7 +951,7 @@ __device__ __forceinline__ void done_reward(const T y[13], const T act[4], const
 template <typename T, typename P>
 __device__ __forceinline__ void prepare_action(const T raw[4], const Cfg<T>& cfg, const P& pl, T w[4], T effort[4],
                                                T cl[4], T act[4], Act<T>& u) {
-    using m = Mth<T>;
+    using m = typename P::math;
     if (cfg.direct) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -874,14 +970,14 @@ __device__ __forceinline__ void prepare_action(const T raw[4], const Cfg<T>& cfg
 // ---- LQR law, lqr_quad.py:128-154 with the CARE gains in closed form (App. A.8) ---------
 template <typename T> struct LqrGains { T kt[3]; T ka[3][2]; };  // velocity gains; attitude (e, e_dot)
 
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __device__ __forceinline__ void lqr_law(const T y[13], const Book<T>& bk, const LqrGains<T>& g, T act[4]) {
-    using m = Mth<T>;
+    using m = M;
     const T F0 = g.kt[0] * y[1], F1 = g.kt[1] * y[3], F2 = g.kt[2] * y[5];
     const T theta_t = m::atan2(F0, F2 + T(phys::G));
     const T ct = m::cos(theta_t);
     const T phi_t = m::atan2(-F1 * ct, F2 + T(phys::G));
-    act[0] = T(phys::M) * (F2 + T(phys::G)) / (ct * m::cos(phi_t));
+    act[0] = m::div(T(phys::M) * (F2 + T(phys::G)), ct * m::cos(phi_t));
     act[1] = g.ka[0][0] * (bk.ang[0] - phi_t) + g.ka[0][1] * bk.ang_vel[0];
     act[2] = g.ka[1][0] * (bk.ang[1] - theta_t) + g.ka[1][1] * bk.ang_vel[1];
     act[3] = g.ka[2][0] * bk.ang[2] + g.ka[2][1] * bk.ang_vel[2];
@@ -891,42 +987,42 @@ __device__ __forceinline__ void lqr_law(const T y[13], const Book<T>& bk, const 
 template <typename T> struct PidGains { T p[6], i[6], d[6]; T ts; };
 template <typename T> struct PidState { T ix[6], x_old[6], ang_d_ant[3]; };
 
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __device__ __forceinline__ T pid_eval(const PidGains<T>& g, PidState<T>& s, int k, T x, T x_d, T dx_d) {
-    const T dx = (x - s.x_old[k]) / g.ts;
+    const T dx = M::div(x - s.x_old[k], g.ts);
     s.x_old[k] = x;
     s.ix[k] = s.ix[k] + (x_d - x) * g.ts;
     return g.p[k] * (x_d - x) + g.d[k] * (dx_d - dx) - g.i[k] * s.ix[k];
 }
 
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __device__ __forceinline__ void pid_law(const T y[13], const Book<T>& bk, const PidGains<T>& g, PidState<T>& s,
                                         const T tgt[4], T t_step, T act[4]) {
-    using m = Mth<T>;
-    const T u1 = pid_eval(g, s, 0, y[1], tgt[0], T(0));
-    const T u2 = pid_eval(g, s, 1, y[3], tgt[1], T(0));
-    const T u3 = pid_eval(g, s, 2, y[5], tgt[2], T(0));
+    using m = M;
+    const T u1 = pid_eval<T, M>(g, s, 0, y[1], tgt[0], T(0));
+    const T u2 = pid_eval<T, M>(g, s, 1, y[3], tgt[1], T(0));
+    const T u3 = pid_eval<T, M>(g, s, 2, y[5], tgt[2], T(0));
     const T theta_d = m::atan2(u1, u3 + T(phys::G));
     const T ctd = m::cos(theta_d);
     const T phi_d = m::atan2(-u2 * ctd, u3 + T(phys::G));
-    act[0] = T(phys::M) * (u3 + T(phys::G)) / (ctd * m::cos(phi_d));
+    act[0] = m::div(T(phys::M) * (u3 + T(phys::G)), ctd * m::cos(phi_d));
     const T ang_d[3] = {phi_d, theta_d, tgt[3]};
     T u567[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const T v_ang_d = (ang_d[k] - s.ang_d_ant[k]) / t_step;
-        u567[k] = pid_eval(g, s, 3 + k, bk.ang[k], ang_d[k], v_ang_d);
+        const T v_ang_d = m::div(ang_d[k] - s.ang_d_ant[k], t_step);
+        u567[k] = pid_eval<T, M>(g, s, 3 + k, bk.ang[k], ang_d[k], v_ang_d);
         s.ang_d_ant[k] = ang_d[k];
     }
     const T phi = bk.ang[0], theta = bk.ang[1];
     const T sp = m::sin(phi), cp = m::cos(phi), ct = m::cos(theta), tt = m::tan(theta);
     const T b1 = T(1.0 / phys::JX), b2 = tt * sp * T(1.0 / phys::JY), b3 = tt * cp * T(1.0 / phys::JZ);
     const T b4 = cp * T(1.0 / phys::JY), b5 = -sp * T(1.0 / phys::JZ);
-    const T b6 = sp / ct * T(1.0 / phys::JY), b7 = cp / ct * T(1.0 / phys::JZ);
+    const T b6 = m::div(sp, ct) * T(1.0 / phys::JY), b7 = m::div(cp, ct) * T(1.0 / phys::JZ);
     const T det = b4 * b7 - b5 * b6;
-    const T U3 = (b7 * u567[1] - b5 * u567[2]) / det;
-    const T U4 = (-b6 * u567[1] + b4 * u567[2]) / det;
-    act[1] = (u567[0] - b2 * U3 - b3 * U4) / b1;
+    const T U3 = m::div(b7 * u567[1] - b5 * u567[2], det);
+    const T U4 = m::div(-b6 * u567[1] + b4 * u567[2], det);
+    act[1] = m::div(u567[0] - b2 * U3 - b3 * U4, b1);
     act[2] = U3;
     act[3] = U4;
 }
@@ -934,10 +1030,10 @@ __device__ __forceinline__ void pid_law(const T y[13], const Book<T>& bk, const 
 // ---- position-tracking PD, environment/controller/PID_control.py:24-106,205-216 ---------------
 // tgt = {xd, yd, zd, dxd, dyd, dzd, psi_d}; the passed derivatives (state velocity, env.ang_vel) are
 // used, arctan instead of arctan2.  Only ix[] and ang_d_ant[] of the PID state are touched.
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __device__ __forceinline__ void pidpos_law(const T y[13], const Book<T>& bk, PidState<T>& s, const T tgt[7], T t_step,
                                            T act[4]) {
-    using m = Mth<T>;
+    using m = M;
     const T P[6] = {T(6), T(6), T(6), T(22), T(22), T(1)}, D[6] = {T(3), T(3), T(3), T(12), T(12), T(0.1)};
     const T ts = T(0.01);
     T u[3];
@@ -947,15 +1043,15 @@ __device__ __forceinline__ void pidpos_law(const T y[13], const Book<T>& bk, Pid
         s.ix[k] = s.ix[k] + (tgt[k] - x) * ts;
         u[k] = P[k] * (tgt[k] - x) + D[k] * (tgt[3 + k] - dx);  // I = 0 (PID_control.py:24-27)
     }
-    const T theta_d = m::atan2(u[0] / (u[2] + T(phys::G)), T(1));  // arctan
+    const T theta_d = m::atan2(m::div(u[0], u[2] + T(phys::G)), T(1));  // arctan
     const T ctd = m::cos(theta_d);
-    const T phi_d = m::atan2(-u[1] / (u[2] + T(phys::G)) * ctd, T(1));
-    act[0] = T(phys::M) * (u[2] + T(phys::G)) / (ctd * m::cos(phi_d));
+    const T phi_d = m::atan2(m::div(-u[1], u[2] + T(phys::G)) * ctd, T(1));
+    act[0] = m::div(T(phys::M) * (u[2] + T(phys::G)), ctd * m::cos(phi_d));
     const T ang_d[3] = {phi_d, theta_d, tgt[6]};
     T u567[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const T v_ang_d = (ang_d[k] - s.ang_d_ant[k]) / t_step;
+        const T v_ang_d = m::div(ang_d[k] - s.ang_d_ant[k], t_step);
         s.ix[3 + k] = s.ix[3 + k] + (ang_d[k] - bk.ang[k]) * ts;
         u567[k] = P[3 + k] * (ang_d[k] - bk.ang[k]) + D[3 + k] * (v_ang_d - bk.ang_vel[k]);
         s.ang_d_ant[k] = ang_d[k];
@@ -964,11 +1060,11 @@ __device__ __forceinline__ void pidpos_law(const T y[13], const Book<T>& bk, Pid
     const T sp = m::sin(phi), cp = m::cos(phi), ct = m::cos(theta), tt = m::tan(theta);
     const T b1 = T(1.0 / phys::JX), b2 = tt * sp * T(1.0 / phys::JY), b3 = tt * cp * T(1.0 / phys::JZ);
     const T b4 = cp * T(1.0 / phys::JY), b5 = -sp * T(1.0 / phys::JZ);
-    const T b6 = sp / ct * T(1.0 / phys::JY), b7 = cp / ct * T(1.0 / phys::JZ);
+    const T b6 = m::div(sp, ct) * T(1.0 / phys::JY), b7 = m::div(cp, ct) * T(1.0 / phys::JZ);
     const T det = b4 * b7 - b5 * b6;
-    const T U3 = (b7 * u567[1] - b5 * u567[2]) / det;
-    const T U4 = (-b6 * u567[1] + b4 * u567[2]) / det;
-    act[1] = (u567[0] - b2 * U3 - b3 * U4) / b1;
+    const T U3 = m::div(b7 * u567[1] - b5 * u567[2], det);
+    const T U4 = m::div(-b6 * u567[1] + b4 * u567[2], det);
+    act[1] = m::div(u567[0] - b2 * U3 - b3 * U4, b1);
     act[2] = U3;
     act[3] = U4;
 }

@@ -1,908 +1,21 @@
-// qenv_env.hip -- env kernels (reset / step / fused rollout / controllers) and their C-ABI
-// entry points (include/qenv.h).  gfx950 only.
-//
-// Data layout in HBM: one caller-provided workspace holding structure-of-arrays rows,
-// row r of env e at (row_base + r) * N + e, so a wavefront's 64 lanes touch 64
-// consecutive elements of each row (256 B for fp32): every global access is one fully
-// coalesced wave-wide transaction.  One lane = one quadrotor; 256-thread workgroups
-// (4 waves); the state never leaves VGPRs inside a step (or inside a fused rollout).
-#include "qenv_host.hpp"
-#include <type_traits>
+// qenv_env.hip -- C-ABI entry points of the env (include/qenv.h) + the fp32 instantiation of the env kernels
+// (qenv_env_impl.hpp).  gfx950 only.
+#define QENV_ENV_UNIT_F32
+#include "qenv_env_impl.hpp"
 
 namespace qenv {
-
-// ---- kernel argument blocks (live in SGPRs) ------------------------------------------------
-// T = arithmetic type, S = storage type of the workspace and of the caller's arrays.  S == T for the fp32 and
-// fp64 handles; the mixed handle (fp64 rows, fp32 arithmetic) uses T = float, S = double: the state rows are
-// advanced by state += (double)increment, so no per-step rounding of the state enters the closed loop.
-using GustSrc = qenv_gust_src;
-
-template <typename T, typename S = T> struct StepArgs {
-    GustSrc gust;
-    Cfg<T> cfg;
-    S* ws;                 // workspace rows of type S
-    int32_t* wsi;          // int rows (I, FLAGS)
-    int64_t N;
-    const S* actions;      // [4][N] or null (zero_control)
-    const uint8_t* mask;   // null or [N]: only envs with mask != 0 are stepped
-    const int32_t* idx;    // null, or a compacted list of env indices (k_compact_mask) ...
-    const int32_t* count;  // ... and its length on the device: lane g steps env idx[g] if g < *count
-    S* out_obs;            // [14][N] or null
-    S* out_reward;         // [N] or null
-    uint8_t* out_done;     // [N] or null
-    S* out_mask;           // [N] or null: 1 - done
-    float* win;            // observation ring or null
-    int32_t win_slot;      // ring slot this step's slice goes to
-    int32_t mode;          // QENV_STEP_* (mode bits only)
-    int32_t ang_ok;        // every env's prev_ang row is the angle of its state row (see euler_update)
-    int32_t outer_kind;    // outer position loop evaluated at the window push (QENV_OUTER_*)
-    int32_t outer_rows;
-    const S* outer_target; // VELPID: [rows][7] mission table (wave-uniform rows); POSPI: [3][N]
-    T outer_gain[3];       // POSPI: P, D, I
-};
-
-template <typename T, typename S = T> struct RolloutArgs {
-    GustSrc gust;
-    Cfg<T> cfg;
-    S* ws;
-    int32_t* wsi;
-    int64_t N;
-    int32_t n_steps;
-    int32_t mode;
-    int32_t pid_first;
-    int32_t ang_ok;
-    T const_action[4];
-    T pid_target[7];
-    const S* target_table;  // null, or [n_steps][7]: PIDPOS target of each step
-    const int32_t* idx;     // null, or compacted env list + its device-side length (masked reset warm-up)
-    const int32_t* count;
-    float* win;             // null, or the observation ring: step s also writes its slice to slot (win_head+s)%win_T
-    int32_t win_head, win_T;
-    LqrGains<T> lqr;
-    PidGains<T> pid;
-};
-
-template <typename S> __device__ __forceinline__ S ld(const S* base, int row, int64_t N, int64_t e) {
-    return base[(int64_t)row * N + e];
-}
-template <typename S, typename V> __device__ __forceinline__ void st(S* base, int row, int64_t N, int64_t e, V v) {
-    base[(int64_t)row * N + e] = (S)v;
-}
-
-template <typename T, typename S>
-__device__ __forceinline__ void load_book(const S* ws, const int32_t* wsi, int64_t N, int64_t e, bool opt, Book<T>& bk) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        bk.prev_ang[k] = (T)ld(ws, ROW_PREV_ANG + k, N, e);
-        bk.ang[k] = opt ? (T)ld(ws, ROW_ANG + k, N, e) : T(0);  // only the opt variant reads the old ang
-        bk.ang_vel[k] = T(0);
-    }
-    bk.prev_shaping = (T)ld(ws, ROW_PREV_SHAPING, N, e);
-    bk.abs_sum = (T)ld(ws, ROW_ABS_SUM, N, e);
-    bk.ep_return = (T)ld(ws, ROW_EP_RETURN, N, e);
-    bk.reward = T(0);
-    bk.i = wsi[IROW_I * N + e];
-    bk.flags = wsi[IROW_FLAGS * N + e];
-}
-
-template <typename T, typename S>
-__device__ __forceinline__ void store_book(S* ws, int32_t* wsi, int64_t N, int64_t e, const Book<T>& bk, bool aux) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        st(ws, ROW_PREV_ANG + k, N, e, bk.prev_ang[k]);
-        st(ws, ROW_ANG + k, N, e, bk.ang[k]);
-        if (aux) st(ws, ROW_ANG_VEL + k, N, e, bk.ang_vel[k]);
-    }
-    st(ws, ROW_PREV_SHAPING, N, e, bk.prev_shaping);
-    st(ws, ROW_ABS_SUM, N, e, bk.abs_sum);
-    st(ws, ROW_EP_RETURN, N, e, bk.ep_return);
-    st(ws, ROW_REWARD, N, e, bk.reward);
-    wsi[IROW_I * N + e] = bk.i;
-    wsi[IROW_FLAGS * N + e] = bk.flags;
-}
-
-// robust handles: the episode's plant parameters and the gust state of env e (rows ROW_ROB.., ROW_GUST..)
-template <typename T, typename S>
-__device__ __forceinline__ void load_plant(const S* ws, const int32_t* wsi, int64_t N, int64_t e, const GustSrc& g,
-                                           Plant<T, true>& pl) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        pl.kf[k] = (T)ld(ws, ROW_ROB + k, N, e);
-        pl.ir[k] = T(phys::I_R) * (T(1) + (T)ld(ws, ROW_ROB + 5 + k, N, e));
-    }
-    const T qm = T(phys::M) * (T(1) + (T)ld(ws, ROW_ROB + 4, N, e));
-    pl.inv_m = T(1) / qm;
-    pl.mg = qm * T(phys::G);
-    const T J[3] = {T(phys::JX), T(phys::JY), T(phys::JZ)};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        pl.ij[k] = T(1) / (J[k] + J[k] * (T)ld(ws, ROW_ROB + 9 + k, N, e));
-        pl.gust[k] = (T)ld(ws, ROW_GUST + k, N, e);
-        pl.last[k] = (T)ld(ws, ROW_GUST + 3 + k, N, e);
-        pl.wind[k] = T(0);
-    }
-    pl.redraw = false; pl.k = 0; pl.epoch = 0; pl.evals = -1;
-    pl.table = g.table; pl.table_f64 = g.f64; pl.table_E = g.E; pl.table_K = g.K;
-    pl.N = N; pl.e = e;
-    const uint64_t ge = (uint64_t)(g.env_offset + e);
-    pl.key0 = g.key0; pl.key1 = g.key1; pl.ctr0 = (uint32_t)ge; pl.ctr1 = (uint32_t)(ge >> 32);
-    pl.episode = (uint32_t)wsi[IROW_EPISODES * N + e];
-}
-template <typename T, typename S>
-__device__ __forceinline__ void store_gust(S* ws, int32_t* wsi, int64_t N, int64_t e, const Plant<T, true>& pl) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { st(ws, ROW_GUST + k, N, e, pl.gust[k]); st(ws, ROW_GUST + 3 + k, N, e, pl.last[k]); }
-    if (pl.evals >= 0) wsi[IROW_GUST_K * N + e] = pl.evals;  // draws the last redraw step consumed (host RNG replay)
-}
-
-#ifndef QENV_MIN_WAVES
-#define QENV_MIN_WAVES 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
-#endif
-
-// quad.step for N envs: one launch, one lane per env.
-template <typename T, typename S, int INTEG, bool ROBUST>
-__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= a.N) return;
-    if (a.idx) {  // masked steps (reset warm-ups) run on the compacted list: only ceil(count/64) waves do any work
-        if (e >= *a.count) return;
-        e = a.idx[e];
-    } else if (a.mask && a.mask[e] == 0) return;
-    const int64_t N = a.N;
-    const Cfg<T>& cfg = a.cfg;
-    constexpr bool MIXED = !std::is_same<T, S>::value;
-    T y[13];
-    S ys[13];
-#pragma unroll
-    for (int k = 0; k < 13; ++k) { ys[k] = ld(a.ws, ROW_STATE + k, N, e); y[k] = (T)ys[k]; }
-    T raw[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        raw[k] = a.actions ? (T)a.actions[(int64_t)k * N + e] : ((cfg.direct || k == 0) ? cfg.zero_control0 : T(0));
-    T w[4], effort[4], cl[4], act[4], kq[13], dy[13];
-    const T q_old[4] = {y[6], y[7], y[8], y[9]};
-    Act<T> u;
-    Plant<T, ROBUST> pl;
-    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
-    if constexpr (ROBUST) {
-        load_plant(a.ws, a.wsi, N, e, a.gust, pl);
-        begin_step_wind(pl, a.wsi[IROW_I * N + e] + 1);  // self.i += 1 comes first in step (:467)
-    }
-    prepare_action(raw, cfg, pl, w, effort, cl, act, u);
-    integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy);
-    if constexpr (ROBUST) store_gust(a.ws, a.wsi, N, e, pl);
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        if (MIXED) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; st(a.ws, ROW_STATE + k, N, e, ys[k]); }
-        else st(a.ws, ROW_STATE + k, N, e, y[k]);
-    }
-    if (a.mode == QENV_STEP_DYNAMICS_ONLY) return;
-
-    Book<T> bk;
-    load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
-    bk.i += 1;
-    euler_update(q_old, y, dy, a.ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
-    done_reward(y, act, effort, cfg, bk);
-    const bool aux = a.mode != QENV_STEP_NO_AUX;
-    store_book(a.ws, a.wsi, N, e, bk, aux);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) st(a.ws, ROW_VQ + k, N, e, kq[6 + k]);
-    if (aux) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            st(a.ws, ROW_W + k, N, e, w[k]);
-            st(a.ws, ROW_EFFORT + k, N, e, effort[k]);
-            st(a.ws, ROW_CLIPPED + k, N, e, cl[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) st(a.ws, ROW_ACCEL + k, N, e, kq[1 + 2 * k]);
-    }
-    if (a.out_obs) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) a.out_obs[(int64_t)k * N + e] = MIXED ? ys[k] : (S)y[k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a.out_obs[(int64_t)(10 + k) * N + e] = (S)kq[6 + k];
-    }
-    if (a.out_reward) a.out_reward[e] = (S)bk.reward;
-    if (a.out_done) a.out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
-    if (a.out_mask) a.out_mask[e] = (bk.flags & FLAG_DONE) ? S(0) : S(1);
-    if (a.win) {  // dl_in_gen.dl_input: [raw action(4), vel(3), q(4), q_dot(4)] (dl_auxiliary.py:27-31)
-        float* wv = a.win + (int64_t)a.win_slot * 15 * N + e;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wv[(int64_t)k * N] = (float)raw[k];
-        T voff[3] = {T(0), T(0), T(0)};
-        if (a.outer_kind != QENV_OUTER_NONE) {  // the policy sees state - state_error (position.py:233-244)
-            T integ[3], cmd[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) integ[k] = (T)ld(a.ws, ROW_OUTER + k, N, e);
-            if (a.outer_kind == QENV_OUTER_VELPID) {  // velocity_pid.py:16-35
-                int row = bk.i - cfg.warmup - 1;     // k-th policy step after the T warm-ups
-                row = row < 0 ? 0 : (row >= a.outer_rows ? a.outer_rows - 1 : row);
-                const S* tg = a.outer_target + (int64_t)row * 7;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T err = (T)tg[k] - y[2 * k];
-                    const T prev = (T)ld(a.ws, ROW_OUTER + 3 + k, N, e);
-                    integ[k] = integ[k] + err * T(0.01);
-                    const T der = (err - prev) / T(0.01);
-                    cmd[k] = T(3) * err + T(0) * integ[k] + T(0.05) * der;
-                    voff[k] = (T)tg[3 + k] + cmd[k];
-                    st(a.ws, ROW_OUTER + 3 + k, N, e, err);
-                }
-            } else {  // pos_pi, math_trajectory.py:46-62, clip of :123
-                const T lo[3] = {T(-0.5), T(-0.5), T(-1.666)}, hi[3] = {T(0.5), T(0.5), T(0.333)};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T err = (T)a.outer_target[(int64_t)k * N + e] - y[2 * k];
-                    integ[k] += err * cfg.t_step;
-                    const T v = a.outer_gain[0] * err + a.outer_gain[1] * (T(0) - y[2 * k + 1]) + a.outer_gain[2] * integ[k];
-                    cmd[k] = v < lo[k] ? lo[k] : (v > hi[k] ? hi[k] : v);
-                    voff[k] = cmd[k];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { st(a.ws, ROW_OUTER + k, N, e, integ[k]); st(a.ws, ROW_OUTER + 6 + k, N, e, cmd[k]); }
-        }
-        wv[4 * N] = (float)(y[1] - voff[0]); wv[5 * N] = (float)(y[3] - voff[1]); wv[6 * N] = (float)(y[5] - voff[2]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
-    }
-}
-
-// n_steps env steps in one launch, controller on device, state in VGPRs throughout.
-template <typename T, typename S, int INTEG, int CTRL, bool ROBUST>
-__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T, S> a) {
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= a.N) return;
-    if (a.idx) {
-        if (e >= *a.count) return;
-        e = a.idx[e];
-    }
-    const int64_t N = a.N;
-    const Cfg<T>& cfg = a.cfg;
-    constexpr bool MIXED = !std::is_same<T, S>::value;
-    T y[13];
-    S ys[13];
-#pragma unroll
-    for (int k = 0; k < 13; ++k) { ys[k] = ld(a.ws, ROW_STATE + k, N, e); y[k] = (T)ys[k]; }
-    const bool dyn_only = a.mode == QENV_STEP_DYNAMICS_ONLY;
-    Book<T> bk;
-    if (!dyn_only) {
-        load_book(a.ws, a.wsi, N, e, true, bk);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) bk.ang_vel[k] = (T)ld(a.ws, ROW_ANG_VEL + k, N, e);
-    }
-    PidState<T> ps;
-    if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { ps.ix[k] = (T)ld(a.ws, ROW_PID + k, N, e); ps.x_old[k] = (T)ld(a.ws, ROW_PID + 6 + k, N, e); }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = (T)ld(a.ws, ROW_PID + 12 + k, N, e);
-    }
-    T w[4], effort[4], cl[4], act[4], kq[13], raw[4], dy[13];
-    Act<T> u;
-    Plant<T, ROBUST> pl;
-    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
-    if constexpr (ROBUST) load_plant(a.ws, a.wsi, N, e, a.gust, pl);  // the host refuses dynamics-only robust rollouts
-    if (CTRL == QENV_CTRL_CONST) {  // constant action: mix once for the whole rollout
-        prepare_action(a.const_action, cfg, pl, w, effort, cl, act, u);
-    }
-    bool ang_ok = a.ang_ok != 0;
-    for (int s = 0; s < a.n_steps; ++s) {
-        if (CTRL == QENV_CTRL_LQR) {
-            lqr_law(y, bk, a.lqr, raw);
-            prepare_action(raw, cfg, pl, w, effort, cl, act, u);
-        } else if (CTRL == QENV_CTRL_PID) {
-            if (s == 0 && a.pid_first) {
-                raw[0] = T(phys::M * phys::G); raw[1] = raw[2] = raw[3] = T(0);
-            } else {
-                pid_law(y, bk, a.pid, ps, a.pid_target, cfg.t_step, raw);
-            }
-            prepare_action(raw, cfg, pl, w, effort, cl, act, u);
-        } else if (CTRL == QENV_CTRL_PIDPOS) {
-            if (a.target_table) {
-                T tg[7];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) tg[k] = (T)a.target_table[s * 7 + k];  // wave-uniform address: scalar loads
-                pidpos_law(y, bk, ps, tg, cfg.t_step, raw);
-            } else {
-                pidpos_law(y, bk, ps, a.pid_target, cfg.t_step, raw);
-            }
-            prepare_action(raw, cfg, pl, w, effort, cl, act, u);
-        }
-        const T q_old[4] = {y[6], y[7], y[8], y[9]};
-        // constant actuation: f(y_end) of the previous step IS f0 of this one (not in the mixed handle, where the
-        // step starts from the re-rounded fp64 state)
-        // (nor in a robust plant: the wind changes from step to step)
-        if constexpr (ROBUST) begin_step_wind(pl, bk.i + 1);
-        integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !MIXED && !ROBUST && s > 0);
-        if (MIXED) {
-#pragma unroll
-            for (int k = 0; k < 13; ++k) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; }
-        }
-        if (!dyn_only) {
-            bk.i += 1;
-            euler_update(q_old, y, dy, ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
-            done_reward(y, act, effort, cfg, bk);
-            ang_ok = true;  // from here on every env's prev_ang belongs to the state in its registers
-            if (a.win) {  // dl_in_gen.dl_input of this step (reset warm-up: raw action = the constant action)
-                int slot = a.win_head + s;
-                while (slot >= a.win_T) slot -= a.win_T;
-                float* wv = a.win + (int64_t)slot * 15 * N + e;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) wv[(int64_t)k * N] = (float)(CTRL == QENV_CTRL_CONST ? a.const_action[k] : raw[k]);
-                wv[4 * N] = (float)y[1]; wv[5 * N] = (float)y[3]; wv[6 * N] = (float)y[5];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        if (MIXED) st(a.ws, ROW_STATE + k, N, e, ys[k]);
-        else st(a.ws, ROW_STATE + k, N, e, y[k]);
-    }
-    if (dyn_only) return;
-    if constexpr (ROBUST) store_gust(a.ws, a.wsi, N, e, pl);
-    store_book(a.ws, a.wsi, N, e, bk, true);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        st(a.ws, ROW_VQ + k, N, e, kq[6 + k]);
-        st(a.ws, ROW_W + k, N, e, w[k]);
-        st(a.ws, ROW_EFFORT + k, N, e, effort[k]);
-        st(a.ws, ROW_CLIPPED + k, N, e, cl[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st(a.ws, ROW_ACCEL + k, N, e, kq[1 + 2 * k]);
-    if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { st(a.ws, ROW_PID + k, N, e, ps.ix[k]); st(a.ws, ROW_PID + 6 + k, N, e, ps.x_old[k]); }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) st(a.ws, ROW_PID + 12 + k, N, e, ps.ang_d_ant[k]);
-    }
-}
-
-// ---- two envs per lane (fp32, even N): the integrator runs on packed float2 math -----------------
-// Lane g owns envs 2g and 2g+1 (adjacent in every row: one 8-byte load/store per row per lane, 512 B
-// per wave).  Mixing, Euler angles, done/reward and the controllers are evaluated per env with the
-// scalar code; only the integrator -- >90% of the instructions -- is packed.
-template <int INTEG, int CTRL>
-__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutArgs<float> a) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t N = a.N;
-    if (2 * g >= N) return;
-    const Cfg<float>& cfg = a.cfg;
-    const float2* ws2 = reinterpret_cast<const float2*>(a.ws);
-    const int64_t N2 = N / 2;
-    F2 y[13];
-#pragma unroll
-    for (int k = 0; k < 13; ++k) { const float2 v = ws2[(int64_t)(ROW_STATE + k) * N2 + g]; y[k] = F2{v.x, v.y}; }
-    const bool dyn_only = a.mode == QENV_STEP_DYNAMICS_ONLY;
-    Book<float> bk[2];
-    PidState<float> ps[2];
-    if (!dyn_only) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            load_book(a.ws, a.wsi, N, 2 * g + c, true, bk[c]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) bk[c].ang_vel[k] = ld(a.ws, ROW_ANG_VEL + k, N, 2 * g + c);
-            if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { ps[c].ix[k] = ld(a.ws, ROW_PID + k, N, 2 * g + c); ps[c].x_old[k] = ld(a.ws, ROW_PID + 6 + k, N, 2 * g + c); }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) ps[c].ang_d_ant[k] = ld(a.ws, ROW_PID + 12 + k, N, 2 * g + c);
-            }
-        }
-    }
-    Plant<F2, false> pl2;
-    pl2.cm_xy = F2{cfg.cm_xy, cfg.cm_xy}; pl2.cm_z = F2{cfg.cm_z, cfg.cm_z};
-    Plant<float, false> pl1;
-    pl1.cm_xy = cfg.cm_xy; pl1.cm_z = cfg.cm_z;
-    float w[2][4], effort[2][4], cl[2][4], act[2][4], raw[4];
-    Act<float> us[2];
-    Act<F2> u;
-    if (CTRL == QENV_CTRL_CONST) {
-        prepare_action(a.const_action, cfg, pl1, w[0], effort[0], cl[0], act[0], us[0]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { w[1][k] = w[0][k]; effort[1][k] = effort[0][k]; cl[1][k] = cl[0][k]; act[1][k] = act[0][k]; }
-        u.F = F2{us[0].F, us[0].F}; u.Mx = F2{us[0].Mx, us[0].Mx}; u.My = F2{us[0].My, us[0].My};
-        u.Mz = F2{us[0].Mz, us[0].Mz}; u.omr = F2{us[0].omr, us[0].omr};
-    }
-    bool ang_ok = a.ang_ok != 0;
-    F2 kq[13], dy[13];
-    for (int s = 0; s < a.n_steps; ++s) {
-        if (CTRL != QENV_CTRL_CONST) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                float yc[13];
-#pragma unroll
-                for (int k = 0; k < 13; ++k) yc[k] = y[k][c];
-                if (CTRL == QENV_CTRL_LQR) lqr_law(yc, bk[c], a.lqr, raw);
-                else if (CTRL == QENV_CTRL_PID) {
-                    if (s == 0 && a.pid_first) { raw[0] = float(phys::M * phys::G); raw[1] = raw[2] = raw[3] = 0.f; }
-                    else pid_law(yc, bk[c], a.pid, ps[c], a.pid_target, cfg.t_step, raw);
-                } else pidpos_law(yc, bk[c], ps[c], a.target_table ? a.target_table + s * 7 : a.pid_target, cfg.t_step, raw);
-                prepare_action(raw, cfg, pl1, w[c], effort[c], cl[c], act[c], us[c]);
-            }
-            u.F = F2{us[0].F, us[1].F}; u.Mx = F2{us[0].Mx, us[1].Mx}; u.My = F2{us[0].My, us[1].My};
-            u.Mz = F2{us[0].Mz, us[1].Mz}; u.omr = F2{us[0].omr, us[1].omr};
-        }
-        const F2 q_old[4] = {y[6], y[7], y[8], y[9]};
-        integrate2<INTEG>(y, u, pl2, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && s > 0);
-        if (!dyn_only) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                float yc[13], dyc[13];
-#pragma unroll
-                for (int k = 0; k < 13; ++k) { yc[k] = y[k][c]; dyc[k] = dy[k][c]; }
-                const float qo[4] = {q_old[0][c], q_old[1][c], q_old[2][c], q_old[3][c]};
-                bk[c].i += 1;
-                euler_update(qo, yc, dyc, ang_ok && (bk[c].flags & FLAG_ANG_OK), cfg, bk[c]);
-                done_reward(yc, act[c], effort[c], cfg, bk[c]);
-            }
-            ang_ok = true;
-        }
-    }
-    float2* wso = reinterpret_cast<float2*>(a.ws);
-#pragma unroll
-    for (int k = 0; k < 13; ++k) wso[(int64_t)(ROW_STATE + k) * N2 + g] = make_float2(y[k].x, y[k].y);
-    if (dyn_only) return;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int64_t e = 2 * g + c;
-        store_book(a.ws, a.wsi, N, e, bk[c], true);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            st(a.ws, ROW_VQ + k, N, e, kq[6 + k][c]);
-            st(a.ws, ROW_W + k, N, e, w[c][k]);
-            st(a.ws, ROW_EFFORT + k, N, e, effort[c][k]);
-            st(a.ws, ROW_CLIPPED + k, N, e, cl[c][k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) st(a.ws, ROW_ACCEL + k, N, e, kq[1 + 2 * k][c]);
-        if (CTRL == QENV_CTRL_PID || CTRL == QENV_CTRL_PIDPOS) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { st(a.ws, ROW_PID + k, N, e, ps[c].ix[k]); st(a.ws, ROW_PID + 6 + k, N, e, ps[c].x_old[k]); }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) st(a.ws, ROW_PID + 12 + k, N, e, ps[c].ang_d_ant[k]);
-        }
-    }
-}
-
-// quad.reset front half (quadrotor_env.py:428-445): load initial states, clear counters -- and, for a masked
-// reset, everything else the reset needs, in the same launch: the initial states can be drawn here (Philox, the
-// qenv_sample_init_states streams) instead of read, and the compacted list of reset envs that the warm-up rollout
-// walks is built with one atomic per 1024-thread block (LDS prefix over the 16 wave ballots).  The list length lives
-// in one of two ping-pong counters: this launch fills `count` and zeroes `count_next` for the next masked reset (the
-// kernel that read it has finished: same stream), so no memset launch is needed.  In config 5 this chain was
-// memset + k_sample_init + k_reset + k_compact_mask = 30 us of a 191 us step.
-struct ResetSample { uint64_t seed, episode; int64_t env_offset; int32_t on; };
-template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_reset(T* ws, int32_t* wsi, int64_t N, const T* init, const uint8_t* mask,
-                                                 ResetSample smp, int32_t* idx, int32_t* count, int32_t* count_next) {
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool on = e < N && (!mask || mask[e] != 0);
-    if (idx) {  // compaction (uniform branch: every thread of the block takes part in the barriers)
-        __shared__ int32_t wcnt[BLOCK / 64], wbase[BLOCK / 64];
-        const unsigned long long b = __ballot(on);
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (lane == 0) wcnt[wv] = __popcll(b);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < BLOCK / 64; ++w) { wbase[w] = tot; tot += wcnt[w]; }
-            const int base = tot ? atomicAdd(count, tot) : 0;
-            for (int w = 0; w < BLOCK / 64; ++w) wbase[w] += base;
-            if (blockIdx.x == 0) *count_next = 0;
-        }
-        __syncthreads();
-        if (on) idx[wbase[wv] + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)e;
-    }
-    if (!on) return;
-    using m = Mth<T>;
-    if (mask) {  // an episode ends here: bank its return before the counters are cleared
-        st(ws, ROW_LAST_RETURN, N, e, ld(ws, ROW_EP_RETURN, N, e));
-        wsi[IROW_EPISODES * N + e] += 1;
-    }
-    T x[13];
-    if (smp.on) {
-        float xf[13];
-        sample_init_state(smp.seed, smp.episode, (uint64_t)(smp.env_offset + e), xf);
-#pragma unroll
-        for (int k = 0; k < 13; ++k) x[k] = (T)xf[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 13; ++k) x[k] = init[(int64_t)k * N + e];
-    }
-#pragma unroll
-    for (int k = 0; k < 13; ++k) st(ws, ROW_STATE + k, N, e, x[k]);
-    const T* q = x + 6;
-    // self.ang = quat_euler(q) (:438); only the opt variant reads it back (prev_ang = ang)
-    st(ws, ROW_ANG + 0, N, e, m::atan2(T(2) * (q[0] * q[1] + q[2] * q[3]), T(1) - T(2) * (q[1] * q[1] + q[2] * q[2])));
-    st(ws, ROW_ANG + 1, N, e, m::asin(T(2) * (q[0] * q[2] - q[3] * q[1])));
-    st(ws, ROW_ANG + 2, N, e, m::atan2(T(2) * (q[0] * q[3] + q[1] * q[2]), T(1) - T(2) * (q[2] * q[2] + q[3] * q[3])));
-    st(ws, ROW_PREV_SHAPING, N, e, T(0));
-    st(ws, ROW_ABS_SUM, N, e, T(0));
-    st(ws, ROW_EP_RETURN, N, e, T(0));
-    st(ws, ROW_REWARD, N, e, T(0));
-    wsi[IROW_I * N + e] = 0;
-    wsi[IROW_FLAGS * N + e] = 0;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_fill_actions(T* out, int64_t N, T a0, T a1, T a2, T a3, const uint8_t* mask) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    (void)mask;
-    out[e] = a0; out[N + e] = a1; out[2 * N + e] = a2; out[3 * N + e] = a3;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_copy_rows(T* dst, const T* src, int rows, int64_t N) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    for (int r = 0; r < rows; ++r) dst[(int64_t)r * N + e] = src[(int64_t)r * N + e];
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_lqr_action(const T* ws, int64_t N, LqrGains<T> g, T* out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    T y[13];
-#pragma unroll
-    for (int k = 0; k < 13; ++k) y[k] = T(0);
-    y[1] = ld(ws, ROW_STATE + 1, N, e); y[3] = ld(ws, ROW_STATE + 3, N, e); y[5] = ld(ws, ROW_STATE + 5, N, e);
-    Book<T> bk;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { bk.ang[k] = ld(ws, ROW_ANG + k, N, e); bk.ang_vel[k] = ld(ws, ROW_ANG_VEL + k, N, e); }
-    T act[4];
-    lqr_law(y, bk, g, act);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_pid_action(T* ws, int64_t N, PidGains<T> g, T t0, T t1, T t2, T t3, T t_step,
-                                                    T* out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    T y[13];
-#pragma unroll
-    for (int k = 0; k < 13; ++k) y[k] = T(0);
-    y[1] = ld(ws, ROW_STATE + 1, N, e); y[3] = ld(ws, ROW_STATE + 3, N, e); y[5] = ld(ws, ROW_STATE + 5, N, e);
-    Book<T> bk;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { bk.ang[k] = ld(ws, ROW_ANG + k, N, e); bk.ang_vel[k] = T(0); }
-    PidState<T> ps;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { ps.ix[k] = ld(ws, ROW_PID + k, N, e); ps.x_old[k] = ld(ws, ROW_PID + 6 + k, N, e); }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(ws, ROW_PID + 12 + k, N, e);
-    const T tgt[4] = {t0, t1, t2, t3};
-    T act[4];
-    pid_law(y, bk, g, ps, tgt, t_step, act);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { st(ws, ROW_PID + k, N, e, ps.ix[k]); st(ws, ROW_PID + 6 + k, N, e, ps.x_old[k]); }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st(ws, ROW_PID + 12 + k, N, e, ps.ang_d_ant[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
-}
-
-template <typename T> struct Tgt7 { T v[7]; };
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_pidpos_action(T* ws, int64_t N, Tgt7<T> tg, T t_step, T* out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    T y[13];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) y[k] = ld(ws, ROW_STATE + k, N, e);
-#pragma unroll
-    for (int k = 6; k < 13; ++k) y[k] = T(0);
-    Book<T> bk;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { bk.ang[k] = ld(ws, ROW_ANG + k, N, e); bk.ang_vel[k] = ld(ws, ROW_ANG_VEL + k, N, e); }
-    PidState<T> ps;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { ps.ix[k] = ld(ws, ROW_PID + k, N, e); ps.x_old[k] = T(0); }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(ws, ROW_PID + 12 + k, N, e);
-    T act[4];
-    pidpos_law(y, bk, ps, tg.v, t_step, act);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) st(ws, ROW_PID + k, N, e, ps.ix[k]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st(ws, ROW_PID + 12 + k, N, e, ps.ang_d_ant[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_pid_reset(T* ws, int64_t N, const uint8_t* mask) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    if (mask && mask[e] == 0) return;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) st(ws, ROW_PID + k, N, e, T(0));
-}
-
-template <typename S>
-__global__ __launch_bounds__(256) void k_outer_reset(S* ws, int64_t N, const uint8_t* mask) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    if (mask && mask[e] == 0) return;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) st(ws, ROW_OUTER + k, N, e, S(0));
-}
-
-// robust_control.reset (quadrotor_env.py:97-101): the 12 episode draws, injected or Philox
-template <typename S>
-__global__ __launch_bounds__(256) void k_robust_params(S* ws, const int32_t* wsi, int64_t N, const S* params, uint64_t seed,
-                                                       int64_t env_offset, const uint8_t* mask) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
-    if (mask && mask[e] == 0) return;
-    if (params) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) st(ws, ROW_ROB + k, N, e, params[(int64_t)k * N + e]);
-        return;
-    }
-    const uint64_t ge = (uint64_t)(env_offset + e);
-    float v[12];
-#pragma unroll
-    for (int blk = 0; blk < 3; ++blk) {
-        // a masked call precedes the masked qenv_reset that ends the episode and bumps the counter: key the NEXT episode
-        uint32_t c[4] = {(uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)(wsi[IROW_EPISODES * N + e] + (mask ? 1 : 0)), (uint32_t)blk};
-        philox_core(c, (uint32_t)seed ^ 0x0B0Bu, (uint32_t)(seed >> 32) ^ 0xE915u);
-        if (blk == 0) {         // episode_kf = random(4) * D_KF
-            for (int k = 0; k < 4; ++k) v[k] = 0.1f * philox_u01(c[k]);
-        } else if (blk == 1) {  // episode_ir = random(4) * D_IR
-            for (int k = 0; k < 4; ++k) v[5 + k] = 0.1f * philox_u01(c[k]);
-        } else {                // episode_m ~ N(0, D_M), episode_J ~ N(0, D_J)
-            float z0, z1, z2, z3;
-            philox_normal2(c[0], c[1], z0, z1);
-            philox_normal2(c[2], c[3], z2, z3);
-            v[4] = 0.3f * z0; v[9] = 0.1f * z1; v[10] = 0.1f * z2; v[11] = 0.1f * z3;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) st(ws, ROW_ROB + k, N, e, v[k]);
-}
-
-// ---- host-side helpers -------------------------------------------------------------------------
-template <typename T> static Cfg<T> make_cfg(const qenv_s* q) {
-    Cfg<T> c;
-    const qenv_config& f = q->cfg;
-    const bool opt = f.variant == QENV_OPT;
-    c.t_step = (T)f.t_step;
-    c.cm_xy = (T)(phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3));
-    c.cm_z = (T)(2.0 * phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3));
-    double bb[9];
-    if (opt) {
-        const double b[9] = {10, 10, 10, phys::BB_ANG, phys::BB_ANG, 4, 30, 30, 30};
-        for (int k = 0; k < 9; ++k) bb[k] = f.training ? b[k] : b[k] * 1000;
-    } else {
-        const double b[9] = {10, 10, 10, phys::BB_ANG, phys::BB_ANG, 0.75 * phys::PI, 20, 20, 20};
-        for (int k = 0; k < 9; ++k) bb[k] = b[k];
-    }
-    for (int k = 0; k < 9; ++k) c.bb[k] = (T)bb[k];
-    c.zero_control0 = f.direct_control ? (T)(2.0 / phys::T2WR - 1.0) : (T)(phys::M * phys::G);
-    c.n_max = f.n_max + f.T;
-    c.warmup = f.T;
-    c.training = f.training ? 1 : 0;
-    c.direct = f.direct_control ? 1 : 0;
-    c.clipped = f.clipped ? 1 : 0;
-    c.variant = opt ? 1 : 0;
-    return c;
-}
-
-// CARE solution for the decoupled double integrators of lqr_quad.py:25-111 (App. A.8)
-template <typename T> static LqrGains<T> make_lqr(bool clipped) {
-    double q_att[6], q_t[6], r_att = 40, r_t;
-    if (clipped) {
-        const double qa[6] = {5, 1, 5, 1, 0.05, 0.01}, qt[6] = {1e-8, 1, 1e-8, 1, 1e-8, 0.8};
-        for (int k = 0; k < 6; ++k) { q_att[k] = qa[k] * 50; q_t[k] = qt[k] * 10; }
-        r_t = 10;
-    } else {
-        const double qa[6] = {5, 0.3, 5, 0.3, 2, 0.3}, qt[6] = {1e-8, 1, 1e-8, 1, 1e-8, 0.5};
-        for (int k = 0; k < 6; ++k) { q_att[k] = qa[k] * 160; q_t[k] = qt[k] * 60; }
-        r_t = 5;
-    }
-    const double b_att[3] = {1 / phys::JX, 1 / phys::JY, 1 / phys::JZ};
-    LqrGains<T> g;
-    for (int a = 0; a < 3; ++a) {
-        double k1 = std::sqrt(q_att[2 * a] / r_att);
-        double k2 = std::sqrt(q_att[2 * a + 1] / r_att + 2 * k1 / b_att[a]);
-        g.ka[a][0] = (T)(-k1); g.ka[a][1] = (T)(-k2);
-        k1 = std::sqrt(q_t[2 * a] / r_t);
-        k2 = std::sqrt(q_t[2 * a + 1] / r_t + 2 * k1 * phys::M);
-        g.kt[a] = (T)(-k2);  // positions are zeroed in state_t (lqr_quad.py:129), only the velocity gain acts
-    }
-    return g;
-}
-
-// pid_vel_control.py:17-27
-template <typename T> static PidGains<T> make_pid(bool clipped) {
-    PidGains<T> g;
-    const double P = clipped ? 1 : 2, Pz = clipped ? 0.4 : 1, Pa = clipped ? 20 : 180, Da = clipped ? 20 : 50,
-                 Pp = clipped ? 5 : 40, Dp = clipped ? 5 : 20;
-    const double p[6] = {P, P, Pz, Pa, Pa, Pp}, d[6] = {0, 0, 0, Da, Da, Dp};
-    for (int k = 0; k < 6; ++k) { g.p[k] = (T)p[k]; g.i[k] = (T)0; g.d[k] = (T)d[k]; }
-    g.ts = (T)0.01;
-    return g;
-}
-
-static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 255) / 256)); }
-
-template <typename T, typename S> static int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
-                                                     void* out_reward, uint8_t* out_done, void* out_mask, int flags_in,
-                                                     int win_slot) {
-    const int flags = flags_in & QENV_STEP_MODE_MASK;
-    StepArgs<T, S> a;
-    a.cfg = make_cfg<T>(q);
-    a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N;
-    a.actions = (const S*)actions; a.mask = mask;
-    a.idx = nullptr; a.count = nullptr;
-    if (mask && q->compact_valid) { a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N + q->count_used; }
-    a.out_obs = (S*)out_obs; a.out_reward = (S*)out_reward; a.out_done = out_done; a.mode = flags;
-    a.out_mask = (S*)out_mask;
-    a.win = win_slot >= 0 ? q->window : nullptr;
-    a.win_slot = win_slot;
-    a.outer_kind = q->outer.kind;
-    a.outer_rows = q->outer.rows;
-    a.outer_target = (const S*)q->outer.target;
-    for (int k = 0; k < 3; ++k) a.outer_gain[k] = (T)q->outer.gain[k];
-    a.ang_ok = q->ang_ok;
-    // host-side half of the prev_ang bookkeeping: a dynamics-only step moves every state without
-    // touching the angle rows; an unmasked full step re-synchronises all of them
-    if (flags == QENV_STEP_DYNAMICS_ONLY) q->ang_ok = 0;
-    else if (!mask) q->ang_ok = 1;
-    const dim3 g = grid_for(q->N), b(256);
-    a.gust = q->gust;
-    if (q->robust) {
-        if (flags == QENV_STEP_DYNAMICS_ONLY)
-            return fail(QENV_ERR_ARG, "robust_control: the gusts follow the step counter, dynamics-only steps are not available");
-        switch (q->cfg.integrator) {
-            case QENV_RK45: hipLaunchKernelGGL((k_step<T, S, INT_RK45, true>), g, b, 0, q->stream, a); break;
-            case QENV_DP5: hipLaunchKernelGGL((k_step<T, S, INT_DP5, true>), g, b, 0, q->stream, a); break;
-            default: hipLaunchKernelGGL((k_step<T, S, INT_RK4, true>), g, b, 0, q->stream, a); break;
-        }
-        return check_launch("k_step(robust)");
-    }
-    switch (q->cfg.integrator) {
-        case QENV_RK45: hipLaunchKernelGGL((k_step<T, S, INT_RK45, false>), g, b, 0, q->stream, a); break;
-        case QENV_DP5: hipLaunchKernelGGL((k_step<T, S, INT_DP5, false>), g, b, 0, q->stream, a); break;
-        default: hipLaunchKernelGGL((k_step<T, S, INT_RK4, false>), g, b, 0, q->stream, a); break;
-    }
-    return check_launch("k_step");
-}
-
-template <typename T, typename S, int INTEG> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T, S>& a) {
-    const dim3 g = grid_for(q->N), b(256);
-    if (q->robust) {
-        switch (controller) {
-            case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST, true>), g, b, 0, q->stream, a); break;
-            case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_LQR, true>), g, b, 0, q->stream, a); break;
-            case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PIDPOS, true>), g, b, 0, q->stream, a); break;
-            default: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PID, true>), g, b, 0, q->stream, a); break;
-        }
-        return;
-    }
-    if constexpr (sizeof(T) == 4 && sizeof(S) == 4) {
-        // two envs per lane, packed fp32 integrator: bit-identical results; measured (tools/ab_packed.py) +26..37 %
-        // for the fixed-step integrators under a constant action once there are >= 2 lane-pairs-worth of waves per
-        // SIMD (N >= 131072), a loss below that, and no gain for rk45 or with a controller in the loop.
-        // QENV_PACKED=0/1 overrides the rule.
-        const bool auto_packed = q->packed < 0 && INTEG != INT_RK45 && controller == QENV_CTRL_CONST && q->N >= 131072;
-        if ((q->packed > 0 || auto_packed) && (q->N % 2) == 0) {
-            const dim3 g2 = grid_for(q->N / 2), b2(256);
-            switch (controller) {
-                case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_CONST>), g2, b2, 0, q->stream, a); break;
-                case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_LQR>), g2, b2, 0, q->stream, a); break;
-                case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_PIDPOS>), g2, b2, 0, q->stream, a); break;
-                default: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_PID>), g2, b2, 0, q->stream, a); break;
-            }
-            return;
-        }
-    }
-    switch (controller) {
-        case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST, false>), g, b, 0, q->stream, a); break;
-        case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_LQR, false>), g, b, 0, q->stream, a); break;
-        case QENV_CTRL_PIDPOS: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PIDPOS, false>), g, b, 0, q->stream, a); break;
-        default: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_PID, false>), g, b, 0, q->stream, a); break;
-    }
-}
-
-template <typename T, typename S> static int do_rollout(qenv_s* q, int controller, int n_steps, const double* const_action,
-                                                        int pid_first, int flags, const void* target_table = nullptr) {
-    RolloutArgs<T, S> a;
-    a.target_table = (const S*)target_table;
-    a.idx = nullptr; a.count = nullptr; a.win = nullptr; a.win_head = 0; a.win_T = q->cfg.T;
-    if (q->compact_valid) {  // called from a masked qenv_reset: warm-up of the reset envs only
-        a.idx = q->wsi + IROW_IDX * q->N; a.count = q->wsi + IROW_COUNT * q->N + q->count_used;
-        if (q->warmup_push) { a.win = q->window; a.win_head = q->win_head; }
-    }
-    a.cfg = make_cfg<T>(q);
-    a.gust = q->gust;
-    if (q->robust && flags == QENV_STEP_DYNAMICS_ONLY)
-        return fail(QENV_ERR_ARG, "robust_control: the gusts follow the step counter, dynamics-only rollouts are not available");
-    a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N; a.n_steps = n_steps; a.mode = flags; a.pid_first = pid_first;
-    a.ang_ok = q->ang_ok;
-    if (!a.idx) q->ang_ok = flags == QENV_STEP_DYNAMICS_ONLY ? 0 : 1;  // a masked warm-up leaves the global flag alone
-    for (int k = 0; k < 7; ++k) a.pid_target[k] = (controller == QENV_CTRL_PIDPOS && const_action) ? (T)const_action[k] : (T)0;
-    for (int k = 0; k < 4; ++k)
-        a.const_action[k] = (const_action && controller == QENV_CTRL_CONST)
-                                ? (T)const_action[k]
-                                : ((q->cfg.direct_control || k == 0) ? a.cfg.zero_control0 : (T)0);
-    a.lqr = make_lqr<T>(q->cfg.clipped != 0);
-    a.pid = make_pid<T>(q->cfg.clipped != 0);
-    switch (q->cfg.integrator) {
-        case QENV_RK45: launch_rollout<T, S, INT_RK45>(q, controller, a); break;
-        case QENV_DP5: launch_rollout<T, S, INT_DP5>(q, controller, a); break;
-        default: launch_rollout<T, S, INT_RK4>(q, controller, a); break;
-    }
-    return check_launch("k_rollout");
-}
-
-template <typename T, typename S> static int do_reset(qenv_s* q, const void* init, const uint8_t* mask, void* out_states,
-                                                      void* out_actions, int push_window, const ResetSample* sample = nullptr) {
-    const dim3 g = grid_for(q->N), b(256);
-    ResetSample smp{0, 0, 0, 0};
-    if (sample) smp = *sample;
-    int rc;
-    q->compact_valid = 0;
-    if (mask) {  // the T warm-up steps touch only the reset envs: they run on the compacted index list built right here
-        int32_t* counters = q->wsi + IROW_COUNT * q->N;  // [0], [1]: ping-pong list lengths (see k_reset)
-        const int cur = q->count_cur;
-        hipLaunchKernelGGL((k_reset<S, 1024>), dim3((unsigned)((q->N + 1023) / 1024)), dim3(1024), 0, q->stream, (S*)q->ws, q->wsi,
-                           q->N, (const S*)init, mask, smp, q->wsi + IROW_IDX * q->N, counters + cur, counters + (cur ^ 1));
-        rc = check_launch("k_reset(masked)");
-        q->compact_valid = 1;
-        q->count_used = cur;
-        q->count_cur = cur ^ 1;
-    } else {
-        hipLaunchKernelGGL((k_reset<S, 256>), g, b, 0, q->stream, (S*)q->ws, q->wsi, q->N, (const S*)init, mask, smp,
-                           (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
-        rc = check_launch("k_reset");
-    }
-    const Cfg<S> c = make_cfg<S>(q);
-    if (mask && rc == 0 && !out_states && !out_actions) {
-        // masked reset inside a rollout: all T warm-up steps of the (few) reset envs in ONE launch -- their wall time
-        // is the latency of a single wave's step, so T launches cost T times that; state stays in registers
-        q->warmup_push = push_window;
-        const int keep = q->packed;
-        q->packed = 0;
-        rc = do_rollout<T, S>(q, QENV_CTRL_CONST, q->cfg.T, nullptr, 0, QENV_STEP_FULL);
-        q->packed = keep;
-        q->warmup_push = 0;
-        q->compact_valid = 0;
-        return rc;
-    }
-    const int outer_keep = q->outer.kind;
-    q->outer.kind = QENV_OUTER_NONE;  // the warm-up slices are the plain states (position.py:205-206, math_trajectory.py:106)
-    for (int t = 0; t < q->cfg.T && rc == 0; ++t) {
-        S* obs = out_states ? (S*)out_states + (int64_t)t * 14 * q->N : nullptr;
-        // warm-up slice t goes to ring slot head+t: after T of them the reset env's ring is full and in
-        // phase with the (unmoved) head, whatever the other envs did meanwhile
-        rc = do_step<T, S>(q, nullptr, mask, obs, nullptr, nullptr, nullptr, QENV_STEP_FULL,
-                        push_window ? (q->win_head + t) % q->cfg.T : -1);
-        if (rc == 0 && out_actions) {
-            S* oa = (S*)out_actions + (int64_t)t * 4 * q->N;
-            const S z = c.zero_control0;
-            hipLaunchKernelGGL((k_fill_actions<S>), g, b, 0, q->stream, oa, q->N, z, c.direct ? z : (S)0,
-                               c.direct ? z : (S)0, c.direct ? z : (S)0, mask);
-            rc = check_launch("k_fill_actions");
-        }
-    }
-    q->outer.kind = outer_keep;
-    q->compact_valid = 0;
-    return rc;
-}
-
+QENV_ENV_INSTANCES(, float, float, false)
 }  // namespace qenv
 
 using namespace qenv;
+
+// (arithmetic, storage) of a handle: fp32 | mixed (fp64 rows, fp32 arithmetic) | lean fp64 | fp64
+#define QENV_DISPATCH(q, FN, ...)                                                                     \
+    ((q)->cfg.dtype == QENV_F64                                                                       \
+         ? ((q)->cfg.compute == QENV_COMPUTE_F32    ? FN<float, double, false>(__VA_ARGS__)           \
+            : (q)->cfg.compute == QENV_COMPUTE_LEAN ? FN<double, double, true>(__VA_ARGS__)           \
+                                                    : FN<double, double, false>(__VA_ARGS__))         \
+         : FN<float, float, false>(__VA_ARGS__))
 
 // ---- C-ABI ----------------------------------------------------------------------------------------
 extern "C" {
@@ -920,8 +33,9 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     if (cfg->n_envs <= 0 || cfg->T < 1 || cfg->T > 64 || cfg->t_step <= 0)
         return fail(QENV_ERR_ARG, "qenv_create: n_envs, T (1..64) and t_step must be positive");
     if (cfg->dtype != QENV_F32 && cfg->dtype != QENV_F64) return fail(QENV_ERR_ARG, "qenv_create: bad dtype");
-    if (cfg->compute != QENV_COMPUTE_NATIVE && !(cfg->compute == QENV_COMPUTE_F32 && cfg->dtype == QENV_F64))
-        return fail(QENV_ERR_ARG, "qenv_create: compute must be NATIVE, or F32 on a QENV_F64 handle");
+    if (cfg->compute != QENV_COMPUTE_NATIVE &&
+        !((cfg->compute == QENV_COMPUTE_F32 || cfg->compute == QENV_COMPUTE_LEAN) && cfg->dtype == QENV_F64))
+        return fail(QENV_ERR_ARG, "qenv_create: compute must be NATIVE, or F32 / LEAN on a QENV_F64 handle");
     if (cfg->integrator < QENV_RK45 || cfg->integrator > QENV_RK4) return fail(QENV_ERR_ARG, "qenv_create: bad integrator");
     if (cfg->variant != QENV_MAIN && cfg->variant != QENV_OPT) return fail(QENV_ERR_ARG, "qenv_create: bad variant");
     const WsLayout L = ws_layout(*cfg);
@@ -931,6 +45,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     if (!q) return fail(QENV_ERR_ARG, "qenv_create: out of host memory");
     q->cfg = *cfg; q->N = cfg->n_envs; q->ws = workspace; q->ws_bytes = bytes; q->stream = (hipStream_t)stream;
     q->wsi = (int32_t*)((char*)workspace + L.int_off);
+    q->counters = (int32_t*)((char*)workspace + L.cnt_off);
     q->window = (float*)((char*)workspace + L.win_off);
     q->win_head = 0;
     q->ang_ok = 0;
@@ -1050,19 +165,13 @@ int qenv_robust_gusts(qenv_t q, const void* table, int32_t E, int32_t K, uint64_
 int qenv_reset(qenv_t q, const void* init_states, const uint8_t* mask, void* out_states, void* out_actions,
                int push_window) {
     if (!q || !init_states) return fail(QENV_ERR_ARG, "qenv_reset: null argument");
-    if (q->cfg.dtype == QENV_F64)
-        return q->cfg.compute == QENV_COMPUTE_F32 ? do_reset<float, double>(q, init_states, mask, out_states, out_actions, push_window)
-                                                  : do_reset<double, double>(q, init_states, mask, out_states, out_actions, push_window);
-    return do_reset<float, float>(q, init_states, mask, out_states, out_actions, push_window);
+    return QENV_DISPATCH(q, do_reset, q, init_states, mask, out_states, out_actions, push_window, nullptr);
 }
 
 int qenv_reset_sampled(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset, const uint8_t* mask, int push_window) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_reset_sampled: null handle");
     const ResetSample smp{seed, episode, env_offset, 1};
-    if (q->cfg.dtype == QENV_F64)
-        return q->cfg.compute == QENV_COMPUTE_F32 ? do_reset<float, double>(q, nullptr, mask, nullptr, nullptr, push_window, &smp)
-                                                  : do_reset<double, double>(q, nullptr, mask, nullptr, nullptr, push_window, &smp);
-    return do_reset<float, float>(q, nullptr, mask, nullptr, nullptr, push_window, &smp);
+    return QENV_DISPATCH(q, do_reset, q, nullptr, mask, nullptr, nullptr, push_window, &smp);
 }
 
 int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, uint8_t* out_done, void* out_mask,
@@ -1075,11 +184,7 @@ int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, ui
     if (push && mode == QENV_STEP_DYNAMICS_ONLY)
         return fail(QENV_ERR_STATE, "qenv_step: PUSH_WINDOW needs a full step (the slice holds q_dot)");
     const int slot = push ? q->win_head : -1;
-    const int rc = q->cfg.dtype == QENV_F64
-                       ? (q->cfg.compute == QENV_COMPUTE_F32
-                              ? do_step<float, double>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot)
-                              : do_step<double, double>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot))
-                       : do_step<float, float>(q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot);
+    const int rc = QENV_DISPATCH(q, do_step, q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot);
     if (push && rc == 0) q->win_head = (q->win_head + 1) % q->cfg.T;
     return rc;
 }
@@ -1094,10 +199,7 @@ int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_acti
     if (controller != QENV_CTRL_CONST && q->cfg.direct_control)
         return fail(QENV_ERR_STATE, "qenv_rollout: LQR/PID command [F,Mx,My,Mz]; create the handle with direct_control=0");
     if (n_steps == 0) return QENV_OK;
-    if (q->cfg.dtype == QENV_F64)
-        return q->cfg.compute == QENV_COMPUTE_F32 ? do_rollout<float, double>(q, controller, n_steps, const_action, pid_first_action, flags)
-                                                  : do_rollout<double, double>(q, controller, n_steps, const_action, pid_first_action, flags);
-    return do_rollout<float, float>(q, controller, n_steps, const_action, pid_first_action, flags);
+    return QENV_DISPATCH(q, do_rollout, q, controller, n_steps, const_action, pid_first_action, flags, nullptr);
 }
 
 int qenv_rollout_track(qenv_t q, int n_steps, const void* targets, int flags) {
@@ -1106,10 +208,7 @@ int qenv_rollout_track(qenv_t q, int n_steps, const void* targets, int flags) {
     if (flags != QENV_STEP_FULL && flags != QENV_STEP_NO_AUX) return fail(QENV_ERR_ARG, "qenv_rollout_track: bad flags");
     if (q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_rollout_track: the PD commands [F,Mx,My,Mz]; direct_control=0");
     if (n_steps == 0) return QENV_OK;
-    if (q->cfg.dtype == QENV_F64)
-        return q->cfg.compute == QENV_COMPUTE_F32 ? do_rollout<float, double>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets)
-                                                  : do_rollout<double, double>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets);
-    return do_rollout<float, float>(q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets);
+    return QENV_DISPATCH(q, do_rollout, q, QENV_CTRL_PIDPOS, n_steps, nullptr, 0, flags, targets);
 }
 
 int qenv_lqr_action(qenv_t q, void* out_actions) {

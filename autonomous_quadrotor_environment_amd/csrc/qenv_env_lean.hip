@@ -1,0 +1,7 @@
+// qenv_env_lean.hip -- the env kernels of the lean fp64 handle (QENV_COMPUTE_LEAN) (qenv_env_impl.hpp).
+#define QENV_ENV_UNIT_LEAN
+#include "qenv_env_impl.hpp"
+
+namespace qenv {
+QENV_ENV_INSTANCES(, double, double, true)
+}  // namespace qenv

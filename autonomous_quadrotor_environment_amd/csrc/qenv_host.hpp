@@ -35,10 +35,12 @@ enum {
     ROW_OUTER = 79,         // 9: outer position loop: integral(3), previous error(3), velocity command(3)
     ROWS_T = 88
 };
-enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_COUNT = 4, IROW_GUST_K = 5, IROWS = 6 };  // IDX/COUNT: compacted reset list
+// IDX: compacted reset list; its two ping-pong length counters live in their own 256-B tail (WsLayout::cnt_off), not in
+// a per-env row: a row has only n_envs words, and with n_envs == 1 a second word would alias the next row
+enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_GUST_K = 4, IROWS = 5 };
 
 struct WsLayout {
-    size_t int_off, win_off, total;
+    size_t int_off, cnt_off, win_off, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -48,7 +50,8 @@ static inline WsLayout ws_layout(const qenv_config& c) {
     const size_t N = (size_t)c.n_envs;
     WsLayout L;
     L.int_off = align256((size_t)ROWS_T * N * esz);
-    L.win_off = align256(L.int_off + (size_t)IROWS * N * sizeof(int32_t));
+    L.cnt_off = align256(L.int_off + (size_t)IROWS * N * sizeof(int32_t));
+    L.win_off = L.cnt_off + 256;
     L.total = align256(L.win_off + (size_t)15 * c.T * N * sizeof(float));
     return L;
 }
@@ -80,6 +83,7 @@ struct qenv_s {
     void* ws;
     size_t ws_bytes;
     int32_t* wsi;
+    int32_t* counters;  // [0], [1]: ping-pong lengths of the compacted reset list (see k_reset)
     float* window;
     int32_t win_head;  // ring slot the next push writes
     int32_t warmup_push;    // the masked warm-up in progress also refills the observation ring

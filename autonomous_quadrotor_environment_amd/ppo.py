@@ -371,8 +371,11 @@ class PolicyRollout:
     window -> actor + critic (fp32 MFMA) -> Normal sample -> env.step (+ window push) -> masked
     auto-reset of finished episodes, stored time-major; `finish()` runs GAE.
 
-    Every per-step buffer is preallocated, every call enqueues kernels only, so `step()` can be
-    captured into a hipGraph.  `env_offset` = this shard's first global env index (keeps the Philox
+    Every per-step buffer is preallocated and every call enqueues kernels only.  hipGraph capture is valid for the
+    DETERMINISTIC policy without auto-reset only (`step(deterministic=True)`, `auto_reset=False`; a replay must cover a
+    multiple of T steps so that the ring head returns): the Philox step counter, the ring head and the reset list's
+    ping-pong counter are host-side values baked into the kernel arguments, so a replayed sampling / auto-reset step
+    would repeat the same noise and reuse a stale list (`capturable` tells).  `env_offset` = this shard's first global env index (keeps the Philox
     streams shard-invariant)."""
 
     def __init__(self, env: BatchedQuad, weights: ActorCriticWeights, horizon, store_obs=False, auto_reset=False,
@@ -400,6 +403,11 @@ class PolicyRollout:
         self.init = torch.zeros(13, N, device=dev, dtype=dt)
         self.t = 0
         self.global_step = 0
+
+    @property
+    def capturable(self):
+        """True if step(deterministic=True) may be captured into a hipGraph (see the class docstring)."""
+        return not self.auto_reset
 
     def start(self, init_states=None):
         """reset() + fill the window with the T warm-up slices (ppo.py:234-240)."""

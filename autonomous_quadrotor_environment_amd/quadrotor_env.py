@@ -114,11 +114,13 @@ class BatchedQuad:
 
     def __init__(self, n_envs, t_step, n, training=True, euler=0, direct_control=1, T=1, clipped=True,
                  variant="main", integrator="rk45", device="cuda", dtype=torch.float32, compute=None):
-        """compute="f32" on dtype=torch.float64 selects the mixed handle: fp64 rows, fp32 arithmetic."""
+        """compute="f32" on dtype=torch.float64 selects the mixed handle (fp64 rows, fp32 arithmetic), compute="lean"
+        the lean fp64 handle (fp64 multiply-adds, Newton-refined hardware reciprocals / square roots, guard-banded
+        fast step-size control; include/qenv.h QENV_COMPUTE_LEAN)."""
         if dtype not in (torch.float32, torch.float64):
             raise ValueError("dtype must be torch.float32 or torch.float64")
-        if compute not in (None, "native", "f32") or (compute == "f32" and dtype != torch.float64):
-            raise ValueError("compute must be None/'native', or 'f32' together with dtype=torch.float64")
+        if compute not in (None, "native", "f32", "lean") or (compute in ("f32", "lean") and dtype != torch.float64):
+            raise ValueError("compute must be None/'native', or 'f32' / 'lean' together with dtype=torch.float64")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BatchedQuad runs on the GPU only (device='cuda[:i]'); there is no CPU path")
@@ -140,7 +142,7 @@ class BatchedQuad:
         self._cfg = L.QenvConfig(self.n_envs, float(t_step), int(n), self.T, int(bool(training)),
                                  int(bool(direct_control)), int(bool(clipped)), L.VARIANTS[variant],
                                  L.INTEGRATORS[integrator], L.F64 if dtype == torch.float64 else L.F32,
-                                 1 if compute == "f32" else 0)
+                                 {"f32": 1, "lean": 2}.get(compute, 0))
         nbytes = L.lib.qenv_workspace_bytes(C.byref(self._cfg))
         if nbytes == 0:
             raise L.QenvError("qenv_workspace_bytes rejected the configuration")
@@ -343,12 +345,40 @@ class BatchedQuad:
         self._bind()
         L.check(L.lib.qenv_window_push(self._h, L.ptr(o), L.ptr(a), int(bool(reset_first))), "qenv_window_push")
 
+    def _check_head(self, W, name, n_out=None):
+        """The kernels take raw pointers: a weight set of another window length, dtype or device would be read out of
+        bounds (or mis-strided), so refuse it here.  W = [W1, b1, W2, b2, W3, b3] in torch layout."""
+        W1, b1, W2, b2, W3, b3 = W
+        H, K = int(W1.shape[0]), 15 * self.T
+        want = [(H, K), (H,), (H, H), (H,), (int(W3.shape[0]), H), (int(W3.shape[0]),)]
+        for t, shp, nm in zip(W, want, ("W1", "b1", "W2", "b2", "W3", "b3")):
+            if tuple(t.shape) != shp:
+                raise ValueError(f"{name}.{nm}: expected shape {shp} for a T={self.T} window (state_dim {K}), got {tuple(t.shape)}")
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"{name}.{nm}: must be a contiguous float32 tensor on {self.device}")
+        if n_out is not None and int(W3.shape[0]) != n_out:
+            raise ValueError(f"{name}: expected {n_out} outputs, got {int(W3.shape[0])}")
+        return H
+
+    def _check_buf(self, t, rows, name, dtype=None):
+        if t is None:
+            return
+        dtype = dtype or self.dtype
+        shp = (rows, self.n_envs) if rows else (self.n_envs,)
+        ok_shape = tuple(t.shape) == shp or (rows == 1 and tuple(t.shape) in ((self.n_envs,), (1, self.n_envs)))
+        if not ok_shape or t.dtype != dtype or not t.is_contiguous() or t.device != self.device:
+            raise ValueError(f"{name}: expected a contiguous {dtype} tensor of shape {shp} on {self.device}, got "
+                             f"{tuple(t.shape)} {t.dtype} on {t.device}")
+
     def mlp_forward(self, weights, head="actor", out=None, obs_store=None):
         """ActorCritic.actor / .critic forward on the observation ring (model.py:27-42).
         obs_store: optional float32 [15*T, N] receiving the window in time order."""
         W1, b1, W2, b2, W3, b3 = weights.head(head)
+        self._check_head((W1, b1, W2, b2, W3, b3), head)
         n_out = W3.shape[0]
         out = torch.empty(n_out, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        self._check_buf(out, n_out, "out")
+        self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
         self._bind()
         L.check(L.lib.qenv_mlp_forward(self._h, W1.shape[0], n_out, int(head == "actor"), L.ptr(W1), L.ptr(b1),
                                        L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), L.ptr(obs_store)),
@@ -360,8 +390,12 @@ class BatchedQuad:
         """ActorCritic.act (model.py:52-72) in one launch: actor forward on the observation ring + Normal(mean, std)
         sample + per-dimension log-prob (mlp_forward followed by sample_action, bit for bit)."""
         W1, b1, W2, b2, W3, b3 = weights.head("actor")
+        self._check_head((W1, b1, W2, b2, W3, b3), "actor", n_out=4)
         out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
         nz = None if noise is None else self._as_rows(noise, 4, "noise")
+        for t, nm in ((out, "out"), (logprob, "logprob"), (mean, "mean")):
+            self._check_buf(t, 4, nm)
+        self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
         self._bind()
         L.check(L.lib.qenv_policy_act(self._h, W1.shape[0], L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3),
                                       float(weights.std), L.ptr(nz), int(seed), int(step), int(env_offset), L.ptr(mean),

@@ -57,8 +57,9 @@ def parse():
     p.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     p.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the workload's own size)")
     p.add_argument("--integrator", default="rk45", choices=["rk45", "dp5", "rk4"])
-    p.add_argument("--dtype", default="f32", choices=["f32", "f64", "mix"],
-                   help="mix = fp64 rows + fp32 arithmetic (QENV_COMPUTE_F32)")
+    p.add_argument("--dtype", default="f32", choices=["f32", "f64", "mix", "lean"],
+                   help="mix = fp64 rows + fp32 arithmetic (QENV_COMPUTE_F32); lean = fp64 multiply-adds with "
+                        "Newton-refined hardware reciprocals and guard-banded fast step control (QENV_COMPUTE_LEAN)")
     p.add_argument("--launch", default="fused", choices=["step", "fused"],
                    help="step: one kernel launch per env step (quad.step API); fused: the whole K-step "
                         "region in ONE launch with the state held in registers (qenv_rollout)")
@@ -254,7 +255,7 @@ def main():
     n_global = envs_per_gpu * world
     lo, hi = shard_range(n_global, rank, world)
     dt = torch.float32 if args.dtype == "f32" else torch.float64
-    compute = "f32" if args.dtype == "mix" else None
+    compute = {"mix": "f32", "lean": "lean"}.get(args.dtype)
 
     ppo = controller.startswith("ppo")
 
@@ -352,7 +353,7 @@ def main():
         "metric": "quadrotor env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32", "f64": "f64", "mix": "f32 arithmetic on f64 state rows"}[args.dtype], "data": "synthetic",
+        "dtype": {"f32": "f32", "f64": "f64", "mix": "f32 arithmetic on f64 state rows", "lean": "f64 (lean)"}[args.dtype], "data": "synthetic",
         "config": {"workload": desc, "envs_per_gpu": hi - lo, "global_envs": n_global,
                    "integrator": args.integrator, "launch": args.launch, "controller": controller,
                    "steps_per_graph_replay_or_launch": chunk, "hip_graph": (args.launch == "step" and not args.no_graph and controller != "ppo_rollout"),

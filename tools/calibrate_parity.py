@@ -9,8 +9,10 @@ import autonomous_quadrotor_environment_amd as aq
 from tests.conftest import golden
 
 SCALE = np.array([5, 10, 5, 10, 5, 10, 1, 1, 1, 1, 20, 20, 20.0])
-DT = {"f32": torch.float32, "f64": torch.float64, "mix": torch.float64}
-COMPUTE = {"f32": None, "f64": None, "mix": "f32"}
+DT = {"f32": torch.float32, "f64": torch.float64, "mix": torch.float64, "lean": torch.float64}
+COMPUTE = {"f32": None, "f64": None, "mix": "f32", "lean": "lean"}
+DTYPES = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f32", "mix", "lean", "f64"]
+INTEGS = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rk45", "dp5", "rk4"]
 out = {}
 
 def errs(got, ref):
@@ -20,8 +22,8 @@ def errs(got, ref):
 def dev(x, dt):
     return torch.from_numpy(np.ascontiguousarray(x)).to("cuda", DT[dt])
 
-for dt in ("f32", "mix", "f64"):
-    for integ in ("rk45", "dp5", "rk4"):
+for dt in DTYPES:
+    for integ in INTEGS:
         # one step
         for name, kw in (("g4_step_direct", dict(direct_control=1)), ("g4_step_indirect", dict(direct_control=0))):
             g = golden(name); n = len(g["x0"])
