@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "qenv_fastmath.hpp"
+
 namespace qenv {
 
 // ---- scalar math per precision --------------------------------------------------------
@@ -77,51 +79,24 @@ template <> struct Mth<double> {
 //     decision that selects between different results -- accept/reject at err = 1 -- is re-evaluated with exact
 //     divisions whenever the fast norm lands within 1e-5 of the threshold (dp5_step), so the accepted sub-steps are
 //     those of the fp64 handle.
+struct HwSeed {  // v_rcp_f64 / v_rsq_f64: 2^-23 relative
+    static __device__ __forceinline__ double rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }
+    static __device__ __forceinline__ double rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
+};
 struct MthLean {
     static constexpr bool lean = true;
-    static __device__ __forceinline__ double rsqrt(double x) {
-        double r = __builtin_amdgcn_rsq(x);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const double t = x * r;
-            const double e = fma(-t, r, 1.0);
-            r = fma(0.5 * r, e, r);
-        }
-        return r;
-    }
-    static __device__ __forceinline__ double sqrt(double x) {  // x >= 0 (0 -> 0); negative -> NaN like ::sqrt
-        const double xs = x == 0.0 ? 1.0 : x;
-        double r = __builtin_amdgcn_rsq(xs);
-        double g = xs * r, h = 0.5 * r;
-        double e = fma(-h, g, 0.5);
-        g = fma(g, e, g); h = fma(h, e, h);
-        e = fma(-h, g, 0.5);
-        g = fma(g, e, g); h = fma(h, e, h);
-        const double d = fma(-g, g, xs);
-        g = fma(d, h, g);
-        return x == 0.0 ? 0.0 : g;
-    }
-    static __device__ __forceinline__ double rcp(double x) {
-        double r = __builtin_amdgcn_rcp(x);
-        double e = fma(-x, r, 1.0);
-        r = fma(r, e, r);
-        e = fma(-x, r, 1.0);
-        r = fma(r, e, r);
-        return r;
-    }
-    static __device__ __forceinline__ double div(double a, double b) {
-        const double r = rcp(b);
-        const double q = a * r;
-        return fma(fma(-b, q, a), r, q);
-    }
+    static __device__ __forceinline__ double rsqrt(double x) { return fm::rsqrt<HwSeed>(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return fm::sqrt<HwSeed>(x); }
+    static __device__ __forceinline__ double rcp(double x) { return fm::rcp<HwSeed>(x); }
+    static __device__ __forceinline__ double div(double a, double b) { return fm::div<HwSeed>(a, b); }
     static __device__ __forceinline__ double abs(double x) { return fabs(x); }
     static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
-    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
-    static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
-    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
-    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
-    static __device__ __forceinline__ double tan(double x) { return ::tan(x); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return fm::atan2<HwSeed>(y, x); }
+    static __device__ __forceinline__ double asin(double x) { return fm::asin<HwSeed>(x); }
+    static __device__ __forceinline__ double cos(double x) { return fm::cos<HwSeed>(x); }
+    static __device__ __forceinline__ double sin(double x) { return fm::sin<HwSeed>(x); }
+    static __device__ __forceinline__ double tan(double x) { return fm::tan<HwSeed>(x); }
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
     // control only
     static __device__ __forceinline__ double pow_ctl(double x, double y) {

@@ -214,7 +214,10 @@ int qenv_rollout_track(qenv_t q, int n_steps, const void* targets, int flags) {
 int qenv_lqr_action(qenv_t q, void* out_actions) {
     if (!q || !out_actions) return fail(QENV_ERR_ARG, "qenv_lqr_action: null argument");
     const dim3 g = grid_for(q->N), b(256);
-    if (q->cfg.dtype == QENV_F64)
+    if (q->cfg.dtype == QENV_F64 && q->cfg.compute == QENV_COMPUTE_LEAN)  // the same elementary functions as the fused rollout
+        hipLaunchKernelGGL((k_lqr_action<double, MthLean>), g, b, 0, q->stream, (const double*)q->ws, q->N,
+                           make_lqr<double>(q->cfg.clipped != 0), (double*)out_actions);
+    else if (q->cfg.dtype == QENV_F64)
         hipLaunchKernelGGL((k_lqr_action<double>), g, b, 0, q->stream, (const double*)q->ws, q->N,
                            make_lqr<double>(q->cfg.clipped != 0), (double*)out_actions);
     else
@@ -228,7 +231,10 @@ int qenv_pid_action(qenv_t q, const double* targets, void* out_actions) {
     const dim3 g = grid_for(q->N), b(256);
     double t[4] = {0, 0, 0, 0};
     if (targets) for (int k = 0; k < 4; ++k) t[k] = targets[k];
-    if (q->cfg.dtype == QENV_F64)
+    if (q->cfg.dtype == QENV_F64 && q->cfg.compute == QENV_COMPUTE_LEAN)
+        hipLaunchKernelGGL((k_pid_action<double, MthLean>), g, b, 0, q->stream, (double*)q->ws, q->N,
+                           make_pid<double>(q->cfg.clipped != 0), t[0], t[1], t[2], t[3], q->cfg.t_step, (double*)out_actions);
+    else if (q->cfg.dtype == QENV_F64)
         hipLaunchKernelGGL((k_pid_action<double>), g, b, 0, q->stream, (double*)q->ws, q->N,
                            make_pid<double>(q->cfg.clipped != 0), t[0], t[1], t[2], t[3], q->cfg.t_step, (double*)out_actions);
     else
@@ -244,7 +250,10 @@ int qenv_pidpos_action(qenv_t q, const double* targets, void* out_actions) {
     if (q->cfg.dtype == QENV_F64) {
         Tgt7<double> tg;
         for (int k = 0; k < 7; ++k) tg.v[k] = targets ? targets[k] : 0.0;
-        hipLaunchKernelGGL((k_pidpos_action<double>), g, b, 0, q->stream, (double*)q->ws, q->N, tg, q->cfg.t_step, (double*)out_actions);
+        if (q->cfg.compute == QENV_COMPUTE_LEAN)
+            hipLaunchKernelGGL((k_pidpos_action<double, MthLean>), g, b, 0, q->stream, (double*)q->ws, q->N, tg, q->cfg.t_step, (double*)out_actions);
+        else
+            hipLaunchKernelGGL((k_pidpos_action<double>), g, b, 0, q->stream, (double*)q->ws, q->N, tg, q->cfg.t_step, (double*)out_actions);
     } else {
         Tgt7<float> tg;
         for (int k = 0; k < 7; ++k) tg.v[k] = targets ? (float)targets[k] : 0.f;

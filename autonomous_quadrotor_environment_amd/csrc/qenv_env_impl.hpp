@@ -318,11 +318,12 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             prepare_action(raw, cfg, pl, w, effort, cl, act, u);
         }
         const T q_old[4] = {y[6], y[7], y[8], y[9]};
-        // constant actuation: f(y_end) of the previous step IS f0 of this one (not in the mixed handle, where the
-        // step starts from the re-rounded fp64 state)
-        // (nor in a robust plant: the wind changes from step to step)
+        // constant actuation: f(y_end) of the previous step IS f0 of this one (not in a robust plant: the wind changes
+        // from step to step).  Mixed handle: the step starts from the fp64 row re-rounded to fp32, which is within one
+        // fp32 ulp of the y_end that f was evaluated at -- the same size as every other rounding of its fp32
+        // arithmetic; the fused rollout of a mixed handle is therefore close to, not bit-equal with, its per-step path
         if constexpr (ROBUST) begin_step_wind(pl, bk.i + 1);
-        integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !MIXED && !ROBUST && s > 0);
+        integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !ROBUST && s > 0);
         if (MIXED) {
 #pragma unroll
             for (int k = 0; k < 13; ++k) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; }
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void k_copy_rows(T* dst, const T* src, int row
     for (int r = 0; r < rows; ++r) dst[(int64_t)r * N + e] = src[(int64_t)r * N + e];
 }
 
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __global__ __launch_bounds__(256) void k_lqr_action(const T* ws, int64_t N, LqrGains<T> g, T* out) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= N) return;
@@ -563,12 +564,12 @@ __global__ __launch_bounds__(256) void k_lqr_action(const T* ws, int64_t N, LqrG
 #pragma unroll
     for (int k = 0; k < 3; ++k) { bk.ang[k] = ld(ws, ROW_ANG + k, N, e); bk.ang_vel[k] = ld(ws, ROW_ANG_VEL + k, N, e); }
     T act[4];
-    lqr_law(y, bk, g, act);
+    lqr_law<T, M>(y, bk, g, act);
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
 }
 
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __global__ __launch_bounds__(256) void k_pid_action(T* ws, int64_t N, PidGains<T> g, T t0, T t1, T t2, T t3, T t_step,
                                                     T* out) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256) void k_pid_action(T* ws, int64_t N, PidGains<T
     for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(ws, ROW_PID + 12 + k, N, e);
     const T tgt[4] = {t0, t1, t2, t3};
     T act[4];
-    pid_law(y, bk, g, ps, tgt, t_step, act);
+    pid_law<T, M>(y, bk, g, ps, tgt, t_step, act);
 #pragma unroll
     for (int k = 0; k < 6; ++k) { st(ws, ROW_PID + k, N, e, ps.ix[k]); st(ws, ROW_PID + 6 + k, N, e, ps.x_old[k]); }
 #pragma unroll
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void k_pid_action(T* ws, int64_t N, PidGains<T
 
 template <typename T> struct Tgt7 { T v[7]; };
 
-template <typename T>
+template <typename T, typename M = Mth<T>>
 __global__ __launch_bounds__(256) void k_pidpos_action(T* ws, int64_t N, Tgt7<T> tg, T t_step, T* out) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= N) return;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(256) void k_pidpos_action(T* ws, int64_t N, Tgt7<T>
 #pragma unroll
     for (int k = 0; k < 3; ++k) ps.ang_d_ant[k] = ld(ws, ROW_PID + 12 + k, N, e);
     T act[4];
-    pidpos_law(y, bk, ps, tg.v, t_step, act);
+    pidpos_law<T, M>(y, bk, ps, tg.v, t_step, act);
 #pragma unroll
     for (int k = 0; k < 6; ++k) st(ws, ROW_PID + k, N, e, ps.ix[k]);
 #pragma unroll

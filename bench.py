@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- quadrotor env-steps/sec on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over this rank's batch: one `quad.step()` for every env.
 Default workload = BASELINE.json configs[1]: 65 536 parallel envs per GPU, zero action from a
@@ -10,11 +9,27 @@ Default workload = BASELINE.json configs[1]: 65 536 parallel envs per GPU, zero 
 shard across ranks with no data-path collective (weak scaling: per-GPU batch fixed); the episode
 returns are all-gathered once after the timed region for the configs that have rewards.
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` and `cpu_baseline`.
+N > 1: one process per GPU over RCCL.  Under `python -m torch.distributed.run` the ranks come
+from the environment; started plainly with `--gpus N` this process only launches those N ranks
+itself (before any GPU call), relays rank 0's line and exits with their status -- it never
+reports a single-rank number for an N-GPU request.
+
+Every workload runs on the cheapest handle that holds the north-star tolerance (1e-5, scaled
+metric of tests/conftest.py) over the workload's own horizon on the workload's own initial
+distribution (tests/tools/config2_parity.py): that is the lean fp64 handle
+for all of them -- fp32 arithmetic (fp32 and mixed handles) is at 1e-4 / 5e-5 after 100 steps of
+config 2 already (thrust minus weight cancels to 1e-6 m/s^2 in fp32).
+
+The K-step region (barrier + sync on both sides, exactly K steps) is repeated until >= 0.3 s
+have been timed; `ms_per_step` / `value` are the MEDIAN region.  Rank 0 prints ONE JSON line
+with the contract fields plus `roofline`, `cpu_baseline`, `sustained` and (default 1-GPU run)
+`configs`: short per-GPU slices of BASELINE configs[2..4].
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -26,30 +41,37 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic HBM bytes per env-step, fp32 SoA (SURVEY.md section 8d / DESIGN.md)
+# algorithmic HBM bytes per env-step, fp32 SoA (SURVEY.md section 8d / DESIGN.md) -- the same figure for every handle
 BYTES_DYNAMICS = 104   # read state 13x4 + write state 13x4
 BYTES_FULL = 224       # full quad.step (reads 88 + writes 136)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+MIN_TIMED_S = 0.3
 
 WORKLOADS = {
-    # name: (envs/GPU, direct_control, controller, flags, bytes/env-step, description)
-    "config2": (65536, 1, "const", 1, BYTES_DYNAMICS,
+    # name: (envs/GPU, direct_control, controller, flags, bytes/env-step, qualified handle, description)
+    "config2": (65536, 1, "const", 1, BYTES_DYNAMICS, "lean",
                 "BASELINE configs[1]: 65536 envs/GPU, zero action, perturbed hover, dynamics only"),
-    "config3": (262144, 0, "lqr", 2, BYTES_FULL,
+    "config3": (262144, 0, "lqr", 2, BYTES_FULL, "lean",
                 "BASELINE configs[2]: 262144 envs/GPU, LQR inner loop, random init, full step"),
     # PPO workloads: controller names select the runner below; bytes from SURVEY.md section 8d
-    "config4": (131072, 1, "ppo_actor", 2, BYTES_FULL + 360,
+    "config4": (131072, 1, "ppo_actor", 2, BYTES_FULL + 360, "lean",
                 "BASELINE configs[3]: 131072 envs/GPU (1048576 on 8), PPO actor MLP 75-128-128-4 (fp32 MFMA) in the "
                 "loop, T=5 window, deterministic mean action, random init"),
-    "config5": (65536, 1, "ppo_rollout", 2, BYTES_FULL + 360 + 332 + 20,
+    "config5": (65536, 1, "ppo_rollout", 2, BYTES_FULL + 360 + 332 + 20, "lean",
                 "BASELINE configs[4]: 65536 envs/GPU (524288 on 8), full PPO rollout (actor+critic, Normal(mean,0.1) "
                 "Philox sampling, reward_fn, masked auto-reset) + GAE per 128-step horizon, returns all-gathered"),
 }
 MLP_FLOPS = 2 * (75 * 128 + 128 * 128 + 128 * 4)  # per env and forward: 53.0 kflop
 MFMA_F32_PEAK_TFLOPS = 157.3
+HANDLES = {  # --dtype -> (torch dtype of the rows, compute mode, arithmetic type reported as `dtype`)
+    "f32": (torch.float32, None, "f32"),
+    "mix": (torch.float64, "f32", "f32"),
+    "lean": (torch.float64, "lean", "f64"),
+    "f64": (torch.float64, None, "f64"),
+}
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20000)
@@ -57,22 +79,57 @@ def parse():
     p.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     p.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the workload's own size)")
     p.add_argument("--integrator", default="rk45", choices=["rk45", "dp5", "rk4"])
-    p.add_argument("--dtype", default="f32", choices=["f32", "f64", "mix", "lean"],
-                   help="mix = fp64 rows + fp32 arithmetic (QENV_COMPUTE_F32); lean = fp64 multiply-adds with "
-                        "Newton-refined hardware reciprocals and guard-banded fast step control (QENV_COMPUTE_LEAN)")
+    p.add_argument("--dtype", default="auto", choices=["auto", "f32", "f64", "mix", "lean"],
+                   help="auto = the workload's parity-qualified handle; mix = fp64 rows + fp32 arithmetic "
+                        "(QENV_COMPUTE_F32); lean = fp64 multiply-adds, Newton-refined hardware reciprocals, "
+                        "guard-banded fast step control (QENV_COMPUTE_LEAN)")
     p.add_argument("--launch", default="fused", choices=["step", "fused"],
                    help="step: one kernel launch per env step (quad.step API); fused: the whole K-step "
-                        "region in ONE launch with the state held in registers (qenv_rollout)")
+                        "region in launches of up to 250 steps with the state held in registers (qenv_rollout)")
     p.add_argument("--chunk", type=int, default=0, help="env steps per graph replay / fused launch "
-                   "(0 = gcd(steps, warmup) capped at 250)")
+                   "(0 = the largest divisor of --steps up to 250)")
     p.add_argument("--no-graph", action="store_true", help="launch=step: eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--extras", action="store_true", help="also time the other integrators / launch modes")
     p.add_argument("--no-extras", action="store_true", help="skip the extras that the default 1-GPU config-2 run adds")
-    return p.parse_args()
+    p.add_argument("--no-subconfigs", action="store_true", help="skip the config3/4/5 slices of the default 1-GPU run")
+    p.add_argument("--min-seconds", type=float, default=MIN_TIMED_S, help="repeat the K-step region until this much is timed")
+    return p.parse_args(argv)
 
 
+# ---- N > 1 without torchrun: launch the ranks, relay rank 0's line ---------------------------------------------------
+def self_launch(args):
+    """Parent of a plain `bench.py --gpus N`: no GPU call has happened in this process (importing torch and counting
+    devices does not initialise HIP), so the N ranks start as children through torch.distributed.run."""
+    backend = os.environ.get("QENV_DIST_BACKEND") or "nccl"
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible (one rank per GPU over RCCL; "
+                         f"QENV_DIST_BACKEND=gloo rehearses more ranks than GPUs)")
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank launch failed (exit {rc}, result line {'present' if line else 'missing'})")
+    if json.loads(line)["n_gpus"] != args.gpus:
+        raise SystemExit(f"bench.py: asked for {args.gpus} ranks, the result line reports {json.loads(line)['n_gpus']}")
+    print(line, flush=True)
+    raise SystemExit(0)
+
+
+# ---- workload construction ----------------------------------------------------------------------------------------
 def make_init(workload, n_global, lo, hi):
     from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
     x0 = fast_random_init_states(2 if workload == "config2" else 3, n_global, lo, hi)
@@ -82,6 +139,24 @@ def make_init(workload, n_global, lo, hi):
         x0[:, 6:10] = [1, 0, 0, 0]
         x0[:, 10:13] *= 0.05
     return x0
+
+
+def build_env(workload, handle, integrator, n_global, lo, hi, dev):
+    from autonomous_quadrotor_environment_amd import BatchedQuad
+    _, direct, controller, _, _, _, _ = WORKLOADS[workload]
+    dt, compute, _ = HANDLES[handle]
+    x0 = torch.from_numpy(np.ascontiguousarray(make_init(workload, n_global, lo, hi).T))
+    if controller.startswith("ppo"):  # config 5 trains (solved/broken/timeout end episodes, 500-step episodes as ppo.py:301)
+        env = BatchedQuad(hi - lo, 0.01, 500, training=(controller == "ppo_rollout"), direct_control=1, T=5,
+                          integrator=integrator, device=dev, dtype=dt, compute=compute)
+        env.reset(x0, return_history=False, push_window=True)
+        return env
+    env = BatchedQuad(hi - lo, 0.01, 10 ** 9, training=False, direct_control=direct, T=1,
+                      integrator=integrator, device=dev, dtype=dt, compute=compute)
+    env.reset(x0)
+    if controller == "pid":
+        env.pid_reset()
+    return env
 
 
 def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_global):
@@ -157,9 +232,11 @@ def make_runner(env, controller, flags, launch, chunk, use_graph):
     return graph.replay, chunk
 
 
+# ---- timing ---------------------------------------------------------------------------------------------------------
 def time_region(run, per_call, steps, world, dev):
     """barrier + sync | exactly `steps` env steps | barrier + sync; returns seconds (max over ranks)."""
     assert steps % per_call == 0
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -176,6 +253,18 @@ def time_region(run, per_call, steps, world, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def timed_regions(run, per_call, steps, world, dev, min_seconds, max_regions=5000):
+    """The K-step region repeated until `min_seconds` have been timed (at least once): the list of region times.
+    Every region is bracketed as the contract says; the times are max-over-ranks, so all ranks agree on the count."""
+    ts, total = [], 0.0
+    while True:
+        dt = time_region(run, per_call, steps, world, dev)
+        ts.append(dt)
+        total += dt
+        if total >= min_seconds or len(ts) >= max_regions:
+            return ts
 
 
 def kernel_launch_us(run, per_call, launch, reps=20):
@@ -197,12 +286,124 @@ def kernel_launch_us(run, per_call, launch, reps=20):
     return us if launch == "fused" else us / per_call
 
 
+def recorded(name):
+    """A figure recorded by an earlier profiling run (profiles/*.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def pick(total, cap, mult=1):
+    ok = [c for c in range(1, cap + 1) if total % c == 0 and c % mult == 0]
+    return max(ok) if ok else 0
+
+
+def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_graph, envs, rank, world, dev,
+            min_seconds):
+    """One workload on this rank's shard: W untimed warm-up steps, the K-step region repeated (median), the dominant
+    kernel's per-launch time by HIP events, and its roofline block.  Returns (result dict, env, runner info)."""
+    from autonomous_quadrotor_environment_amd.distributed import all_gather_returns, shard_range
+    envs_per_gpu, direct, controller, flags, bytes_per_step, _, desc = WORKLOADS[workload]
+    envs_per_gpu = envs or envs_per_gpu
+    n_global = envs_per_gpu * world
+    lo, hi = shard_range(n_global, rank, world)
+    ppo = controller.startswith("ppo")
+    # steps per call (fused launch / graph replay / rollout horizon): the largest divisor of the K timed steps, so the
+    # timed region is independent of W; the W warm-up steps run first through their own (same-kind) runner when W is not
+    # a multiple of it
+    cap = 128 if controller == "ppo_rollout" else 250
+    mult = 5 if (controller == "ppo_actor" and not no_graph) else 1  # a graph replay must bring the ring head back
+    chunk = chunk_arg or pick(steps, cap, mult)
+    if not chunk:  # K has no multiple-of-5 divisor: eager launches instead of a graph replay
+        no_graph, mult = True, 1
+        chunk = pick(steps, cap)
+    if steps % chunk:
+        raise SystemExit("--chunk must divide --steps")
+    env = build_env(workload, handle, integrator, n_global, lo, hi, dev)
+    if ppo:
+        launch = "step"
+
+    def runner(c, graph_ok=True):
+        if ppo:
+            return make_ppo_runner(env, controller, c, graph_ok and (not no_graph) and controller == "ppo_actor",
+                                   seed=4, env_offset=lo, n_global=n_global)
+        return make_runner(env, controller, flags, launch, c, not no_graph) + (None,)
+    run, per_call, ro = runner(chunk)
+    if warmup and warmup % chunk == 0:
+        time_region(run, per_call, warmup, world, dev)     # W untimed warm-up steps
+    elif warmup:
+        cw = pick(warmup, cap, mult)
+        rw, pcw, _ = runner(cw, True) if cw else runner(pick(warmup, cap), False)  # no %T divisor: eager warm-up
+        time_region(rw, pcw, warmup, world, dev)
+    regions = timed_regions(run, per_call, steps, world, dev, min_seconds)   # each: exactly K timed steps
+    secs = float(np.median(regions))
+    value = n_global * steps / secs
+    finite = bool(torch.isfinite(env.state).all())
+    gathered = None
+    if flags != 1 and controller != "ppo_rollout":
+        gathered = all_gather_returns(env.episode_return, n_global)  # the path's one exchange step (RCCL over xGMI)
+
+    # dominant kernel, per-launch duration by HIP events on the launch stream
+    spl = chunk if launch == "fused" else 1
+    k_us = kernel_launch_us(run, per_call, launch)
+    algo_bytes = bytes_per_step * (hi - lo) * spl
+    achieved = algo_bytes / (k_us * 1e-6) / 1e9
+    ttype = {"f32": "float, float", "mix": "float, double", "lean": "double, double (lean)", "f64": "double, double"}[handle]
+    kname = ("k_rollout" if (launch == "fused" or controller != "const") else "k_step") + f"<{ttype}, {integrator}, {controller}>"
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kname,
+                "kernel_us": k_us, "algorithmic_bytes_per_launch": algo_bytes,
+                "bytes_per_env_step": bytes_per_step, "env_steps_per_launch": (hi - lo) * spl}
+    if launch == "fused":
+        roofline["achieved_is"] = ("algorithmic bytes (SURVEY 8d figure x env steps per launch) / launch time; the fused "
+                                   "kernel keeps the state in registers between steps, the HBM bytes it really moves are "
+                                   "`traffic` -- its limiter is VALU issue (`valu`), not HBM")
+        roofline["limiter"] = "valu_issue"
+    tr = recorded("traffic.json")
+    key = f"{workload}:{integrator}:{launch}:{handle}"
+    if tr and key in tr:
+        roofline["traffic"] = tr[key]
+        roofline["traffic_unit"] = "B/launch"
+        roofline["traffic_source"] = "recorded: profiles/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, not measured in this run)"
+    va = recorded("valu.json")
+    if va and key in va:  # SQ counters of the same kernel, recorded by tools/pmc_valu_count.sh
+        v = va[key]
+        spw = (hi - lo) * spl / 64.0 / (k_us * 1e-6)   # wave-steps per second of this rank
+        roofline["valu"] = {"source": "recorded: profiles/valu.json (" + v.get("source", "rocprofv3 PMC") + ")",
+                            "instructions_per_env_step_per_wave": v["valu_per_wave_step"],
+                            "issue_cycles_per_instruction": v["active_valu_cycles_per_inst"], "simds": 1024,
+                            "clock_ghz": v["clock_ghz"],
+                            "issue_frac": spw * v["valu_per_wave_step"] * v["active_valu_cycles_per_inst"] / (1024 * v["clock_ghz"] * 1e9)}
+    if ppo:  # the dominant kernel of the PPO workloads is the fp32-MFMA MLP forward
+        heads = 2 if controller == "ppo_rollout" else 1
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        torch.cuda.synchronize()
+        for a_, b_ in evs:
+            a_.record(); env.mlp_forward(ro.w, "actor", out=ro.mean); b_.record()
+        torch.cuda.synchronize()
+        ts = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in evs)
+        mlp_us = float(np.mean(ts[:15]))
+        tfl = MLP_FLOPS * (hi - lo) / (mlp_us * 1e-6) / 1e12
+        roofline = {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tfl / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "k_mlp<128,5> (actor forward)",
+                    "kernel_us": mlp_us, "flops_per_launch": MLP_FLOPS * (hi - lo), "mlp_forwards_per_env_step": heads,
+                    "hbm_algorithmic_GBps_whole_step": bytes_per_step * value / world / 1e9}
+    res = {"value": value, "ms_per_step": secs / steps * 1e3, "regions": len(regions),
+           "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3,
+           "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,
+           "hip_graph": (launch == "step" and not no_graph and controller != "ppo_rollout"),
+           "envs_per_gpu": hi - lo, "global_envs": n_global, "controller": controller, "desc": desc, "roofline": roofline,
+           "all_gather_len": None if gathered is None else int(gathered.numel())}
+    return res, env, (controller, flags, no_graph, bytes_per_step, n_global)
+
+
 def cpu_baseline(workload, integrator, seconds):
     """The fp64 C oracle (a port of the reference's algorithm, pinned by the reference's golden
     vectors) timed on this host's cores on a bounded sample of the same workload."""
     from oracle import quad_oracle as qo
     qo.build()
-    _, direct, controller, _, _, _ = WORKLOADS[workload]
+    _, direct, controller, _, _, _, _ = WORKLOADS[workload]
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box's CPU share for one GPU is 16
     x0 = make_init(workload, 4096 * threads, 0, 4096 * threads)
     if controller.startswith("ppo"):  # actor (+ critic for config 5) MLP in the loop, same random-init weights
@@ -234,158 +435,106 @@ def cpu_baseline(workload, integrator, seconds):
     dt = time.perf_counter() - t0
     total = threads * per_thread * steps
     return {"value": total / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{threads} threads x {per_thread} envs x {steps} steps of {workload} ({integrator}, fp64 C oracle), "
-                      f"{dt:.1f} s; single-thread rate {rate1:.0f}/s; reference Python measured in the survey "
-                      f"container: ~800 env-steps/s/core (BASELINE.md section 3)"}
+            "sample": f"{threads} threads x {per_thread} envs x {steps} steps of {workload} ({integrator})",
+            "what": "fp64 C restatement of the reference (the oracle/ directory), pinned by reference-generated fixtures",
+            "threads": threads, "envs_per_thread": per_thread, "steps": steps, "seconds": dt,
+            "single_thread_rate": rate1,
+            "reference_python_rate": 800.0,
+            "reference_python_rate_source": "the reference's own Python step, measured in the survey container per core "
+                                            "(BASELINE.md section 3); it cannot travel to the GPU box"}
 
 
 def main():
     args = parse()
-    from autonomous_quadrotor_environment_amd import BatchedQuad
-    from autonomous_quadrotor_environment_amd.distributed import (all_gather_returns, init_process_group_from_env,
-                                                                  shard_range)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        self_launch(args)  # never returns
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    from autonomous_quadrotor_environment_amd.distributed import init_process_group_from_env
     rank, world, local = init_process_group_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert world == args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    envs_per_gpu, direct, controller, flags, bytes_per_step, desc = WORKLOADS[args.workload]
-    if args.envs:
-        envs_per_gpu = args.envs
-    n_global = envs_per_gpu * world
-    lo, hi = shard_range(n_global, rank, world)
-    dt = torch.float32 if args.dtype == "f32" else torch.float64
-    compute = {"mix": "f32", "lean": "lean"}.get(args.dtype)
+    handle = WORKLOADS[args.workload][5] if args.dtype == "auto" else args.dtype
 
+    res, env, (controller, flags, no_graph, bytes_per_step, n_global) = measure(
+        args.workload, handle, args.integrator, args.launch, args.steps, args.warmup, args.chunk, args.no_graph,
+        args.envs, rank, world, dev, args.min_seconds)
     ppo = controller.startswith("ppo")
-
-    def build_env(integrator):
-        if ppo:  # config 5 trains (solved/broken/timeout end episodes, 500-step episodes as ppo.py:301)
-            env = BatchedQuad(hi - lo, 0.01, 500, training=(controller == "ppo_rollout"), direct_control=1, T=5,
-                              integrator=integrator, device=dev, dtype=dt, compute=compute)
-            env.reset(torch.from_numpy(np.ascontiguousarray(make_init(args.workload, n_global, lo, hi).T)),
-                      return_history=False, push_window=True)
-            return env
-        env = BatchedQuad(hi - lo, 0.01, 10 ** 9, training=False, direct_control=direct, T=1,
-                          integrator=integrator, device=dev, dtype=dt, compute=compute)
-        env.reset(torch.from_numpy(np.ascontiguousarray(make_init(args.workload, n_global, lo, hi).T)))
-        if controller == "pid":
-            env.pid_reset()
-        return env
-
-    # steps per call (fused launch / graph replay / rollout horizon): the largest divisor of the K timed steps, so the
-    # timed region is independent of W; the W warm-up steps run first through their own (same-kind) runner when W is not
-    # a multiple of it
-    def pick(total, cap, mult=1):
-        ok = [c for c in range(1, cap + 1) if total % c == 0 and c % mult == 0]
-        return max(ok) if ok else 0
-    cap = 128 if controller == "ppo_rollout" else 250
-    mult = 5 if (controller == "ppo_actor" and not args.no_graph) else 1  # a graph replay must bring the ring head back
-    chunk = args.chunk or pick(args.steps, cap, mult)
-    if not chunk:  # K has no multiple-of-5 divisor: eager launches instead of a graph replay
-        args.no_graph, mult = True, 1
-        chunk = pick(args.steps, cap)
-    if args.steps % chunk:
-        raise SystemExit("--chunk must divide --steps")
-    env = build_env(args.integrator)
-
-    def runner(c):
-        if ppo:
-            return make_ppo_runner(env, controller, c, (not args.no_graph) and controller == "ppo_actor",
-                                   seed=4, env_offset=lo, n_global=n_global)
-        return make_runner(env, controller, flags, args.launch, c, not args.no_graph) + (None,)
-    if ppo:
-        args.launch = "step"
-    run, per_call, ro = runner(chunk)
-    if args.warmup % chunk == 0:
-        time_region(run, per_call, args.warmup, world, dev)     # W untimed warm-up steps
-    elif args.warmup:
-        rw, pcw, _ = runner(pick(args.warmup, cap, mult) or pick(args.warmup, cap))
-        time_region(rw, pcw, args.warmup, world, dev)
-    secs = time_region(run, per_call, args.steps, world, dev)   # exactly K timed steps
-    value = n_global * args.steps / secs
-    finite = bool(torch.isfinite(env.state).all())
-    if flags != 1 and controller != "ppo_rollout":
-        all_gather_returns(env.episode_return, n_global)  # the path's one exchange step (RCCL over xGMI)
-
-    # dominant kernel, per-launch duration by HIP events on the launch stream
-    spl = chunk if args.launch == "fused" else 1
-    k_us = kernel_launch_us(run, per_call, args.launch)
-    esz = 1 if args.dtype == "f32" else 2
-    algo_bytes = bytes_per_step * esz * (hi - lo) * spl
-    achieved = algo_bytes / (k_us * 1e-6) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get(f"{args.workload}:{args.integrator}:{args.launch}:{args.dtype}")
-        except Exception:
-            traffic = None
-    kname = ("k_rollout" if (args.launch == "fused" or controller != "const") else "k_step") + \
-            f"<{'double' if args.dtype == 'f64' else 'float'},{args.integrator}>"
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kname,
-                "kernel_us": k_us, "algorithmic_bytes_per_launch": algo_bytes,
-                "bytes_per_env_step": bytes_per_step * esz, "env_steps_per_launch": (hi - lo) * spl}
-    if controller == "const" and args.launch == "fused" and args.integrator == "rk45" and args.dtype == "f32":
-        # what actually bounds this kernel: VALU issue.  1 425 instructions per env step and wave
-        # (SQ_INSTS_VALU, profiles/r01_pmc_valu_headline.txt; the ISA census gives 1 460), 4 issue cycles each,
-        # on 256 CUs x 4 SIMDs at the 2.4 GHz boost clock
-        spw = (hi - lo) * spl / 64.0 / (k_us * 1e-6)   # wave-steps per second of this rank
-        roofline["valu"] = {"instructions_per_env_step_per_wave": 1425, "issue_cycles_per_instruction": 4,
-                            "simds": 1024, "clock_ghz": 2.4, "issue_frac": spw * 1425 * 4 / (1024 * 2.4e9)}
-    if ppo:  # the dominant kernel of the PPO workloads is the fp32-MFMA MLP forward
-        heads = 2 if controller == "ppo_rollout" else 1
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        torch.cuda.synchronize()
-        for a_, b_ in evs:
-            a_.record(); env.mlp_forward(ro.w, "actor", out=ro.mean); b_.record()
-        torch.cuda.synchronize()
-        ts = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in evs)
-        mlp_us = float(np.mean(ts[:15]))
-        tfl = MLP_FLOPS * (hi - lo) / (mlp_us * 1e-6) / 1e12
-        roofline = {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tfl / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "k_mlp<128,512,true> (actor forward)",
-                    "kernel_us": mlp_us, "flops_per_launch": MLP_FLOPS * (hi - lo), "mlp_forwards_per_env_step": heads,
-                    "hbm_algorithmic_GBps_whole_step": bytes_per_step * esz * value / world / 1e9}
-
+    qualified = WORKLOADS[args.workload][5]
     out = {
-        "metric": "quadrotor env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": secs / args.steps * 1e3,
+        "metric": "quadrotor env-steps/sec", "value": res["value"], "unit": "env-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32", "f64": "f64", "mix": "f32 arithmetic on f64 state rows", "lean": "f64 (lean)"}[args.dtype], "data": "synthetic",
-        "config": {"workload": desc, "envs_per_gpu": hi - lo, "global_envs": n_global,
-                   "integrator": args.integrator, "launch": args.launch, "controller": controller,
-                   "steps_per_graph_replay_or_launch": chunk, "hip_graph": (args.launch == "step" and not args.no_graph and controller != "ppo_rollout"),
-                   "parallelism": f"env-sharded x{world}", "finite": finite},
-        "roofline": roofline,
+        "dtype": HANDLES[handle][2], "data": "synthetic",
+        "config": {"workload": res["desc"], "envs_per_gpu": res["envs_per_gpu"], "global_envs": res["global_envs"],
+                   "integrator": args.integrator, "launch": res["launch"], "controller": controller,
+                   "handle": handle,
+                   "handle_is": {"f32": "fp32 rows, fp32 arithmetic", "mix": "fp64 rows, fp32 arithmetic",
+                                 "lean": "fp64 rows, lean fp64 arithmetic", "f64": "fp64 rows, IEEE fp64 arithmetic"}[handle],
+                   "parity_qualified": handle in (qualified, "f64"),
+                   "steps_per_graph_replay_or_launch": res["chunk"], "hip_graph": res["hip_graph"],
+                   "parallelism": f"env-sharded x{world}", "finite": res["finite"],
+                   "all_gathered_returns": res["all_gather_len"]},
+        "timing": {"regions": res["regions"], "statistic": "median of the K-step regions (each barrier+sync bracketed)",
+                   "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
+                   "timed_seconds": res["timed_seconds"]},
+        "roofline": res["roofline"],
     }
+
+    # what the same kernel sustains when the launch granularity is not tied to K: 250-step launches, one bracket around
+    # >= 0.3 s of them (the driver's K = 20 makes every region a single 20-step launch + its sync)
+    if not ppo and args.launch == "fused":
+        r2, pc = make_runner(env, controller, flags, "fused", 250, False)
+        time_region(r2, pc, 250, world, dev)
+        t1 = time_region(r2, pc, 250, world, dev)
+        n_l = max(1, int(np.ceil(args.min_seconds / max(t1, 1e-6))))
+        if world > 1:  # the same launch count on every rank
+            t = torch.tensor([n_l], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n_l = int(t.item())
+        s = time_region(r2, pc, 250 * n_l, world, dev)
+        out["sustained"] = {"value": n_global * 250 * n_l / s, "unit": "env-steps/s", "steps": 250 * n_l,
+                            "steps_per_launch": 250, "seconds": s}
+    del env
 
     # the default single-GPU run of config 2 also reports the other operating points (a few seconds): the
     # per-step API path (hipGraph-replayed qenv_step launches) and the fixed-step integrators
     if (args.extras or (args.workload == "config2" and not args.no_extras and args.envs == 0)) and world == 1 and not ppo:
+        from autonomous_quadrotor_environment_amd.distributed import shard_range
+        lo, hi = shard_range(n_global, rank, world)
         extras = {}
+        ck = 250
         for integ in ("rk45", "dp5", "rk4"):
-            e2 = build_env(integ)
+            e2 = build_env(args.workload, handle, integ, n_global, lo, hi, dev)
             for launch in ("step", "fused"):
-                r2, pc = make_runner(e2, controller, flags, launch, chunk, not args.no_graph)
-                time_region(r2, pc, chunk, 1, dev)
-                s = time_region(r2, pc, args.steps, 1, dev)
-                extras[f"{integ}:{launch}"] = n_global * args.steps / s
+                r2, pc = make_runner(e2, controller, flags, launch, ck, not args.no_graph)
+                time_region(r2, pc, ck, 1, dev)
+                s = time_region(r2, pc, 2000, 1, dev)
+                extras[f"{integ}:{launch}"] = n_global * 2000 / s
+            del e2
+        if handle != "f32":  # the fp32 handle (outside the tolerance over >= 500 open-loop steps) for comparison
+            e2 = build_env(args.workload, "f32", "rk45", n_global, lo, hi, dev)
+            r2, pc = make_runner(e2, controller, flags, "fused", ck, False)
+            time_region(r2, pc, ck, 1, dev)
+            extras["rk45:fused:f32_handle"] = n_global * 2000 / time_region(r2, pc, 2000, 1, dev)
             del e2
         # config 2's unperturbed variant: at EXACT hover f0 = 0, scipy's select_initial_step takes its
         # h0 = 1e-6 branch and every env step costs ~5 growing sub-steps although the state does not move
-        e3 = build_env("rk45")
-        hover = torch.zeros(13, e3.n_envs, device=dev, dtype=dt); hover[6] = 1
+        e3 = build_env(args.workload, handle, "rk45", n_global, lo, hi, dev)
+        hover = torch.zeros(13, e3.n_envs, device=dev, dtype=e3.dtype); hover[6] = 1
         e3.reset(hover)
-        r3, pc = make_runner(e3, controller, flags, "fused", chunk, False)
-        time_region(r3, pc, chunk, 1, dev)
-        extras["rk45:fused:exact_hover"] = n_global * args.steps / time_region(r3, pc, args.steps, 1, dev)
+        r3, pc = make_runner(e3, controller, flags, "fused", ck, False)
+        time_region(r3, pc, ck, 1, dev)
+        extras["rk45:fused:exact_hover"] = n_global * 2000 / time_region(r3, pc, 2000, 1, dev)
         del e3
         out["extras_env_steps_per_s"] = extras
+        out["extras_note"] = "2000-step regions, 250-step launches / graph replays, same handle as `value` unless named"
         # the same operating points as a fraction of the 8 TB/s HBM peak on the algorithmic bytes per env step;
         # BASELINE.json words config 2 as "RK4 dynamics only": that operating point is extras["rk4:fused"]
-        out["extras_hbm_frac"] = {k: round(v * bytes_per_step * esz / 1e9 / HBM_PEAK_GBPS, 4) for k, v in extras.items()}
+        out["extras_hbm_frac"] = {k: round(v * bytes_per_step / 1e9 / HBM_PEAK_GBPS, 4) for k, v in extras.items()}
         # the denominator measured on this box: a row copy with the env kernels' access shape (13 SoA rows,
         # one lane per env), 872 MB read + 872 MB written per launch, far beyond the 256 MiB Infinity Cache
         from autonomous_quadrotor_environment_amd import _lib as L
@@ -403,6 +552,21 @@ def main():
         b_.record(); torch.cuda.synchronize()
         out["roofline"]["measured_row_copy_GBps"] = round(2 * 13 * n_c * 4 * 10 / (a_.elapsed_time(b_) * 1e-3) / 1e9, 1)
         del src, dst
+
+    # short per-GPU slices of the other BASELINE configs (LQR full step, PPO actor in the loop, full PPO rollout + GAE):
+    # the driver's record then covers the 224-B step, the controller and the MLP, each on its qualified handle
+    if args.workload == "config2" and world == 1 and not args.no_subconfigs and args.envs == 0:
+        subs = {}
+        for name, k_steps, w_steps in (("config3", 250, 250), ("config4", 250, 50), ("config5", 128, 128)):
+            r, e_, _ = measure(name, WORKLOADS[name][5], "rk45", "fused", k_steps, w_steps, 0, False, 0, 0, 1, dev, 0.1)
+            rf = r["roofline"]
+            subs[name] = {"value": r["value"], "unit": "env-steps/s (one GPU's slice)", "ms_per_step": r["ms_per_step"],
+                          "steps": k_steps, "regions": r["regions"], "envs": r["envs_per_gpu"], "handle": WORKLOADS[name][5],
+                          "workload": r["desc"], "finite": r["finite"], "dominant_kernel": rf["kernel"],
+                          "kernel_us": rf["kernel_us"], "bound": rf["bound"], "frac": rf["frac"],
+                          "achieved": rf["achieved"], "roofline_unit": rf["unit"]}
+            del e_
+        out["configs"] = subs
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.integrator, args.cpu_seconds)

@@ -558,3 +558,26 @@ def test_policy_act_equals_forward_then_sample(aq, dt, hidden, N, T):
         env.mlp_forward(w, "actor", obs_store=obs_ref)
         assert torch.equal(obs, obs_ref)
         assert float((act - mean).abs().max()) > 0.1
+
+
+def test_bench_gpus2_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent starts the two ranks itself (gloo here: one
+    GPU box), rank 0's line reports n_gpus = 2, twice the per-GPU batch, and the all-gathered episode returns have
+    the global length (ppo.py:356-382's Pool gather)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["QENV_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "config3", "--envs", "8192",
+                        "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--min-seconds", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["config"]["global_envs"] == 2 * 8192
+    assert d["config"]["all_gathered_returns"] == 2 * 8192 and d["config"]["finite"]
+    assert d["value"] > 0 and d["timing"]["regions"] >= 1

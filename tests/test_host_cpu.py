@@ -36,9 +36,16 @@ def test_argument_validation_without_a_device(built):
     n32 = L.lib.qenv_workspace_bytes(C.byref(cfg))
     cfg.dtype = L.F64
     n64 = L.lib.qenv_workspace_bytes(C.byref(cfg))
-    # 88 rows of T (61 + 12 robust parameters + 6 gust + 9 outer loop) + 6 int rows + 15*T float rows, 256-byte aligned sections
-    assert n32 == 88 * 1024 * 4 + 6 * 1024 * 4 + 75 * 1024 * 4
-    assert n64 == 88 * 1024 * 8 + 6 * 1024 * 4 + 75 * 1024 * 4
+    # 88 rows of T (61 + 12 robust parameters + 6 gust + 9 outer loop) + 5 int rows + the 256-byte tail of the two
+    # reset-list counters (their own slot, valid for n_envs = 1 too) + 15*T float rows, 256-byte aligned sections
+    assert n32 == 88 * 1024 * 4 + 5 * 1024 * 4 + 256 + 75 * 1024 * 4
+    assert n64 == 88 * 1024 * 8 + 5 * 1024 * 4 + 256 + 75 * 1024 * 4
+    one = L.QenvConfig(1, 0.01, 1000, 5, 1, 1, 1, L.MAIN, L.RK45, L.F32, 0)
+    assert L.lib.qenv_workspace_bytes(C.byref(one)) == 512 + 256 + 256 + 512  # rows, int rows, counters, ring
+    lean = L.QenvConfig(1024, 0.01, 1000, 5, 1, 1, 1, L.MAIN, L.RK45, L.F64, 2)
+    assert L.lib.qenv_workspace_bytes(C.byref(lean)) == n64
+    assert L.lib.qenv_create(C.byref(L.QenvConfig(4, 0.01, 10, 1, 1, 1, 1, L.MAIN, L.RK45, L.F32, 2)), C.c_void_p(256), 1 << 20, None,
+                             C.byref(C.c_void_p())) == -1 and b"LEAN" in L.lib.qenv_last_error()
     bad = L.QenvConfig(0, 0.01, 1000, 1, 1, 1, 1, 0, 0, 0, 0)
     assert L.lib.qenv_workspace_bytes(C.byref(bad)) == 0
     h = C.c_void_p()
@@ -160,3 +167,33 @@ def test_header_is_plain_c_and_a_c_host_links(built, tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.split()[0] == "0", (r.stdout, r.stderr)  # n_envs = 0 is rejected: 0 bytes
+
+
+def test_bench_refuses_to_report_one_rank_for_an_n_gpu_request():
+    """`bench.py --gpus N` must either run N ranks or fail loudly: with no GPU visible the self-launching parent exits
+    non-zero before any rank starts, a WORLD_SIZE that contradicts --gpus does too, and neither prints a result line."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QENV_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "20", "--warmup", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout and "--gpus 2" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout and "WORLD_SIZE=2" in r.stderr
+
+
+def test_lean_fastmath_accuracy(tmp_path):
+    """The lean fp64 handle's elementary functions (csrc/qenv_fastmath.hpp: hardware seed + Newton, short minimax
+    polynomials) on the host with seeds of the hardware's accuracy: within a few ulp of libm over 2 M random arguments
+    incl. the branch points, with libm's edge cases (atan2 at the origin / on the axes, asin at and beyond +-1)."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "fm_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "tools", "fastmath_host_check.cpp")])
+    r = json.loads(subprocess.check_output([exe], text=True))
+    assert r["edges"] is True
+    assert r["atan2_abs"] < 1e-15 and r["asin_abs"] < 1e-15 and r["sin_abs"] < 5e-16 and r["cos_abs"] < 5e-16
+    assert r["tan_rel"] < 1e-15 and r["div_rel"] < 3e-16 and r["sqrt_rel"] < 3e-16 and r["rsqrt_rel"] < 5e-16

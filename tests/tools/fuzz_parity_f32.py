@@ -1,6 +1,12 @@
-"""GPU box: teacher-forced ONE-STEP error of the fp32 handle against the fp64 C oracle over random points of the
-configuration space (as tests/tools/fuzz_parity.py): before every step the fp32 env's state rows are overwritten with the
-oracle's state, so each comparison isolates one step's arithmetic (north-star: 1e-5 on the scale-floored metric)."""
+"""GPU box: teacher-forced ONE-STEP error of the fp32-arithmetic handles (fp32, or mixed with QENV_FUZZ_HANDLE=mix)
+against the fp64 C oracle over random points of the configuration space (as tests/tools/fuzz_parity.py): before every step
+the env's state rows are overwritten with the oracle's state, so each comparison isolates one step's arithmetic.
+
+Pass criterion = the north-star: every component within 1e-5 on the scale-floored metric |d| / max(|ref|, 1e-3 scale),
+with ONE documented exemption: a component whose reference value sits AT the metric's floor (|ref| <= 2e-3 scale) is held
+to the absolute bound |d| <= 1.5e-8 scale instead (at the floor the relative metric divides an absolute fp32 rounding of
+an O(1) increment -- e.g. 2e-7 rad/s on a body rate that changes by 3 rad/s in the step -- by the floor itself; 1.05e-5
+was the worst seen in 2.5 M steps, always on such a component).  Every floor-crossing sample is printed with its margin."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -11,8 +17,10 @@ O.build()
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 SC = np.array([5, 10, 5, 10, 5, 10, 1, 1, 1, 1, 20, 20, 20.0])
+HANDLE = os.environ.get("QENV_FUZZ_HANDLE", "f32")
 worst = 0.0
 hist = []
+violations, floor_cases = [], []
 for case in range(n_cases):
     variant = ["main", "opt"][rng.randint(2)]
     integ = ["rk45", "dp5", "rk4"][rng.randint(3)]
@@ -23,7 +31,8 @@ for case in range(n_cases):
         t_step = float(sys.argv[3])  # e.g. 0.01: the only step size the reference's scripts use
     N, S = 32, 25
     kw = dict(training=False, direct_control=direct, T=1, clipped=clipped, variant=variant, integrator=integ)
-    env = aq.BatchedQuad(N, t_step, 10 ** 6, dtype=torch.float32, **kw)
+    env = aq.BatchedQuad(N, t_step, 10 ** 6, dtype=torch.float64 if HANDLE == "mix" else torch.float32,
+                         compute="f32" if HANDLE == "mix" else None, **kw)
     refs = [O.OracleQuad(t_step, 10 ** 6, euler=0, **kw) for _ in range(N)]
     x0 = aq.random_init_states(rng, N, variant) * rng.choice([0.2, 1.0])
     x0[:, 6:10] /= np.linalg.norm(x0[:, 6:10], axis=1, keepdims=True)
@@ -33,7 +42,7 @@ for case in range(n_cases):
     err, worst_at = 0.0, None
     for k in range(S):
         prev = np.stack([r.state for r in refs], 1)
-        env.state.copy_(torch.from_numpy(prev).to("cuda", torch.float32))
+        env.state.copy_(torch.from_numpy(prev.astype(np.float32).astype(np.float64)).to("cuda", env.dtype))
         if direct:
             a = rng.normal(0, rng.choice([0.3, 1.5]), (4, N))
         else:
@@ -45,11 +54,24 @@ for case in range(n_cases):
             # the oracle starts the step from the fp32-rounded state the device was given
             r.set_previous_state(prev[:, e].astype(np.float32).astype(np.float64))
             r.step(a[:, e])
-            ev = np.abs(S_[:, e] - r.state) / np.maximum(np.abs(r.state), 1e-3 * SC)
+            d = np.abs(S_[:, e] - r.state)
+            ev = d / np.maximum(np.abs(r.state), 1e-3 * SC)
+            over = ev > 1e-5
+            if over.any():
+                at_floor = np.abs(r.state) <= 2e-3 * SC
+                for c in np.flatnonzero(over):
+                    rec = dict(case=case, step=k, env=e, component=int(c), ref=float(r.state[c]), abs_err=float(d[c]),
+                               scaled=float(ev[c]), abs_err_over_scale=float(d[c] / SC[c]))
+                    (floor_cases if (at_floor[c] and d[c] <= 1.5e-8 * SC[c]) else violations).append(rec)
             if ev.max() > err:
                 err, worst_at = float(ev.max()), dict(component=int(ev.argmax()), ref=float(r.state[ev.argmax()]),
                                                       rates=[round(float(x), 2) for x in r.state[10:13]])
     worst = max(worst, err); hist.append(err)
     print(json.dumps(dict(case=case, variant=variant, integ=integ, direct=direct, clipped=clipped, t_step=t_step, one_step_scaled_err=float(err), worst_at=worst_at)), flush=True)
-print(json.dumps(dict(cases=n_cases, worst=float(worst), median=float(np.median(hist)), p95=float(np.percentile(hist, 95)))))
-sys.exit(1 if worst > 2e-5 else 0)  # 1.01e-5 is the worst seen at t_step = 0.01 (480 000 steps), 1.7e-5 at 0.02
+for rec in floor_cases:
+    print(json.dumps(dict(floor_crossing=rec)))
+for rec in violations:
+    print(json.dumps(dict(violation=rec)))
+print(json.dumps(dict(handle=HANDLE, cases=n_cases, worst=float(worst), median=float(np.median(hist)), p95=float(np.percentile(hist, 95)),
+                      floor_crossings=len(floor_cases), violations=len(violations))))
+sys.exit(1 if violations else 0)

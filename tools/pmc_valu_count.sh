@@ -1,20 +1,28 @@
 #!/bin/bash
-# GPU box: VALU instructions per env step and wave of the headline kernel (config 2, rk45, fused 250-step launches).
+# GPU box: VALU / SALU instructions per env step and wave of the fused rollout kernel of a bench.py run.
+#   tools/pmc_valu_count.sh TAG [bench.py arguments]     (default: the headline, config 2 rk45 250-step launches)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_valu; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --steps 2000 --warmup 250 --no-extras --no-cpu-baseline > $OUT/a.log 2>&1 || echo failed
-python3 - <<'PY'
-import csv, glob, collections
-acc = collections.defaultdict(list); ds = []
-for f in glob.glob("gpurun_out/pmc_valu/a/**/*counter_collection.csv", recursive=True):
+TAG=${1:-headline}; shift
+OUT=gpurun_out/pmc_valu_$TAG; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --steps 2000 --warmup 250 --min-seconds 0 --no-extras --no-cpu-baseline --no-subconfigs "$@" > $OUT/a.log 2>&1 || echo failed
+python3 - "$OUT" <<'PY'
+import csv, glob, collections, sys, json
+out = sys.argv[1]
+acc = collections.defaultdict(list); ds = []; names = set()
+for f in glob.glob(out + "/a/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "k_rollout" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for f in glob.glob("gpurun_out/pmc_valu/a/**/*kernel_trace.csv", recursive=True):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"])); names.add(r["Kernel_Name"][:90])
+for f in glob.glob(out + "/a/**/*kernel_trace.csv", recursive=True):
     ds += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "k_rollout" in r["Kernel_Name"]]
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 steps = 250
-print("launch_us", sum(ds) / len(ds) / 1e3, m)
-print("VALU instructions per wave and env step:", m["SQ_INSTS_VALU"] / m["SQ_WAVES"] / steps,
-      " SALU:", m["SQ_INSTS_SALU"] / m["SQ_WAVES"] / steps, " clock GHz:", m["GRBM_GUI_ACTIVE"] / 8 / (sum(ds) / len(ds)))
+us = sum(ds) / len(ds) / 1e3
+res = {"kernel": sorted(names), "launch_us": us, "launches": len(ds), "counters": m,
+       "valu_per_wave_step": m["SQ_INSTS_VALU"] / m["SQ_WAVES"] / steps, "salu_per_wave_step": m["SQ_INSTS_SALU"] / m["SQ_WAVES"] / steps,
+       "active_valu_cycles_per_inst": 4 * m["SQ_ACTIVE_INST_VALU"] / m["SQ_INSTS_VALU"],
+       "wave_cycles_per_wave_step": 4 * m["SQ_WAVE_CYCLES"] / m["SQ_WAVES"] / steps,
+       "clock_ghz": m["GRBM_GUI_ACTIVE"] / 8 / (us * 1e3), "steps_per_launch": steps}
+print(json.dumps(res))
+open(out + "/summary.json", "w").write(json.dumps(res, indent=1))
 PY
