@@ -505,14 +505,79 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
 // per iteration.  On exit y = state at tb and kq = f(t_end, y_end)
 // (FSAL) whose rows 6..9 are the reference's V_q.  Every lane leaves the loop after at
 // most MAX_ATTEMPTS attempts.
+// scipy has no cap on the attempts of a step; the nominal plant needs 1-4 per env step.  A robust redraw step (a new
+// gust at every RHS evaluation) legitimately takes hundreds of rejected sub-steps, so its cap is far higher; either way
+// every lane leaves the loop after a bounded number of attempts.
+template <typename P> struct Rk45Cap { static constexpr int value = P::robust ? 16384 : 96; };
+
+// select_initial_step (common.py:66-133) from y and k1 = f(y): the first h_abs of the step.
+template <typename T, typename P>
+__device__ __forceinline__ T rk45_initial_step(const T y[13], const T k1[13], const Act<T>& u, P& pl, T tb) {
+    using m = typename P::math;
+    T d0 = T(0), d1 = T(0);
+    T isc[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        isc[i] = m::rcp_ctl(T(1e-6) + m::abs(y[i]) * T(1e-3));
+        const T a = y[i] * isc[i], b = k1[i] * isc[i];
+        d0 += a * a;
+        d1 += b * b;
+    }
+    d0 = m::sqrt_ctl(d0 * T(1.0 / 13)); d1 = m::sqrt_ctl(d1 * T(1.0 / 13));
+    T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : m::div_ctl(T(0.01) * d0, d1);
+    h0 = m::min(h0, tb);
+    T y1[13], f1[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) y1[i] = y[i] + h0 * k1[i];
+    rhs(y1, u, pl, f1);
+    T d2 = T(0);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const T a = (f1[i] - k1[i]) * isc[i];
+        d2 += a * a;
+    }
+    d2 = m::div_ctl(m::sqrt_ctl(d2 * T(1.0 / 13)), h0);
+    T h1;
+    if (d1 <= T(1e-15) && d2 <= T(1e-15)) h1 = m::max(T(1e-6), h0 * T(1e-3));
+    else h1 = m::pow_ctl(m::div_ctl(T(0.01), m::max(d1, d2)), T(0.2));
+    return m::min(m::min(T(100) * h0, h1), tb);
+}
+
+// One attempted sub-step of the accept/reject loop (rk.py:111-167) at time t with k1 = f(t, y).  Returns true when the
+// env step is over: t has reached tb, or the solver gave up (TOO_SMALL_STEP: the last accepted y stays).
+template <typename T, typename P>
+__device__ __forceinline__ bool rk45_attempt(T y[13], T k1[13], T dy[13], const Act<T>& u, P& pl, T tb, T& t, T& h_abs,
+                                             bool& rejected) {
+    using m = typename P::math;
+    const T min_step = T(10) * m::ulp_up(t);
+    if (!rejected && h_abs < min_step) h_abs = min_step;
+    if (h_abs < min_step) return true;
+    T t_new = t + h_abs;
+    if (t_new > tb) t_new = tb;
+    const T h = t_new - t;
+    h_abs = h;
+    T yn[13], k7[13], inc[13];
+    const T err2 = dp5_step<T, true>(y, k1, u, pl, h, yn, k7, inc);
+    const T err = m::sqrt_ctl(err2 * T(1.0 / 13));
+    // lean: decided on the (guard-banded) sum itself, sqrt_ctl is a hardware approximation there
+    if (m::lean ? (err2 < T(13)) : (err < T(1))) {
+        T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow_ctl(err, T(-0.2)));
+        if (rejected) factor = m::min(T(1), factor);
+        h_abs *= factor;
+        t = t_new;
+        rejected = false;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) { y[i] = yn[i]; k1[i] = k7[i]; dy[i] += inc[i]; }
+    } else {
+        h_abs *= m::max(T(0.2), T(0.9) * m::pow_ctl(err, T(-0.2)));
+        rejected = true;
+    }
+    return !(t < tb);
+}
+
 template <typename T, typename P>
 __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, T tb, T kq[13], T dy[13],
                                                bool have_f0 = false) {
-    using m = typename P::math;
-    // scipy has no cap; the nominal plant needs 1-4 attempts per env step.  A robust redraw step (a new gust at every
-    // RHS evaluation) legitimately takes hundreds of rejected sub-steps, so its cap is far higher; either way every
-    // lane leaves the loop after a bounded number of attempts.
-    constexpr int MAX_ATTEMPTS = P::robust ? 16384 : 96;
     T k1[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) dy[i] = T(0);
@@ -524,63 +589,11 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, 
     } else {
         rhs(y, u, pl, k1);
     }
-    T h_abs;
-    {
-        T d0 = T(0), d1 = T(0);
-        T isc[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            isc[i] = m::rcp_ctl(T(1e-6) + m::abs(y[i]) * T(1e-3));
-            const T a = y[i] * isc[i], b = k1[i] * isc[i];
-            d0 += a * a;
-            d1 += b * b;
-        }
-        d0 = m::sqrt_ctl(d0 * T(1.0 / 13)); d1 = m::sqrt_ctl(d1 * T(1.0 / 13));
-        T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : m::div_ctl(T(0.01) * d0, d1);
-        h0 = m::min(h0, tb);
-        T y1[13], f1[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) y1[i] = y[i] + h0 * k1[i];
-        rhs(y1, u, pl, f1);
-        T d2 = T(0);
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            const T a = (f1[i] - k1[i]) * isc[i];
-            d2 += a * a;
-        }
-        d2 = m::div_ctl(m::sqrt_ctl(d2 * T(1.0 / 13)), h0);
-        T h1;
-        if (d1 <= T(1e-15) && d2 <= T(1e-15)) h1 = m::max(T(1e-6), h0 * T(1e-3));
-        else h1 = m::pow_ctl(m::div_ctl(T(0.01), m::max(d1, d2)), T(0.2));
-        h_abs = m::min(m::min(T(100) * h0, h1), tb);
-    }
+    T h_abs = rk45_initial_step(y, k1, u, pl, tb);
     T t = T(0);
     bool rejected = false;
-    for (int it = 0; it < MAX_ATTEMPTS && t < tb; ++it) {
-        const T min_step = T(10) * m::ulp_up(t);
-        if (!rejected && h_abs < min_step) h_abs = min_step;
-        if (h_abs < min_step) break;  // TOO_SMALL_STEP: solver fails, last accepted y stays
-        T t_new = t + h_abs;
-        if (t_new > tb) t_new = tb;
-        const T h = t_new - t;
-        h_abs = h;
-        T yn[13], k7[13], inc[13];
-        const T err2 = dp5_step<T, true>(y, k1, u, pl, h, yn, k7, inc);
-        const T err = m::sqrt_ctl(err2 * T(1.0 / 13));
-        // lean: decided on the (guard-banded) sum itself, sqrt_ctl is a hardware approximation there
-        if (m::lean ? (err2 < T(13)) : (err < T(1))) {
-            T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow_ctl(err, T(-0.2)));
-            if (rejected) factor = m::min(T(1), factor);
-            h_abs *= factor;
-            t = t_new;
-            rejected = false;
-#pragma unroll
-            for (int i = 0; i < 13; ++i) { y[i] = yn[i]; k1[i] = k7[i]; dy[i] += inc[i]; }
-        } else {
-            h_abs *= m::max(T(0.2), T(0.9) * m::pow_ctl(err, T(-0.2)));
-            rejected = true;
-        }
-    }
+    for (int it = 0; it < Rk45Cap<P>::value && t < tb; ++it)
+        if (rk45_attempt(y, k1, dy, u, pl, tb, t, h_abs, rejected)) break;
 #pragma unroll
     for (int i = 0; i < 13; ++i) kq[i] = k1[i];
 }

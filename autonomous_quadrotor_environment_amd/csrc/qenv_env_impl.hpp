@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         prepare_action(a.const_action, cfg, pl, w, effort, cl, act, u);
     }
     bool ang_ok = a.ang_ok != 0;
-    for (int s = 0; s < a.n_steps; ++s) {
+    T q_old[4];
+    // start of env step s: the controller's action from the state in registers
+    auto begin_step = [&](int s) {
         if (CTRL == QENV_CTRL_LQR) {
             lqr_law<T, M>(y, bk, a.lqr, raw);
             prepare_action(raw, cfg, pl, w, effort, cl, act, u);
@@ -310,20 +312,18 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             if (a.target_table) {
                 T tg[7];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) tg[k] = (T)a.target_table[s * 7 + k];  // wave-uniform address: scalar loads
+                for (int k = 0; k < 7; ++k) tg[k] = (T)a.target_table[s * 7 + k];
                 pidpos_law<T, M>(y, bk, ps, tg, cfg.t_step, raw);
             } else {
                 pidpos_law<T, M>(y, bk, ps, a.pid_target, cfg.t_step, raw);
             }
             prepare_action(raw, cfg, pl, w, effort, cl, act, u);
         }
-        const T q_old[4] = {y[6], y[7], y[8], y[9]};
-        // constant actuation: f(y_end) of the previous step IS f0 of this one (not in a robust plant: the wind changes
-        // from step to step).  Mixed handle: the step starts from the fp64 row re-rounded to fp32, which is within one
-        // fp32 ulp of the y_end that f was evaluated at -- the same size as every other rounding of its fp32
-        // arithmetic; the fused rollout of a mixed handle is therefore close to, not bit-equal with, its per-step path
-        if constexpr (ROBUST) begin_step_wind(pl, bk.i + 1);
-        integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !ROBUST && s > 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q_old[k] = y[6 + k];
+    };
+    // end of env step s: y = state at t_step, kq = f(t_end, y_end), dy = the integrator's increments
+    auto end_step = [&](int s) {
         if (MIXED) {
 #pragma unroll
             for (int k = 0; k < 13; ++k) { ys[k] += (S)dy[k]; y[k] = (T)ys[k]; }
@@ -343,6 +343,53 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
             }
+        }
+    };
+    if constexpr (INTEG == INT_RK45 && !ROBUST && sizeof(T) == 4) {
+        // Lane-asynchronous stepping (fp32 arithmetic only, see the end of this comment).  scipy's RK45 is restarted every env step and ~2 % of the (env, step) pairs of a
+        // closed loop need a second sub-step (a velocity or body-rate component crossing zero shrinks its error scale to
+        // atol, select_initial_step then starts small): with the wave advancing env step by env step, 64 lanes made
+        // nearly every wave-step pay two attempts (oracle census, config 3: 1.02 attempts per env-step, 1.92 per
+        // wave-step).  Here every iteration of ONE loop is one attempted sub-step of whatever env step the lane is in;
+        // a lane that finishes its step runs the step epilogue / next prologue on its own and the lanes drift apart by
+        // the attempts they needed.  Each lane executes exactly the instruction sequence of integrate_rk45, so results
+        // are bit-identical to the per-step kernel; the wave is done after max_lane(sum of attempts) iterations.
+        // Measured (config 3, 262 144 envs): fp32 9.3 -> 10.1 G env-steps/s (config 2: 21.4 -> 24.6), but lean fp64
+        // 6.0 -> 4.5: a few per cent of the envs need ~1.5 attempts per step PERSISTENTLY (oracle census: p99 of the
+        // per-env mean 1.45), so the slowest lane's total is 1.3-1.55 attempts per step while every iteration now also
+        // pays the divergent prologue / epilogue blocks -- no better than advancing in lockstep, and in fp64 worse
+        // (register traffic of the larger loop-carried state).  fp64 arithmetic keeps the step-synchronous loop.
+        int s = 0, it = 0;
+        bool in_step = false, rejected = false;
+        T t = T(0), h_abs = T(0);
+        while (s < a.n_steps) {
+            if (!in_step) {
+                begin_step(s);
+                // constant actuation: f(y_end) of the previous step IS f0 of this one.  Mixed handle: the step starts
+                // from the fp64 row re-rounded to fp32, within one fp32 ulp of the y_end that f was evaluated at -- the
+                // size of every other rounding of its fp32 arithmetic; the fused rollout of a mixed handle is therefore
+                // close to, not bit-equal with, its per-step path
+                if (!(CTRL == QENV_CTRL_CONST && s > 0)) rhs(y, u, pl, kq);
+#pragma unroll
+                for (int k = 0; k < 13; ++k) dy[k] = T(0);
+                h_abs = rk45_initial_step(y, kq, u, pl, cfg.t_step);
+                t = T(0); rejected = false; it = 0; in_step = true;
+            }
+            const bool over = rk45_attempt(y, kq, dy, u, pl, cfg.t_step, t, h_abs, rejected);
+            ++it;
+            if (over || it >= Rk45Cap<Plant<T, ROBUST, LEAN>>::value) {
+                end_step(s);
+                ++s;
+                in_step = false;
+            }
+        }
+    } else {
+        for (int s = 0; s < a.n_steps; ++s) {
+            begin_step(s);
+            // (a robust plant has no FSAL across steps: the wind changes from step to step)
+            if constexpr (ROBUST) begin_step_wind(pl, bk.i + 1);
+            integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !ROBUST && s > 0);
+            end_step(s);
         }
     }
 #pragma unroll

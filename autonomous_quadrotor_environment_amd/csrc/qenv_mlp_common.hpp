@@ -6,6 +6,20 @@
 namespace qenv {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// x = hi + mid + lo with hi, mid, lo in bf16 (round to nearest each time): 24 significant bits, i.e. the fp32 value
+// exactly unless its exponent range underflows bf16's (it has fp32's)
+__device__ __forceinline__ void split3x8(const float x[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2;
+    }
+}
 
 // C/D layout of v_mfma_f32_32x32x2_f32: register j of lane-half `half` holds row (j&3) + 8 (j>>2) + 4 half
 __device__ __forceinline__ int acc_row(int j, int half) { return (j & 3) + 8 * (j >> 2) + 4 * half; }

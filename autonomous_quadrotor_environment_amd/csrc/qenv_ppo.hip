@@ -89,16 +89,27 @@ __device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const 
 // K1 = 15*T window elements; TW > 0: compile-time window length (the whole observation of a tile
 // is prefetched into registers with back-to-back global loads before the first MFMA, and every
 // loop is unrolled so hipcc hoists the LDS operand reads ahead of the MFMAs); TW == 0: run-time T.
-template <int H, int TW, int BLOCK, bool W2_LDS, bool SAMPLE = false>
+// BF16L2: layer 2 (the H x H one: 54 % of the fp32 MFMA time at H = 128) on the bf16 matrix cores with every fp32
+// operand split into three bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits) and the six products that matter
+// (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid: everything down to 2^-24 of the product) accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32 cycles per 16 k instead of 8 fp32 MFMAs of 64 cycles (tools/ubench), and --
+// unlike the fp32 MFMA, which executes on the vector FMA lanes -- they leave the VALU free for the tanh and the splits.
+// The accumulator tile is still the next operand without an LDS round trip: one 32x32x16 step contracts the 16 hidden
+// rows that registers 8 jh .. 8 jh + 7 of the two lane halves hold (MFMA k index 8 half + i  <->  row acc_row(8 jh + i, half)),
+// and the weights are staged in exactly that order, already split, as three 16-byte fragments per lane and step
+// (NT^2 * 2 * 3 KiB = 96 KiB at H = 128: with fp32 W1 and W3 152 of the 160 KiB).
+template <int H, int TW, int BLOCK, bool W2_LDS, bool SAMPLE = false, bool BF16L2 = false>
 __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     constexpr int HP = H < 32 ? 32 : H;  // hidden rows padded to the 32-row MFMA tile
     constexpr int NT = HP / 32;
+    static_assert(!BF16L2 || (W2_LDS && H % 32 == 0), "the split layer 2 keeps its weights in LDS");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K1 = TW ? 15 * TW : 15 * a.T;
     const int K1P = (K1 + 1) & ~1;
     float* W1t = lds;                                   // [K1P][HP]
-    float* W2t = W1t + (size_t)K1P * HP;                // [HP][HP]   (k-major), only if W2_LDS
-    float* W3t = W2t + (W2_LDS ? (size_t)HP * HP : 0);  // [HP][32]   (k-major; output rows >= n_out are zero)
+    float* W2t = W1t + (size_t)K1P * HP;                // [HP][HP]   (k-major), only if W2_LDS; BF16L2: split fragments
+    constexpr size_t W2_WORDS = BF16L2 ? (size_t)NT * NT * 2 * 3 * 64 * 4 : (W2_LDS ? (size_t)HP * HP : 0);
+    float* W3t = W2t + W2_WORDS;                        // [HP][32]   (k-major; output rows >= n_out are zero)
     float* b1s = W3t + 32 * HP;
     float* b2s = b1s + HP;
     float* b3s = b2s + HP;  // [32], zero beyond n_out
@@ -115,7 +126,21 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
             const int h = (blk / kb1) * HL + hl, k = (blk % kb1) * KL + kl;
             if (k < K1P) W1t[k * HP + h] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
         }
-        if (W2_LDS)
+        if constexpr (BF16L2) {
+            // fragment (t, ti, jh, split) = 64 lanes x 16 B: lane (col, half) holds W2[32 t + col][32 ti + acc_row(8 jh + i, half)],
+            // i = 0..7 -- two runs of four consecutive floats of one weight row
+            uint4* frag = reinterpret_cast<uint4*>(W2t);
+            for (int c = threadIdx.x; c < NT * NT * 2 * 64; c += BLOCK) {
+                const int ln = c & 63, jh = (c >> 6) & 1, ti = (c >> 7) % NT, t = (c >> 7) / NT;
+                const float* src = a.W2 + (size_t)(32 * t + (ln & 31)) * H + 32 * ti + 16 * jh + 4 * (ln >> 5);
+                const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
+                const float w8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                bf16x8 sp[3];
+                split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) frag[(((t * NT + ti) * 2 + jh) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+            }
+        } else if (W2_LDS)
             for (int blk = wv; blk < (HP / HL) * (HP / KL); blk += NW) {
                 const int h = (blk / (HP / KL)) * HL + hl, k = (blk % (HP / KL)) * KL + kl;
                 W2t[k * HP + h] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
@@ -227,11 +252,43 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
         f32x16 acc3;
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc3[j] = b3s[acc_row(j, half)];
+        // BF16L2: the layer-1 activations of this lane, split once per tile (they are the B operand of every output tile)
+        bf16x8 bsp[BF16L2 ? NT : 1][2][3];
+        if constexpr (BF16L2) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    float v8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v8[i] = acc1[ti][8 * jh + i];
+                    split3x8(v8, bsp[ti][jh][0], bsp[ti][jh][1], bsp[ti][jh][2]);
+                }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x16 acc2;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+            if constexpr (BF16L2) {
+                const uint4* frag = reinterpret_cast<const uint4*>(W2t) + (size_t)t * NT * 2 * 3 * 64 + lane;
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh) {
+                        const uint4* f = frag + (ti * 2 + jh) * 3 * 64;
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                                     al = __builtin_bit_cast(bf16x8, f[128]);
+                        const bf16x8 bh = bsp[ti][jh][0], bm = bsp[ti][jh][1], bl = bsp[ti][jh][2];
+                        // smallest products first
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
+                    }
+            } else {
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -242,6 +299,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, acc1[ti][j], acc2, 0, 0, 0);
                     if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh(acc2[j]);
             __builtin_amdgcn_sched_barrier(0);
@@ -277,7 +335,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
 // every wave reads tile ti's register j as ITS lane's B operand: conflict-free, and the k-pairs and their order are
 // those of k_mlp).  Layer 3 stays one 16 NT-MFMA chain on wave 0 so the accumulation order is k_mlp's too: the
 // results are bit-identical to k_mlp's.  Dependent MFMAs per tile: 38 + 16 NT + 16 NT instead of NT (38 + 16 NT + 16).
-template <int H, int TW, bool SAMPLE = false>
+template <int H, int TW, bool SAMPLE = false, bool BF16L2 = false>
 __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpArgs a) {
     constexpr int HP = H < 32 ? 32 : H;
     constexpr int NT = HP / 32;
@@ -313,6 +371,20 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
             const float v = w3[k < H ? k : 0];
             a3[i] = (o_ok && k < H) ? v : 0.f;
         }
+    }
+    // BF16L2 (see k_mlp): the same three-way split operands and the same order of the six products per 16-k step, so
+    // the outputs stay bit-identical to k_mlp's
+    bf16x8 asp[BF16L2 ? NT : 1][2][3];
+    if constexpr (BF16L2) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                float w8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w8[i] = a2[16 * ti + 8 * jh + i];
+                split3x8(w8, asp[ti][jh][0], asp[ti][jh][1], asp[ti][jh][2]);
+            }
     }
     float bias1[16], bias2[16], bias3[16];
 #pragma unroll
@@ -361,8 +433,28 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         // layer 2, output tile t, over all NT input tiles
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = bias2[j];
+        if constexpr (BF16L2) {
 #pragma unroll
-        for (int i = 0; i < NT * 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], x1[i * 64 + lane], acc, 0, 0, 0);
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    float v8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v8[i] = x1[(16 * ti + 8 * jh + i) * 64 + lane];
+                    bf16x8 bh, bm, bl;
+                    split3x8(v8, bh, bm, bl);
+                    const bf16x8 ah = asp[ti][jh][0], am = asp[ti][jh][1], al = asp[ti][jh][2];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT * 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], x1[i * 64 + lane], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) x2[(16 * t + j) * 64 + lane] = fast_tanh(acc[j]);
         __syncthreads();  // also: every wave is done with x1 before the next tile overwrites it
@@ -396,10 +488,22 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
 #define QENV_MLP_SMALL_TILES 512
 #endif
 
+static inline int mlp_bf16_layer2() {  // QENV_MLP_BF16=0 keeps layer 2 of the N = 128 policy on the fp32 MFMA
+    static const int on = getenv("QENV_MLP_BF16") ? atoi(getenv("QENV_MLP_BF16")) : 1;
+    return on;
+}
+
 template <int H, int TW, bool SAMPLE = false> static int launch_mlp_small(const MlpArgs& a, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
     const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
-    hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE>), dim3((unsigned)(n_tiles < 4096 ? n_tiles : 4096)), dim3(HP * 2), 0, stream, a);
+    const dim3 g((unsigned)(n_tiles < 4096 ? n_tiles : 4096)), b(HP * 2);
+    if constexpr (H == 128 && TW == 5) {
+        if (mlp_bf16_layer2()) {
+            hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE, true>), g, b, 0, stream, a);
+            return check_launch("k_mlp_small(bf16 layer 2)");
+        }
+    }
+    hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE>), g, b, 0, stream, a);
     return check_launch("k_mlp_small");
 }
 
@@ -411,16 +515,30 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
         if (((a.N + 31) / 32) * a.n_chunks <= small_tiles) return launch_mlp_small<H, TW, SAMPLE>(a, stream);
     }
     const int K1P = (15 * T + 1) & ~1;
-    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 32 * HP + 2 * HP + 32);
-    if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
     if (TW && (int64_t)15 * TW * a.N >= ((int64_t)1 << 31))
         return fail(QENV_ERR_ARG, "qenv_mlp_forward: 15*T*n_envs must stay below 2^31 (32-bit ring offsets)");
     const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
     const int wpb = BLOCK / 64;
     int64_t blocks = (n_tiles + wpb - 1) / wpb;
     if (blocks > 256) blocks = 256;  // one resident workgroup per CU; waves grid-stride over env tiles
+    if constexpr (H == 128 && TW == 5 && W2_LDS) {
+        // layer 2 on the bf16 matrix cores with three-way split operands (see k_mlp): the default for the reference's
+        // N = 128 policy at batch sizes beyond k_mlp_small's; QENV_MLP_BF16=0 keeps the all-fp32-MFMA kernel
+        if (mlp_bf16_layer2()) {
+            constexpr int NT = HP / 32;
+            const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)NT * NT * 2 * 3 * 64 * 4 + 32 * HP + 2 * HP + 32);
+            if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS");
+            hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp bf16)");
+            hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, true>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+            return check_launch("k_mlp(bf16 layer 2)");
+        }
+    }
+    const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 32 * HP + 2 * HP + 32);
+    if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
     hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
     return check_launch("k_mlp");
 }

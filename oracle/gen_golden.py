@@ -885,8 +885,34 @@ def g11():
          cols=np.array("marker[3] pos[3] vel[3] control[3] last_shaping(nan=None) step ang[3] v_ang[3] | reward shaping done n_solved; total_steps=500"))
 
 
+def g22():
+    """a24: the dense tail of visual_landing/rl_nn_model.py's OWN ActorCritic (:58-66 actor, :68-75 critic), through
+    the class's own forward: a seeded instance, 48 random 3x160x160 images, the 800 features its conv front-end
+    produces (the front-end itself is out of scope) and what the full actor / critic return for them."""
+    with quiet:
+        from visual_landing.rl_nn_model import ActorCritic as LandingAC
+        torch.manual_seed(22)
+        m = LandingAC(0, 3, 0.1, child=True)
+    img = torch.rand(48, 3, 160, 160)
+    with torch.no_grad():
+        fa, fc = m.conv1(img), m.conv2(img)            # [48, 800] each: tanh + max-pool outputs in (-1, 1)
+        out_a, out_c = m.actor(img), m.critic(img)     # the class's own fp32 forward
+        m64 = m.double()
+        ref_a = torch.nn.Sequential(*list(m64.actor)[1:])(fa.double())
+        ref_c = torch.nn.Sequential(*list(m64.critic)[1:])(fc.double())
+    assert fa.shape == (48, 800) and out_a.shape == (48, 3) and out_c.shape == (48, 1)
+    w = {}
+    for head, seq in (("actor", m.actor), ("critic", m.critic)):
+        lin = [l for l in list(seq)[1:] if isinstance(l, torch.nn.Linear)]
+        for k, l in enumerate(lin):
+            w[f"{head}_W{k + 1}"] = l.weight.detach().numpy().astype(np.float64)
+            w[f"{head}_b{k + 1}"] = l.bias.detach().numpy().astype(np.float64)
+    save("g22_landing_dense_tail", feat_actor=fa.numpy(), feat_critic=fc.numpy(), out_actor32=out_a.numpy(),
+         out_critic32=out_c.numpy(), out_actor64=ref_a.numpy(), out_critic64=ref_c.numpy(), **w)
+
+
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     for name in todo:
         globals()[name]()

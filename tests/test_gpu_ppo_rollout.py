@@ -222,6 +222,20 @@ def test_dense_tail_rl_nn_model_shape(aq, oracle):
         assert np.max(np.abs(got - ref)) < 5e-6, (K, H, n_out, np.max(np.abs(got - ref)))
 
 
+def test_dense_tail_landing_model_fixture(aq):
+    """a24 pinned by its own class: k_dense_tail on the 800 features that visual_landing/rl_nn_model.py's ActorCritic
+    conv front-end produced, against what the class's own actor / critic forward returned (g22; fp64 twin of the same
+    weights and the class's fp32 result)."""
+    g = golden("g22_landing_dense_tail")
+    for head, ft in (("actor", True), ("critic", False)):
+        w = [torch.from_numpy(g[f"{head}_{n}{k}"]).float().cuda() for k in (1, 2, 3) for n in ("W", "b")]
+        x = torch.from_numpy(np.ascontiguousarray(g[f"feat_{head}"].T)).cuda()   # [800, 48] feature-major
+        got = _np(aq.dense_tail(x, w, final_tanh=ft)).T
+        assert got.shape == g[f"out_{head}64"].shape
+        assert np.max(np.abs(got - g[f"out_{head}64"])) < 2e-6, head
+        assert np.max(np.abs(got - g[f"out_{head}32"])) < 3e-6, head
+
+
 def _torch_nets(w, dtype=torch.float64):
     import torch.nn as nn
     def net(ws, final_tanh):

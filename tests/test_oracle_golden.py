@@ -246,6 +246,17 @@ def test_g11_visual_reward(oracle):
     assert {5.0, 1.0, 0.0, -1.0, -5.0, -2.0, "run"} <= seen, seen
 
 
+def test_g22_landing_dense_tail(oracle):
+    """a24: the oracle MLP on the fixture produced by visual_landing/rl_nn_model.py's own ActorCritic (features out of
+    its conv front-end, outputs of its full actor / critic forward)."""
+    g = golden("g22_landing_dense_tail")
+    for head, ft in (("actor", True), ("critic", False)):
+        w = [g[f"{head}_{n}{k}"] for k in (1, 2, 3) for n in ("W", "b")]
+        out = oracle.mlp_forward(g[f"feat_{head}"].astype(np.float64), *w, ft)
+        assert np.max(np.abs(out - g[f"out_{head}64"])) < 1e-13
+        assert np.max(np.abs(out - g[f"out_{head}32"])) < 2e-6  # the class's own fp32 forward
+
+
 def test_g12_lqr_gains(oracle):
     g = golden("g12_lqr_gains")
     kt, katt = oracle.lqr_gains(True)
