@@ -98,19 +98,27 @@ __device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const 
 // rows that registers 8 jh .. 8 jh + 7 of the two lane halves hold (MFMA k index 8 half + i  <->  row acc_row(8 jh + i, half)),
 // and the weights are staged in exactly that order, already split, as three 16-byte fragments per lane and step
 // (NT^2 * 2 * 3 KiB = 96 KiB at H = 128: with fp32 W1 and W3 152 of the 160 KiB).
-template <int H, int TW, int BLOCK, bool W2_LDS, bool SAMPLE = false, bool BF16L2 = false>
+// BF16 = 2 does the same for layer 1 (the 75-float window padded to 5 steps of 16: lane (col, half) loads the eight
+// window elements 16 s + 8 half + i of its env; 4 * 5 * 3 KiB = 60 KiB of fragments) and keeps only the four real
+// output rows of W3 in LDS ([H][4] instead of the zero-padded [H][32]): 157 of the 160 KiB.  Layer 3 stays fp32.
+template <int H, int TW, int BLOCK, bool W2_LDS, bool SAMPLE = false, int BF16 = 0>
 __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
+    constexpr bool BF16L2 = BF16 >= 1, BF16L1 = BF16 >= 2;
     constexpr int HP = H < 32 ? 32 : H;  // hidden rows padded to the 32-row MFMA tile
     constexpr int NT = HP / 32;
     static_assert(!BF16L2 || (W2_LDS && H % 32 == 0), "the split layer 2 keeps its weights in LDS");
+    static_assert(!BF16L1 || TW > 0, "the split layer 1 is built for the compile-time window");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K1 = TW ? 15 * TW : 15 * a.T;
     const int K1P = (K1 + 1) & ~1;
-    float* W1t = lds;                                   // [K1P][HP]
-    float* W2t = W1t + (size_t)K1P * HP;                // [HP][HP]   (k-major), only if W2_LDS; BF16L2: split fragments
+    constexpr int KS16 = (15 * (TW ? TW : 1) + 15) / 16;  // 16-wide k-steps of the split layer 1
+    float* W1t = lds;                                   // [K1P][HP]; BF16L1: split fragments
+    const size_t W1_WORDS = BF16L1 ? (size_t)NT * KS16 * 3 * 64 * 4 : (size_t)K1P * HP;
+    float* W2t = W1t + W1_WORDS;                        // [HP][HP]   (k-major), only if W2_LDS; BF16L2: split fragments
     constexpr size_t W2_WORDS = BF16L2 ? (size_t)NT * NT * 2 * 3 * 64 * 4 : (W2_LDS ? (size_t)HP * HP : 0);
-    float* W3t = W2t + W2_WORDS;                        // [HP][32]   (k-major; output rows >= n_out are zero)
-    float* b1s = W3t + 32 * HP;
+    constexpr int W3C = BF16L1 ? 4 : 32;                // output rows of W3 kept in LDS
+    float* W3t = W2t + W2_WORDS;                        // [HP][W3C]  (k-major; output rows >= n_out are zero)
+    float* b1s = W3t + W3C * HP;
     float* b2s = b1s + HP;
     float* b3s = b2s + HP;  // [32], zero beyond n_out
     // transposing stage-in, 8 x 8 sub-blocks per wave instruction (lane = 8 hl + kl): the global reads fetch 32 B runs
@@ -122,6 +130,22 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
         const int kl = threadIdx.x % KL, hl = (threadIdx.x / KL) % HL, wv = threadIdx.x >> 6;
         constexpr int NW = BLOCK / 64;
         const int kb1 = (K1P + KL - 1) / KL;
+        if constexpr (BF16L1) {
+            // fragment (t, s, split): lane (col, half) holds W1[32 t + col][16 s + 8 half + i], i = 0..7 (0 beyond K1)
+            uint4* frag = reinterpret_cast<uint4*>(W1t);
+            for (int c = threadIdx.x; c < NT * KS16 * 64; c += BLOCK) {
+                const int ln = c & 63, sk = (c >> 6) % KS16, t = (c >> 6) / KS16;
+                const int k0 = 16 * sk + 8 * (ln >> 5);
+                const float* src = a.W1 + (size_t)(32 * t + (ln & 31)) * K1;
+                float w8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w8[i] = (k0 + i) < K1 ? src[k0 + i] : 0.f;
+                bf16x8 sp[3];
+                split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) frag[((t * KS16 + sk) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+            }
+        } else
         for (int blk = wv; blk < (HP / HL) * kb1; blk += NW) {
             const int h = (blk / kb1) * HL + hl, k = (blk % kb1) * KL + kl;
             if (k < K1P) W1t[k * HP + h] = (k < K1 && h < H) ? a.W1[(size_t)h * K1 + k] : 0.f;
@@ -146,8 +170,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                 W2t[k * HP + h] = (k < H && h < H) ? a.W2[(size_t)h * H + k] : 0.f;
             }
     }
-    for (int idx = threadIdx.x; idx < 32 * HP; idx += BLOCK) {
-        const int h = idx / 32, o = idx % 32;
+    for (int idx = threadIdx.x; idx < W3C * HP; idx += BLOCK) {
+        const int h = idx / W3C, o = idx % W3C;
         W3t[idx] = (o < a.n_out && h < H) ? a.W3[(size_t)o * H + h] : 0.f;
     }
     for (int h = threadIdx.x; h < HP; h += BLOCK) {
@@ -177,7 +201,55 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
         // being fed at a time (a 32x32x2 f32 MFMA chain issues back to back: its 64-cycle dependent latency
         // equals its issue interval) and the live set stays ~110 VGPRs instead of spilling.
         // layer 1: k-step s covers window elements k = 2s (lanes 0-31) and 2s+1 (lanes 32-63)
-        if (TW) {
+        if constexpr (BF16L1) {
+            uint32_t N32 = (uint32_t)a.N;
+            int hsel = half;
+            asm volatile("" : "+s"(N32), "+v"(hsel));
+            const uint32_t e32 = (uint32_t)(valid ? e : a.N - 1);
+            bf16x8 xsp[KS16][3];
+#pragma unroll
+            for (int sk = 0; sk < KS16; ++sk) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    constexpr int KW = 15 * (TW ? TW : 1);
+                    const int k0 = 16 * sk + i, k1 = 16 * sk + 8 + i;  // this element for lane half 0 / 1
+                    int sl0 = a.head + (k0 < KW ? k0 : 0) / 15, sl1 = a.head + (k1 < KW ? k1 : 0) / 15;  // wave-uniform
+                    if (sl0 >= TW) sl0 -= TW;
+                    if (sl1 >= TW) sl1 -= TW;
+                    const uint32_t r0 = (uint32_t)(sl0 * 15 + (k0 < KW ? k0 : 0) % 15);
+                    const uint32_t r1 = (uint32_t)(sl1 * 15 + (k1 < KW ? k1 : 0) % 15);
+                    float x = winc[(hsel ? r1 : r0) * N32 + e32];
+                    if (k1 >= KW) x = (hsel || k0 >= KW) ? 0.f : x;
+                    v8[i] = x;
+                    if (a.obs_store && valid) {
+                        const uint32_t k = (uint32_t)(16 * sk + 8 * half + i);
+                        if (k < (uint32_t)KW) a.obs_store[k * N32 + e32] = x;
+                    }
+                }
+                split3x8(v8, xsp[sk][0], xsp[sk][1], xsp[sk][2]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+                const uint4* frag = reinterpret_cast<const uint4*>(W1t) + (size_t)t * KS16 * 3 * 64 + lane;
+#pragma unroll
+                for (int sk = 0; sk < KS16; ++sk) {
+                    const uint4* f = frag + sk * 3 * 64;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                                 al = __builtin_bit_cast(bf16x8, f[128]);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][1], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xsp[sk][0], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][2], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][0], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][1], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][0], acc1[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
+            }
+        } else if (TW) {
             constexpr int KS = (15 * (TW ? TW : 1) + 1) / 2;
             float xs[KS];
             // 32-bit element offsets from the (scalar) ring base, no per-load predicates: out-of-range envs
@@ -305,7 +377,9 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(W3t[(32 * t + acc_row(j, half)) * 32 + col], acc2[j], acc3, 0, 0, 0);
+                const float w3 = BF16L1 ? (col < 4 ? W3t[(32 * t + acc_row(j, half)) * 4 + col] : 0.f)
+                                        : W3t[(32 * t + acc_row(j, half)) * 32 + col];
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3, acc2[j], acc3, 0, 0, 0);
                 if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -335,11 +409,12 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
 // every wave reads tile ti's register j as ITS lane's B operand: conflict-free, and the k-pairs and their order are
 // those of k_mlp).  Layer 3 stays one 16 NT-MFMA chain on wave 0 so the accumulation order is k_mlp's too: the
 // results are bit-identical to k_mlp's.  Dependent MFMAs per tile: 38 + 16 NT + 16 NT instead of NT (38 + 16 NT + 16).
-template <int H, int TW, bool SAMPLE = false, bool BF16L2 = false>
+template <int H, int TW, bool SAMPLE = false, int BF16 = 0>
 __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpArgs a) {
+    constexpr bool BF16L2 = BF16 >= 1, BF16L1 = BF16 >= 2;
     constexpr int HP = H < 32 ? 32 : H;
     constexpr int NT = HP / 32;
-    constexpr int K1 = 15 * TW, KS = (K1 + 1) / 2;
+    constexpr int K1 = 15 * TW, KS = (K1 + 1) / 2, KS16 = (K1 + 15) / 16;
     __shared__ float x1[NT * 16 * 64], x2[NT * 16 * 64];
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, t = threadIdx.x >> 6;
     const int h = 32 * t + col;  // the hidden row this lane supplies as A operand
@@ -351,12 +426,27 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
     const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
     // this lane's A operands of all three layers, fetched ONCE (they do not depend on the tile) with back-to-back
     // loads: a load in front of every MFMA would put an L2 round trip on the dependent chain 38 + 32 NT times
-    float a1[KS], a2[NT * 16], a3[NT * 16];
+    float a1[BF16L1 ? 1 : KS], a2[NT * 16], a3[NT * 16];
+    bf16x8 a1sp[BF16L1 ? KS16 : 1][3];
+    if constexpr (BF16L1) {  // k_mlp's split layer 1: this lane's A operand of step sk = W1[h][16 sk + 8 half + i]
+#pragma unroll
+        for (int sk = 0; sk < KS16; ++sk) {
+            float w8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 16 * sk + 8 * half + i;
+                const float v = w1[k < K1 ? k : K1 - 1];
+                w8[i] = (h_ok && k < K1) ? v : 0.f;
+            }
+            split3x8(w8, a1sp[sk][0], a1sp[sk][1], a1sp[sk][2]);
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int k = 2 * s + half;
         const float v = w1[k < K1 ? k : K1 - 1];
         a1[s] = (h_ok && k < K1) ? v : 0.f;
+    }
     }
 #pragma unroll
     for (int i = 0; i < NT * 16; ++i) {
@@ -401,6 +491,39 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         const int64_t e = tile * 32 + col;
         const bool valid = e < a.N;
         const int64_t ec = valid ? e : a.N - 1;
+        f32x16 acc;
+        if constexpr (BF16L1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = bias1[j];
+#pragma unroll
+            for (int sk = 0; sk < KS16; ++sk) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k0 = 16 * sk + i, k1 = 16 * sk + 8 + i;
+                    int sl0 = a.head + (k0 < K1 ? k0 : 0) / 15, sl1 = a.head + (k1 < K1 ? k1 : 0) / 15;  // wave-uniform
+                    if (sl0 >= TW) sl0 -= TW;
+                    if (sl1 >= TW) sl1 -= TW;
+                    const int r0 = sl0 * 15 + (k0 < K1 ? k0 : 0) % 15, r1 = sl1 * 15 + (k1 < K1 ? k1 : 0) % 15;
+                    float x = winc[(int64_t)(half ? r1 : r0) * a.N + ec];
+                    if (k1 >= K1) x = (half || k0 >= K1) ? 0.f : x;
+                    v8[i] = x;
+                    if (a.obs_store && valid && t == 0) {
+                        const int k = 16 * sk + 8 * half + i;
+                        if (k < K1) a.obs_store[(int64_t)k * a.N + e] = x;
+                    }
+                }
+                bf16x8 xh, xm, xl;
+                split3x8(v8, xh, xm, xl);
+                const bf16x8 ah = a1sp[sk][0], am = a1sp[sk][1], al = a1sp[sk][2];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc, 0, 0, 0);
+            }
+        } else {
         float xs[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -421,12 +544,12 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
                 if (k < K1) a.obs_store[(int64_t)k * a.N + e] = xs[s];
             }
         }
-        f32x16 acc;
         // layer 1, output tile t: k-step s pairs window elements 2s (lanes 0-31) and 2s+1 (lanes 32-63)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = bias1[j];
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], xs[s], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) x1[(16 * t + j) * 64 + lane] = fast_tanh(acc[j]);
         __syncthreads();
@@ -488,8 +611,10 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
 #define QENV_MLP_SMALL_TILES 512
 #endif
 
-static inline int mlp_bf16_layer2() {  // QENV_MLP_BF16=0 keeps layer 2 of the N = 128 policy on the fp32 MFMA
-    static const int on = getenv("QENV_MLP_BF16") ? atoi(getenv("QENV_MLP_BF16")) : 1;
+// QENV_MLP_BF16: 2 (default) = layers 1 and 2 of the N = 128, T = 5 policy on the bf16 matrix cores with three-way split
+// operands, 1 = layer 2 only, 0 = every layer on the fp32 MFMA
+static inline int mlp_bf16_layer2() {
+    static const int on = getenv("QENV_MLP_BF16") ? atoi(getenv("QENV_MLP_BF16")) : 2;
     return on;
 }
 
@@ -498,8 +623,12 @@ template <int H, int TW, bool SAMPLE = false> static int launch_mlp_small(const 
     const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
     const dim3 g((unsigned)(n_tiles < 4096 ? n_tiles : 4096)), b(HP * 2);
     if constexpr (H == 128 && TW == 5) {
-        if (mlp_bf16_layer2()) {
-            hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE, true>), g, b, 0, stream, a);
+        if (mlp_bf16_layer2() >= 2) {
+            hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE, 2>), g, b, 0, stream, a);
+            return check_launch("k_mlp_small(bf16 layers 1+2)");
+        }
+        if (mlp_bf16_layer2() == 1) {
+            hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE, 1>), g, b, 0, stream, a);
             return check_launch("k_mlp_small(bf16 layer 2)");
         }
     }
@@ -524,14 +653,23 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     if constexpr (H == 128 && TW == 5 && W2_LDS) {
         // layer 2 on the bf16 matrix cores with three-way split operands (see k_mlp): the default for the reference's
         // N = 128 policy at batch sizes beyond k_mlp_small's; QENV_MLP_BF16=0 keeps the all-fp32-MFMA kernel
-        if (mlp_bf16_layer2()) {
-            constexpr int NT = HP / 32;
-            const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)NT * NT * 2 * 3 * 64 * 4 + 32 * HP + 2 * HP + 32);
+        constexpr int NT = HP / 32, KS16 = (15 * TW + 15) / 16;
+        if (mlp_bf16_layer2() >= 2) {
+            const size_t lds = sizeof(float) * ((size_t)NT * KS16 * 3 * 64 * 4 + (size_t)NT * NT * 2 * 3 * 64 * 4 + 4 * HP + 2 * HP + 32);
             if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS");
-            hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, true>,
+            hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 2>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp bf16)");
-            hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, true>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+            hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 2>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+            return check_launch("k_mlp(bf16 layers 1+2)");
+        }
+        if (mlp_bf16_layer2() == 1) {
+            const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)NT * NT * 2 * 3 * 64 * 4 + 32 * HP + 2 * HP + 32);
+            if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS");
+            hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 1>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp bf16)");
+            hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 1>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
             return check_launch("k_mlp(bf16 layer 2)");
         }
     }
