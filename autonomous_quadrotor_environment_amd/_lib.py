@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 3
+QENV_ABI_VERSION = 4
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -42,6 +42,12 @@ class QenvConfig(C.Structure):
 
 class QenvError(RuntimeError):
     pass
+
+
+class PpoStepArgs(C.Structure):  # qenv_ppo_step_args (include/qenv.h)
+    _fields_ = [("hidden", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3")] + \
+               [("std", C.c_double), ("noise", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_uint64), ("env_offset", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("out_mean", "out_action", "out_logprob", "obs_store", "out_reward", "out_done", "out_mask")]
 
 
 # every symbol include/qenv.h declares: (name, restype, argtypes)
@@ -73,6 +79,8 @@ SYMBOLS = {
     "qenv_policy_act": (_i, [_vp, _i] + [_vp] * 6 + [C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_reset_sampled": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i]),
+    "qenv_ppo_step": (_i, [_vp, _vp]),
+    "qenv_ppo_flush": (_i, [_vp]),
     "qenv_outer_velpid": (_i, [_vp, _vp, C.c_int32]),
     "qenv_outer_pospi": (_i, [_vp, _vp, C.c_double, C.c_double, C.c_double]),
     "qenv_outer_reset": (_i, [_vp, _vp]),

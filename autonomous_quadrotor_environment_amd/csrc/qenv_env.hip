@@ -54,6 +54,9 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : -1;  // -1: automatic (see launch_rollout)
     q->robust = 0;
     q->count_cur = 0; q->count_used = 0;
+    q->side = nullptr; q->ev_main = nullptr; q->ev_side = nullptr;
+    q->env_flags[0] = (uint8_t*)workspace + L.flag_off; q->env_flags[1] = q->env_flags[0] + L.flag_stride;
+    q->ar_pending = 0; q->ar_parity = 0;
     q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
@@ -64,6 +67,9 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
 
 int qenv_destroy(qenv_t q) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_destroy: null handle");
+    if (q->ev_main) (void)hipEventDestroy(q->ev_main);
+    if (q->ev_side) (void)hipEventDestroy(q->ev_side);
+    if (q->side) (void)hipStreamDestroy(q->side);
     delete q;
     return QENV_OK;
 }
@@ -165,11 +171,13 @@ int qenv_robust_gusts(qenv_t q, const void* table, int32_t E, int32_t K, uint64_
 int qenv_reset(qenv_t q, const void* init_states, const uint8_t* mask, void* out_states, void* out_actions,
                int push_window) {
     if (!q || !init_states) return fail(QENV_ERR_ARG, "qenv_reset: null argument");
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     return QENV_DISPATCH(q, do_reset, q, init_states, mask, out_states, out_actions, push_window, nullptr);
 }
 
 int qenv_reset_sampled(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset, const uint8_t* mask, int push_window) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_reset_sampled: null handle");
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     const ResetSample smp{seed, episode, env_offset, 1};
     return QENV_DISPATCH(q, do_reset, q, nullptr, mask, nullptr, nullptr, push_window, &smp);
 }
@@ -177,6 +185,7 @@ int qenv_reset_sampled(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_of
 int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, uint8_t* out_done, void* out_mask,
               int flags) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_step: null handle");
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     const int mode = flags & QENV_STEP_MODE_MASK;
     if (flags < 0 || (flags & ~(QENV_STEP_MODE_MASK | QENV_STEP_PUSH_WINDOW)) || mode > QENV_STEP_NO_AUX)
         return fail(QENV_ERR_ARG, "qenv_step: bad flags");
@@ -184,9 +193,104 @@ int qenv_step(qenv_t q, const void* actions, void* out_obs, void* out_reward, ui
     if (push && mode == QENV_STEP_DYNAMICS_ONLY)
         return fail(QENV_ERR_STATE, "qenv_step: PUSH_WINDOW needs a full step (the slice holds q_dot)");
     const int slot = push ? q->win_head : -1;
-    const int rc = QENV_DISPATCH(q, do_step, q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot);
+    const int rc = QENV_DISPATCH(q, do_step, q, actions, nullptr, out_obs, out_reward, out_done, out_mask, mode, slot, nullptr);
     if (push && rc == 0) q->win_head = (q->win_head + 1) % q->cfg.T;
     return rc;
+}
+
+}  // extern "C"
+
+// ---- overlapped PPO rollout step -------------------------------------------------------------------------------
+// warm-up rollout (T steps, window refilled) of the envs on reset list `parity`, on q->stream
+static int ar_warmup(qenv_s* q, int parity) {
+    q->compact_valid = parity ? 2 : 1;
+    q->count_used = parity;
+    q->warmup_push = 1;
+    const int keep = q->packed;
+    q->packed = 0;
+    const int rc = QENV_DISPATCH(q, do_rollout, q, QENV_CTRL_CONST, q->cfg.T, nullptr, 0, QENV_STEP_FULL, nullptr);
+    q->packed = keep;
+    q->warmup_push = 0;
+    q->compact_valid = 0;
+    return rc;
+}
+
+int qenv::ppo_flush(qenv_s* q) {
+    if (!q->ar_pending) return QENV_OK;
+    q->ar_pending = 0;
+    return ar_warmup(q, q->ar_parity);
+}
+
+extern "C" {
+
+int qenv_ppo_flush(qenv_t q) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_ppo_flush: null handle");
+    return ppo_flush(q);
+}
+
+int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
+    if (!q || !p || !p->W1 || !p->out_action) return fail(QENV_ERR_ARG, "qenv_ppo_step: null argument");
+    if (!q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_ppo_step: the policy commands the four rotors (direct_control=1)");
+    if (q->robust) return fail(QENV_ERR_STATE, "qenv_ppo_step: robust_control episodes redraw their plant at reset; use the separate calls");
+    // the side-stream schedule is opt-in: measured on config 5 (65 536 envs, random-init policy: 1.8 % of the envs finish
+    // per step) it is SLOWER than the plain sequence, 234 vs 162 us per step -- the warm-up wavefronts run 1.5x longer when
+    // they share their SIMDs with the policy forward, the gathered forward of the reset envs costs 65 us and the two
+    // streams meet twice per step; with few resets per step (episodes that run their 500 steps) the side chain is shorter
+    // than the main one and it pays (tests/tools/ab_ppo_overlap.py measures both and checks bit-identity)
+    static const int want_overlap = getenv("QENV_PPO_OVERLAP") ? atoi(getenv("QENV_PPO_OVERLAP")) : 0;
+    const bool overlap = want_overlap && (p->hidden == 64 || p->hidden == 128) && q->cfg.T == 5;
+    const int64_t N = q->N;
+    const int cur = q->ar_parity, next = cur ^ 1;
+    StepExtra ex{};
+    ex.ar_on = 1; ex.ar_seed = p->seed; ex.ar_episode = p->step; ex.ar_env_offset = p->env_offset;
+    ex.ar_idx = q->wsi + (next ? IROW_IDX2 : IROW_IDX) * N;
+    ex.ar_count = q->counters + next;
+    ex.ar_flags_next = q->env_flags[next];
+    hipStream_t M = q->stream;
+    hipError_t he = hipMemsetAsync(q->counters + next, 0, sizeof(int32_t), M);  // list `next` was walked two steps ago
+    if (he != hipSuccess) return fail_hip(he, "hipMemsetAsync(reset list length)");
+    const int slot = q->win_head;
+    const int mode = QENV_STEP_NO_AUX;
+    int rc = QENV_OK;
+    const int32_t* list = q->wsi + (cur ? IROW_IDX2 : IROW_IDX) * N;
+    const int32_t* list_n = q->counters + cur;
+    auto act = [&](const uint8_t* skip, const int32_t* li, const int32_t* ln) {
+        return policy_act_subset(q, p->hidden, p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->std, p->noise, p->seed, p->step,
+                                 p->env_offset, p->out_mean, p->out_action, p->out_logprob, p->obs_store, skip, li, ln);
+    };
+    auto step = [&](const uint8_t* skip, const int32_t* li, const int32_t* ln) {
+        ex.env_skip = skip; ex.list_idx = li; ex.list_count = ln;
+        return QENV_DISPATCH(q, do_step, q, p->out_action, nullptr, nullptr, p->out_reward, p->out_done, p->out_mask, mode, slot, &ex);
+    };
+    if (q->ar_pending && overlap) {
+        if (!q->side) {
+            if ((he = hipStreamCreateWithFlags(&q->side, hipStreamNonBlocking)) != hipSuccess) return fail_hip(he, "hipStreamCreate(side)");
+            if ((he = hipEventCreateWithFlags(&q->ev_main, hipEventDisableTiming)) != hipSuccess) return fail_hip(he, "hipEventCreate");
+            if ((he = hipEventCreateWithFlags(&q->ev_side, hipEventDisableTiming)) != hipSuccess) return fail_hip(he, "hipEventCreate");
+        }
+        // side stream: the reset envs' T warm-up steps, then their policy step (dense tiles gathered from the list)
+        (void)hipEventRecord(q->ev_main, M);
+        (void)hipStreamWaitEvent(q->side, q->ev_main, 0);
+        q->stream = q->side;
+        rc = ar_warmup(q, cur);
+        if (rc == QENV_OK) rc = act(nullptr, list, list_n);
+        if (rc == QENV_OK) rc = step(nullptr, list, list_n);
+        (void)hipEventRecord(q->ev_side, q->side);
+        q->stream = M;
+        // main stream, meanwhile: every other env
+        if (rc == QENV_OK) rc = act(q->env_flags[cur], nullptr, nullptr);
+        if (rc == QENV_OK) rc = step(q->env_flags[cur], nullptr, nullptr);
+        (void)hipStreamWaitEvent(M, q->ev_side, 0);
+    } else {
+        if (q->ar_pending) rc = ar_warmup(q, cur);
+        if (rc == QENV_OK) rc = act(nullptr, nullptr, nullptr);
+        if (rc == QENV_OK) rc = step(nullptr, nullptr, nullptr);
+    }
+    if (rc != QENV_OK) return rc;
+    q->win_head = (q->win_head + 1) % q->cfg.T;
+    q->ar_pending = 1;
+    q->ar_parity = next;
+    return QENV_OK;
 }
 
 int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_action, int pid_first_action, int flags) {
@@ -199,6 +303,7 @@ int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_acti
     if (controller != QENV_CTRL_CONST && q->cfg.direct_control)
         return fail(QENV_ERR_STATE, "qenv_rollout: LQR/PID command [F,Mx,My,Mz]; create the handle with direct_control=0");
     if (n_steps == 0) return QENV_OK;
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     return QENV_DISPATCH(q, do_rollout, q, controller, n_steps, const_action, pid_first_action, flags, nullptr);
 }
 

@@ -40,6 +40,17 @@ template <typename T, typename S = T> struct StepArgs {
     int32_t outer_rows;
     const S* outer_target; // VELPID: [rows][7] mission table (wave-uniform rows); POSPI: [3][N]
     T outer_gain[3];       // POSPI: P, D, I
+    // overlapped PPO step: envs whose byte in env_skip is set are left to the side stream (null: none) ...
+    const uint8_t* env_skip;
+    // ... and the auto-reset of the worker loop (ppo.py:232-262) happens in this kernel's epilogue: an env that ends its
+    // episode here banks its return, draws its next initial state (the streams of qenv_reset_sampled) and appends
+    // itself to the list the warm-up rollout will walk; its byte in ar_flags_next marks it for the next step
+    int32_t ar_on;
+    uint64_t ar_seed, ar_episode;
+    int64_t ar_env_offset;
+    int32_t* ar_idx;
+    int32_t* ar_count;
+    uint8_t* ar_flags_next;
 };
 
 template <typename T, typename S = T> struct RolloutArgs {
@@ -70,6 +81,34 @@ template <typename S> __device__ __forceinline__ S ld(const S* base, int row, in
 template <typename S, typename V> __device__ __forceinline__ void st(S* base, int row, int64_t N, int64_t e, V v) {
     base[(int64_t)row * N + e] = (S)v;
 }
+
+// per-env part of a masked quad.reset (quadrotor_env.py:428-445) with a device-drawn initial state: shared by k_reset and
+// the auto-reset epilogue of k_step.  S = storage type; the Euler angles of the new state use S's IEEE functions in both.
+template <typename S>
+__device__ __forceinline__ void reset_env_sampled(S* ws, int32_t* wsi, int64_t N, int64_t e, uint64_t seed, uint64_t episode,
+                                                  int64_t env_offset, bool bank) {
+    using m = Mth<S>;
+    if (bank) {  // an episode ends here: bank its return before the counters are cleared
+        st(ws, ROW_LAST_RETURN, N, e, ld(ws, ROW_EP_RETURN, N, e));
+        wsi[IROW_EPISODES * N + e] += 1;
+    }
+    float xf[13];
+    sample_init_state(seed, episode, (uint64_t)(env_offset + e), xf);
+    S x[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) { x[k] = (S)xf[k]; st(ws, ROW_STATE + k, N, e, x[k]); }
+    const S* q = x + 6;
+    st(ws, ROW_ANG + 0, N, e, m::atan2(S(2) * (q[0] * q[1] + q[2] * q[3]), S(1) - S(2) * (q[1] * q[1] + q[2] * q[2])));
+    st(ws, ROW_ANG + 1, N, e, m::asin(S(2) * (q[0] * q[2] - q[3] * q[1])));
+    st(ws, ROW_ANG + 2, N, e, m::atan2(S(2) * (q[0] * q[3] + q[1] * q[2]), S(1) - S(2) * (q[2] * q[2] + q[3] * q[3])));
+    st(ws, ROW_PREV_SHAPING, N, e, S(0));
+    st(ws, ROW_ABS_SUM, N, e, S(0));
+    st(ws, ROW_EP_RETURN, N, e, S(0));
+    st(ws, ROW_REWARD, N, e, S(0));
+    wsi[IROW_I * N + e] = 0;
+    wsi[IROW_FLAGS * N + e] = 0;
+}
+
 
 template <typename T, typename S>
 __device__ __forceinline__ void load_book(const S* ws, const int32_t* wsi, int64_t N, int64_t e, bool opt, Book<T>& bk) {
@@ -150,6 +189,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, 
         if (e >= *a.count) return;
         e = a.idx[e];
     } else if (a.mask && a.mask[e] == 0) return;
+    if (a.env_skip && a.env_skip[e]) return;
     const int64_t N = a.N;
     const Cfg<T>& cfg = a.cfg;
     constexpr bool MIXED = !std::is_same<T, S>::value;
@@ -248,6 +288,22 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, 
         wv[4 * N] = (float)(y[1] - voff[0]); wv[5 * N] = (float)(y[3] - voff[1]); wv[6 * N] = (float)(y[5] - voff[2]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
+    }
+    if (a.ar_on) {  // wave-uniform; the lanes still here are the envs this launch stepped
+        const bool fin = (bk.flags & FLAG_DONE) != 0;
+        const unsigned long long b = __ballot(fin);
+        const int lane = threadIdx.x & 63;
+        a.ar_flags_next[e] = fin ? 1 : 0;  // every env is stepped by exactly one launch of a step: all N bytes get written
+        if (b) {
+            int base = 0;
+            const int leader = __ffsll((long long)b) - 1;
+            if (lane == leader) base = atomicAdd(a.ar_count, __popcll(b));
+            base = __shfl(base, leader);
+            if (fin) {
+                a.ar_idx[base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)e;
+                reset_env_sampled<S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, true);
+            }
+        }
     }
 }
 
@@ -349,13 +405,13 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         // Lane-asynchronous stepping (fp32 arithmetic only, see the end of this comment).  scipy's RK45 is restarted every env step and ~2 % of the (env, step) pairs of a
         // closed loop need a second sub-step (a velocity or body-rate component crossing zero shrinks its error scale to
         // atol, select_initial_step then starts small): with the wave advancing env step by env step, 64 lanes made
-        // nearly every wave-step pay two attempts (oracle census, config 3: 1.02 attempts per env-step, 1.92 per
+        // nearly every wave-step pay two attempts (census of the CPU restatement, config 3: 1.02 attempts per env-step, 1.92 per
         // wave-step).  Here every iteration of ONE loop is one attempted sub-step of whatever env step the lane is in;
         // a lane that finishes its step runs the step epilogue / next prologue on its own and the lanes drift apart by
         // the attempts they needed.  Each lane executes exactly the instruction sequence of integrate_rk45, so results
         // are bit-identical to the per-step kernel; the wave is done after max_lane(sum of attempts) iterations.
         // Measured (config 3, 262 144 envs): fp32 9.3 -> 10.1 G env-steps/s (config 2: 21.4 -> 24.6), but lean fp64
-        // 6.0 -> 4.5: a few per cent of the envs need ~1.5 attempts per step PERSISTENTLY (oracle census: p99 of the
+        // 6.0 -> 4.5: a few per cent of the envs need ~1.5 attempts per step PERSISTENTLY (same census: p99 of the
         // per-env mean 1.45), so the slowest lane's total is 1.3-1.55 attempts per step while every iteration now also
         // pays the divergent prologue / epilogue blocks -- no better than advancing in lockstep, and in fp64 worse
         // (register traffic of the larger loop-carried state).  fp64 arithmetic keeps the step-synchronous loop.
@@ -555,20 +611,17 @@ __global__ __launch_bounds__(BLOCK) void k_reset(T* ws, int32_t* wsi, int64_t N,
     }
     if (!on) return;
     using m = Mth<T>;
+    if (smp.on) {
+        reset_env_sampled<T>(ws, wsi, N, e, smp.seed, smp.episode, smp.env_offset, mask != nullptr);
+        return;
+    }
     if (mask) {  // an episode ends here: bank its return before the counters are cleared
         st(ws, ROW_LAST_RETURN, N, e, ld(ws, ROW_EP_RETURN, N, e));
         wsi[IROW_EPISODES * N + e] += 1;
     }
     T x[13];
-    if (smp.on) {
-        float xf[13];
-        sample_init_state(smp.seed, smp.episode, (uint64_t)(smp.env_offset + e), xf);
 #pragma unroll
-        for (int k = 0; k < 13; ++k) x[k] = (T)xf[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 13; ++k) x[k] = init[(int64_t)k * N + e];
-    }
+    for (int k = 0; k < 13; ++k) x[k] = init[(int64_t)k * N + e];
 #pragma unroll
     for (int k = 0; k < 13; ++k) st(ws, ROW_STATE + k, N, e, x[k]);
     const T* q = x + 6;
@@ -790,9 +843,17 @@ template <typename T> static PidGains<T> make_pid(bool clipped) {
 
 static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 255) / 256)); }
 
+// extras of the overlapped PPO step (see StepArgs)
+struct StepExtra {
+    const uint8_t* env_skip;
+    const int32_t* list_idx; const int32_t* list_count;  // step only the envs of this compacted list
+    int32_t ar_on; uint64_t ar_seed, ar_episode; int64_t ar_env_offset;
+    int32_t* ar_idx; int32_t* ar_count; uint8_t* ar_flags_next;
+};
+
 template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
                                                      void* out_reward, uint8_t* out_done, void* out_mask, int flags_in,
-                                                     int win_slot) {
+                                                     int win_slot, const StepExtra* ex = nullptr) {
     const int flags = flags_in & QENV_STEP_MODE_MASK;
     StepArgs<T, S> a;
     a.cfg = make_cfg<T>(q);
@@ -809,6 +870,14 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
     a.outer_target = (const S*)q->outer.target;
     for (int k = 0; k < 3; ++k) a.outer_gain[k] = (T)q->outer.gain[k];
     a.ang_ok = q->ang_ok;
+    a.env_skip = nullptr; a.ar_on = 0; a.ar_seed = a.ar_episode = 0; a.ar_env_offset = 0;
+    a.ar_idx = nullptr; a.ar_count = nullptr; a.ar_flags_next = nullptr;
+    if (ex) {
+        a.env_skip = ex->env_skip; a.ar_on = ex->ar_on; a.ar_seed = ex->ar_seed;
+        if (ex->list_idx) { a.idx = ex->list_idx; a.count = ex->list_count; }
+        a.ar_episode = ex->ar_episode; a.ar_env_offset = ex->ar_env_offset; a.ar_idx = ex->ar_idx; a.ar_count = ex->ar_count;
+        a.ar_flags_next = ex->ar_flags_next;
+    }
     // host-side half of the prev_ang bookkeeping: a dynamics-only step moves every state without
     // touching the angle rows; an unmasked full step re-synchronises all of them
     if (flags == QENV_STEP_DYNAMICS_ONLY) q->ang_ok = 0;
@@ -890,7 +959,7 @@ template <typename T, typename S, bool LEAN = false> int do_rollout(qenv_s* q, i
     a.idx = nullptr; a.count = nullptr; a.win = nullptr; a.win_head = 0; a.win_T = q->cfg.T;
     a.half_waves = (getenv("QENV_HALF_WAVES") && atoi(getenv("QENV_HALF_WAVES")) && !q->robust) ? 1 : 0;
     if (q->compact_valid) {  // called from a masked qenv_reset: warm-up of the reset envs only
-        a.idx = q->wsi + IROW_IDX * q->N; a.count = q->counters + q->count_used;
+        a.idx = q->wsi + (q->compact_valid == 2 ? IROW_IDX2 : IROW_IDX) * q->N; a.count = q->counters + q->count_used;
         if (q->warmup_push) { a.win = q->window; a.win_head = q->win_head; }
     }
     a.cfg = make_cfg<T>(q);
@@ -976,7 +1045,8 @@ template <typename T, typename S, bool LEAN = false> int do_reset(qenv_s* q, con
 // The env kernels are compiled in four translation units (fp32, mixed, fp64, lean fp64), each instantiating the host
 // templates of its own (arithmetic, storage) pair; every other unit only sees these declarations.
 #define QENV_ENV_INSTANCES(X, T, S, LEAN)                                                                                \
-    X template int do_step<T, S, LEAN>(qenv_s*, const void*, const uint8_t*, void*, void*, uint8_t*, void*, int, int);   \
+    X template int do_step<T, S, LEAN>(qenv_s*, const void*, const uint8_t*, void*, void*, uint8_t*, void*, int, int,    \
+                                       const StepExtra*);                                                                \
     X template int do_rollout<T, S, LEAN>(qenv_s*, int, int, const double*, int, int, const void*);                      \
     X template int do_reset<T, S, LEAN>(qenv_s*, const void*, const uint8_t*, void*, void*, int, const ResetSample*);
 #ifndef QENV_ENV_UNIT_F32

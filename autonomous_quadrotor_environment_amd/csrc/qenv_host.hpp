@@ -37,10 +37,12 @@ enum {
 };
 // IDX: compacted reset list; its two ping-pong length counters live in their own 256-B tail (WsLayout::cnt_off), not in
 // a per-env row: a row has only n_envs words, and with n_envs == 1 a second word would alias the next row
-enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_GUST_K = 4, IROWS = 5 };
+// IDX2: second list of the overlapped PPO step (qenv_ppo_step), where step t + 1 appends its finished envs while the
+// side stream still walks the list of step t
+enum { IROW_I = 0, IROW_FLAGS = 1, IROW_EPISODES = 2, IROW_IDX = 3, IROW_GUST_K = 4, IROW_IDX2 = 5, IROWS = 6 };
 
 struct WsLayout {
-    size_t int_off, cnt_off, win_off, total;
+    size_t int_off, cnt_off, flag_off, flag_stride, win_off, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -51,7 +53,9 @@ static inline WsLayout ws_layout(const qenv_config& c) {
     WsLayout L;
     L.int_off = align256((size_t)ROWS_T * N * esz);
     L.cnt_off = align256(L.int_off + (size_t)IROWS * N * sizeof(int32_t));
-    L.win_off = L.cnt_off + 256;
+    L.flag_off = L.cnt_off + 256;                   // two byte-per-env flag arrays ("this env was reset in the previous
+    L.flag_stride = align256(N);                    //  step and is being warmed up on the side stream": qenv_ppo_step)
+    L.win_off = L.flag_off + 2 * L.flag_stride;
     L.total = align256(L.win_off + (size_t)15 * c.T * N * sizeof(float));
     return L;
 }
@@ -92,6 +96,13 @@ struct qenv_s {
     int32_t packed;    // 1/0: force / forbid the two-envs-per-lane packed-fp32 rollout kernels; -1: automatic
     int32_t ang_ok;    // 1: no dynamics-only step since the last unmasked full step (see euler_update)
     hipStream_t stream;
+    // overlapped PPO rollout step (qenv_ppo_step): the reset envs' warm-up runs on a side stream beside the policy step
+    // of every 32-env tile that holds no reset env
+    hipStream_t side;          // created on first use
+    hipEvent_t ev_main, ev_side;
+    uint8_t* env_flags[2];     // [parity]: 1 for the envs of reset list `parity`
+    int32_t ar_pending;        // a reset list (parity ar_parity) still waits for its warm-up
+    int32_t ar_parity;
 };
 
 namespace qenv {
@@ -110,5 +121,16 @@ static inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? (int)QENV_OK : fail_hip(e, what);
 }
+
+// qenv_env.hip: run the warm-up a qenv_ppo_step left pending (no-op otherwise)
+int ppo_flush(qenv_s* q);
+
+// qenv_ppo.hip: qenv_policy_act on a subset of the envs (the overlapped PPO step of qenv_env.hip): either every env whose
+// byte in env_skip is 0 (the others are computed with their tile but nothing of theirs is stored), or the envs of a
+// compacted list (list_idx[0 .. *list_count), gathered into dense 32-env tiles by the tile-per-workgroup kernel)
+int policy_act_subset(qenv_s* q, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                      const float* b3, double std, const void* noise, uint64_t seed, uint64_t step, int64_t env_offset,
+                      void* out_mean, void* out_action, void* out_logprob, float* obs_store, const uint8_t* env_skip,
+                      const int32_t* list_idx, const int32_t* list_count);
 
 }  // namespace qenv

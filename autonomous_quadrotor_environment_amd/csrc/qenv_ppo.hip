@@ -53,6 +53,11 @@ struct MlpArgs {
     int64_t env_offset;
     double std, log_norm;
     void *out_action, *out_logprob;  // [4][N] in the handle's dtype; logprob nullable
+    // overlapped PPO step: nothing is stored for an env whose byte in env_skip is set (its tile is computed anyway) ...
+    const uint8_t* env_skip;
+    // ... or: only the envs list_idx[0 .. *list_count) are evaluated, gathered into dense tiles (k_mlp_small only)
+    const int32_t* list_idx;
+    const int32_t* list_count;
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1);
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
         const float* __restrict__ winc = a.win + chunk * (int64_t)K1 * a.N;
         const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
         const int64_t e = tile * 32 + col;
-        const bool valid = e < a.N;
+        // an env left to the side stream (env_skip) rides along in its tile, but nothing of it is stored
+        const bool valid = e < a.N && !(a.env_skip && a.env_skip[e < a.N ? e : 0]);
         f32x16 acc1[NT];
         // Output tiles are the OUTER loop of both layers, so only one 16-register accumulator chain is
         // being fed at a time (a 32x32x2 f32 MFMA chain issues back to back: its 64-cycle dependent latency
@@ -484,11 +490,14 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         bias2[j] = r < H ? a.b2[r] : 0.f;
         bias3[j] = r3 < a.n_out ? a.b3[r3] : 0.f;
     }
+    const int64_t n_list = a.list_idx ? (int64_t)*a.list_count : 0;  // list mode: dense tiles gathered from a compacted list
     for (int64_t gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
         const int64_t chunk = a.n_chunks > 1 ? gtile / tiles_per_chunk : 0;
         const int64_t tile = gtile - chunk * tiles_per_chunk;
+        if (a.list_idx && tile * 32 >= n_list) break;  // block-uniform: no barrier is skipped by a part of the block
         const float* __restrict__ winc = a.win + chunk * (int64_t)K1 * a.N;
-        const int64_t e = tile * 32 + col;
+        const int64_t j_list = tile * 32 + col;
+        const int64_t e = a.list_idx ? (j_list < n_list ? (int64_t)a.list_idx[j_list] : a.N) : j_list;
         const bool valid = e < a.N;
         const int64_t ec = valid ? e : a.N - 1;
         f32x16 acc;
@@ -639,9 +648,10 @@ template <int H, int TW, bool SAMPLE = false> static int launch_mlp_small(const 
 template <int H, int TW, int BLOCK, bool W2_LDS, bool SAMPLE = false>
 static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
+    if (a.list_idx && !(H >= 64 && H <= 128 && TW > 0)) return fail(QENV_ERR_ARG, "policy_act_subset: list mode needs hidden 64 / 128 and T = 5");
     if constexpr (H >= 64 && H <= 128 && TW > 0) {  // >= 2 waves per tile to split over, the reference's window
         static const int small_tiles = getenv("QENV_MLP_SMALL_TILES") ? atoi(getenv("QENV_MLP_SMALL_TILES")) : QENV_MLP_SMALL_TILES;
-        if (((a.N + 31) / 32) * a.n_chunks <= small_tiles) return launch_mlp_small<H, TW, SAMPLE>(a, stream);
+        if (a.list_idx || ((a.N + 31) / 32) * a.n_chunks <= small_tiles) return launch_mlp_small<H, TW, SAMPLE>(a, stream);
     }
     const int K1P = (15 * T + 1) & ~1;
     if (TW && (int64_t)15 * TW * a.N >= ((int64_t)1 << 31))
@@ -1276,6 +1286,7 @@ extern "C" {
 
 int qenv_window_push(qenv_t q, const void* obs, const void* actions, int reset_first) {
     if (!q || !obs || !actions) return fail(QENV_ERR_ARG, "qenv_window_push: null argument");
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     if (reset_first) {
         hipError_t e = hipMemsetAsync(q->window, 0, sizeof(float) * 15 * (size_t)q->cfg.T * (size_t)q->N, q->stream);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(window)");
@@ -1295,8 +1306,9 @@ int qenv_window_push(qenv_t q, const void* obs, const void* actions, int reset_f
 int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const float* W1, const float* b1, const float* W2,
                      const float* b2, const float* W3, const float* b3, void* out, float* obs_store) {
     if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_mlp_forward: null argument");
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     if (n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_forward: n_out must be 1..4");
-    MlpArgs a;
+    MlpArgs a{};
     a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = n_out; a.final_tanh = final_tanh;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     a.out_f64 = q->cfg.dtype == QENV_F64;
@@ -1316,9 +1328,21 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
 int qenv_policy_act(qenv_t q, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                     const float* b3, double std, const void* noise, uint64_t seed, uint64_t step, int64_t env_offset,
                     void* out_mean, void* out_action, void* out_logprob, float* obs_store) {
+    if (q && q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+    return qenv::policy_act_subset(q, hidden, W1, b1, W2, b2, W3, b3, std, noise, seed, step, env_offset, out_mean, out_action,
+                                   out_logprob, obs_store, nullptr, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+// qenv_policy_act on a subset of the envs (see qenv_host.hpp): the overlapped PPO step of qenv_env.hip
+int qenv::policy_act_subset(qenv_s* q, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
+                            const float* W3, const float* b3, double std, const void* noise, uint64_t seed, uint64_t step,
+                            int64_t env_offset, void* out_mean, void* out_action, void* out_logprob, float* obs_store,
+                            const uint8_t* env_skip, const int32_t* list_idx, const int32_t* list_count) {
     if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out_action) return fail(QENV_ERR_ARG, "qenv_policy_act: null argument");
     if (!(std > 0)) return fail(QENV_ERR_ARG, "qenv_policy_act: std must be positive");
-    MlpArgs a;
+    MlpArgs a{};
     a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = 4; a.final_tanh = 1;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out_mean;
     a.out_f64 = q->cfg.dtype == QENV_F64;
@@ -1326,6 +1350,7 @@ int qenv_policy_act(qenv_t q, int hidden, const float* W1, const float* b1, cons
     a.noise = noise; a.seed = seed; a.step = step; a.env_offset = env_offset;
     a.std = std; a.log_norm = -std::log(std) - 0.9189385332046727;  // -log(std) - 0.5 log(2 pi)
     a.out_action = out_action; a.out_logprob = out_logprob;
+    a.env_skip = env_skip; a.list_idx = list_idx; a.list_count = list_count;
     const bool t5 = q->cfg.T == 5;
     switch (hidden) {
         case 16: return t5 ? launch_mlp<16, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<16, 0, 512, true, true>(a, q->cfg.T, q->stream);
@@ -1337,6 +1362,8 @@ int qenv_policy_act(qenv_t q, int hidden, const float* W1, const float* b1, cons
     }
 }
 
+extern "C" {
+
 int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, int n_out, int final_tanh, const float* x,
                            const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                            const float* b3, float* out, void* stream) {
@@ -1344,7 +1371,7 @@ int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, in
     if (n <= 0 || n_chunks < 1 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_dense_tail: bad sizes");
     if ((int64_t)k_in * n >= ((int64_t)1 << 31)) return fail(QENV_ERR_ARG, "qenv_dense_tail: K*n must stay below 2^31");
     if (k_in == 75) {  // the controller's 75-float observation (T = 5): W1 fits the LDS whole -> the k_mlp kernel,
-        MlpArgs m;     // reading each chunk as a window ring with head 0 (row r of a chunk = window element r)
+        MlpArgs m{};   // reading each chunk as a window ring with head 0 (row r of a chunk = window element r)
         m.win = x; m.N = n; m.T = 5; m.head = 0; m.n_out = n_out; m.final_tanh = final_tanh;
         m.W1 = W1; m.b1 = b1; m.W2 = W2; m.b2 = b2; m.W3 = W3; m.b3 = b3; m.out = out; m.out_f64 = 0;
         m.obs_store = nullptr; m.n_chunks = n_chunks;

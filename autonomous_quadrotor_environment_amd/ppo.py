@@ -391,6 +391,10 @@ class PolicyRollout:
                                    and weights.hidden in (16, 32, 64, 128))
         self._values_f32 = None
         self.fused_act = True  # actor forward and Gaussian sampling as one launch (qenv_policy_act); False: two launches
+        # auto-reset steps as ONE library call (qenv_ppo_step: the reset happens in the step kernel's epilogue, the warm-up
+        # of the envs that finished stays pending until the next step / finish() / env.ppo_flush(); with
+        # QENV_PPO_OVERLAP=1 that warm-up runs on a side stream beside the next policy step).  Bit-identical buffers.
+        self.overlap = True
         N, dev, dt, H = env.n_envs, env.device, env.dtype, self.horizon
         self.actions = torch.zeros(H, 4, N, device=dev, dtype=dt)
         self.logprobs = torch.zeros(H, 4, N, device=dev, dtype=dt)
@@ -424,6 +428,13 @@ class PolicyRollout:
         """One env step for all envs.  noise: injected [4, N] standard normal."""
         env, t, w = self.env, self.t, self.w
         store = None if self.obs is None else self.obs[t]
+        if (self.auto_reset and self.overlap and self.fused_act and not deterministic and not self.keep_init
+                and not env.robust_control and (w.critic is None or self.batched_critic)):
+            env.ppo_step(w, self.seed, self.global_step + 1, self.env_offset, self.actions[t], self.logprobs[t], self.mean,
+                         store, self.rewards[t], self.done, self.masks[t], noise=noise)
+            self.t += 1
+            self.global_step += 1
+            return
         if deterministic:  # mean action, as ppo_quad_eval.py:55
             act = env.mlp_forward(w, "actor", out=self.actions[t], obs_store=store)
         elif self.fused_act:  # forward + sample in one launch
@@ -468,6 +479,7 @@ class PolicyRollout:
         """GAE over the collected steps.  bootstrap=False appends V=0 like the reference
         (ppo.py:385); True evaluates the critic on the final window."""
         n = self.t
+        self.env.ppo_flush()  # the envs that finished in the last step: their warm-up before anything reads the env
         if self.batched_critic and n:
             self.critic_values(n)
         if bootstrap and self.w.critic is not None:

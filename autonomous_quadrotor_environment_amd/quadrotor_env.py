@@ -402,6 +402,34 @@ class BatchedQuad:
                                       L.ptr(out), L.ptr(logprob), L.ptr(obs_store)), "qenv_policy_act")
         return out
 
+    def ppo_step(self, weights, seed, step, env_offset, actions, logprob, mean, obs_store, reward, done, mask, noise=None):
+        """One step of the rollout worker loop with auto-reset (qenv_ppo_step): policy_act + step(NO_AUX, push_window) +
+        reset_sampled(mask=done), bit-identical buffers, with the reset envs' warm-up overlapped with the next step (it
+        stays PENDING after the call: ppo_flush(), or any other call that touches the env, completes it)."""
+        key = (id(weights), weights.actor[0].data_ptr())
+        if getattr(self, "_ppo_checked", None) != key:  # validate a weight set once, not on every step
+            self._check_head(weights.head("actor"), "actor", n_out=4)
+            self._ppo_checked = key
+        W = weights.head("actor")
+        for t, nm in ((actions, "actions"), (logprob, "logprob"), (mean, "mean")):
+            self._check_buf(t, 4, nm)
+        self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
+        for t, nm in ((reward, "reward"), (mask, "mask")):
+            self._check_buf(t, 0, nm)
+        nz = None if noise is None else self._as_rows(noise, 4, "noise")
+        a = L.PpoStepArgs(int(W[0].shape[0]), *[t.data_ptr() for t in W], float(weights.std),
+                          None if nz is None else nz.data_ptr(), int(seed), int(step), int(env_offset),
+                          None if mean is None else mean.data_ptr(), actions.data_ptr(),
+                          None if logprob is None else logprob.data_ptr(), None if obs_store is None else obs_store.data_ptr(),
+                          reward.data_ptr(), done.data_ptr(), None if mask is None else mask.data_ptr())
+        self._bind()
+        L.check(L.lib.qenv_ppo_step(self._h, C.byref(a)), "qenv_ppo_step")
+
+    def ppo_flush(self):
+        """Complete the warm-up a ppo_step left pending (no-op otherwise); call before reading the env's fields."""
+        self._bind()
+        L.check(L.lib.qenv_ppo_flush(self._h), "qenv_ppo_flush")
+
     def sample_action(self, mean, std, noise=None, seed=0, step=0, env_offset=0, out=None, logprob=None):
         """ActorCritic.act sampling (model.py:62-68): mean + std*eps and the per-dimension log-prob.
         noise: injected standard-normal [4, N] (for CPU/GPU parity runs); otherwise Philox keyed by

@@ -35,7 +35,7 @@ extern "C" {
 
 /* 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
-#define QENV_ABI_VERSION 3
+#define QENV_ABI_VERSION 4
 
 typedef struct qenv_s *qenv_t;
 
@@ -291,6 +291,34 @@ int qenv_sample_init_states(qenv_t q, uint64_t seed, uint64_t episode, int64_t e
  * mask nullable (all envs; then the T warm-up steps run as T step launches like qenv_reset). */
 int qenv_reset_sampled(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_offset, const uint8_t *mask,
                        int push_window);
+
+/* One step of the rollout worker loop (ppo.py:232-262) with auto-reset: qenv_policy_act, qenv_step(NO_AUX |
+ * PUSH_WINDOW) and the masked qenv_reset_sampled of the envs that finished -- the same kernels, the same Philox streams
+ * (policy noise keyed by `step`, new initial states by episode = `step`), bit-identical buffers -- scheduled so that the
+ * reset envs' T warm-up steps (the latency of ONE wavefront: ~60 us whatever the batch) leave the critical path: an env
+ * that finishes in step t resets in that step kernel's epilogue (its return banked, its next initial state drawn) and
+ * joins the reset list; during step t + 1 that list is warmed up on a side stream, followed by the policy step of
+ * exactly those envs (gathered into dense 32-env tiles), while the main stream steps every other env.  After the call the finished envs
+ * hold their new initial state but their warm-up is PENDING: it runs inside the next qenv_ppo_step, or as soon as any
+ * other entry point that touches the env is called, or in qenv_ppo_flush (call it before reading the handle's fields).
+ * The side-stream schedule is opt-in (QENV_PPO_OVERLAP=1, hidden 64 / 128, T = 5): it pays when few envs finish per step
+ * and loses when many do; without it the same launches run in sequence on the handle's stream.
+ * Arrays as in qenv_policy_act / qenv_step: out_mean, out_logprob, obs_store, out_mask, noise nullable. */
+typedef struct {
+    int32_t hidden;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;   /* actor, torch layout */
+    double std;
+    const void *noise;                          /* null = Philox */
+    uint64_t seed, step;
+    int64_t env_offset;
+    void *out_mean, *out_action, *out_logprob;  /* [4][N] */
+    float *obs_store;                           /* [15*T][N] */
+    void *out_reward;                           /* [N] */
+    uint8_t *out_done;                          /* [N] */
+    void *out_mask;                             /* [N]: 1 - done */
+} qenv_ppo_step_args;
+int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args *args);
+int qenv_ppo_flush(qenv_t q);
 
 /* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------
  * The reference hard-codes `self.robust_control = False` (:183) and a user flips the attribute; this is that

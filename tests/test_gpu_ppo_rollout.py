@@ -595,3 +595,20 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["config"]["global_envs"] == 2 * 8192
     assert d["config"]["all_gathered_returns"] == 2 * 8192 and d["config"]["finite"]
     assert d["value"] > 0 and d["timing"]["regions"] >= 1
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_ppo_step_fused_call_is_bit_identical(overlap):
+    """qenv_ppo_step (reset in the step kernel's epilogue; QENV_PPO_OVERLAP=1: warm-up on a side stream beside the next
+    policy step of every other env) against the separate policy_act / step / reset_sampled calls: every rollout buffer,
+    the GAE outputs, the env state after finish(), banked returns and episode counts equal bit for bit over three
+    horizons (tests/tools/ab_ppo_overlap.py; the variable is read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for n, h, handle in ((4000, 24, "f32"), (333, 24, "lean")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "ab_ppo_overlap.py"), str(n), str(h), handle],
+                           env=dict(os.environ, QENV_PPO_OVERLAP=overlap), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+        assert '"mismatches": []' in r.stdout

@@ -36,12 +36,13 @@ def test_argument_validation_without_a_device(built):
     n32 = L.lib.qenv_workspace_bytes(C.byref(cfg))
     cfg.dtype = L.F64
     n64 = L.lib.qenv_workspace_bytes(C.byref(cfg))
-    # 88 rows of T (61 + 12 robust parameters + 6 gust + 9 outer loop) + 5 int rows + the 256-byte tail of the two
-    # reset-list counters (their own slot, valid for n_envs = 1 too) + 15*T float rows, 256-byte aligned sections
-    assert n32 == 88 * 1024 * 4 + 5 * 1024 * 4 + 256 + 75 * 1024 * 4
-    assert n64 == 88 * 1024 * 8 + 5 * 1024 * 4 + 256 + 75 * 1024 * 4
+    # 88 rows of T (61 + 12 robust parameters + 6 gust + 9 outer loop) + 6 int rows + the 256-byte tail of the two
+    # reset-list counters (their own slot, valid for n_envs = 1 too) + two byte-per-tile flag arrays (256-byte aligned)
+    # + 15*T float rows, 256-byte aligned sections
+    assert n32 == 88 * 1024 * 4 + 6 * 1024 * 4 + 256 + 2 * 256 + 75 * 1024 * 4
+    assert n64 == 88 * 1024 * 8 + 6 * 1024 * 4 + 256 + 2 * 256 + 75 * 1024 * 4
     one = L.QenvConfig(1, 0.01, 1000, 5, 1, 1, 1, L.MAIN, L.RK45, L.F32, 0)
-    assert L.lib.qenv_workspace_bytes(C.byref(one)) == 512 + 256 + 256 + 512  # rows, int rows, counters, ring
+    assert L.lib.qenv_workspace_bytes(C.byref(one)) == 512 + 256 + 256 + 512 + 512  # rows, int rows, counters, flags, ring
     lean = L.QenvConfig(1024, 0.01, 1000, 5, 1, 1, 1, L.MAIN, L.RK45, L.F64, 2)
     assert L.lib.qenv_workspace_bytes(C.byref(lean)) == n64
     assert L.lib.qenv_create(C.byref(L.QenvConfig(4, 0.01, 10, 1, 1, 1, 1, L.MAIN, L.RK45, L.F32, 2)), C.c_void_p(256), 1 << 20, None,
