@@ -23,8 +23,9 @@ struct BwdArgs {
     int32_t loss_mode;           // 0: seed given; 1: clipped surrogate of the actor (ppo.py:185-196); 2: c_value * MSE of the critic
     const float *actions, *old_logprob;  // [c][4][N]
     const float *adv, *returns;          // [c][N]
-    float inv_var, log_norm, eps_clip, c_value, inv_B;
-    double* sums;                // qenv_ppo_loss's {B, sum actor, sum (V - ret)^2, entropy * B}: [1] (mode 1) or [2] (mode 2) accumulated
+    float inv_var, inv_std, log_norm, eps_clip, c_value, inv_B;
+    double* sums;                // qenv_ppo_loss's {B, sum actor, sum (V - ret)^2, entropy * B}: [1] (mode 1) or [2] (mode 2) accumulated;
+                                 // mode 1 also adds sum_s d actor_s / d std to [4] (learned action std, model.py:45-48)
 };
 
 // Stores of a tile go through raw buffer instructions: a lane beyond the chunk (e >= N in the last tile of a chunk) or a
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
     const int64_t tiles_per_chunk = (a.N + 31) / 32, n_tiles = tiles_per_chunk * a.n_chunks;
     double loss_acc = 0.0;  // this lane's share of the loss sum (fused-loss modes), folded once after the walk
+    double std_acc = 0.0;   // ... and of sum_s d actor_s / d std (actor mode)
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         asm volatile("" ::: "memory");  // keep the (tile-invariant) LDS reads inside the loop (see k_mlp)
         // chunk index and chunk bases are wave-uniform (SGPRs); everything per lane is a 32-bit element offset
@@ -185,7 +187,14 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
             const bool live = use1 || (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip);
 #pragma unroll
             for (int k = 0; k < 4; ++k) sd[k] = live ? -A * ratio * d[k] * a.inv_var * a.inv_B : 0.f;
-            if (valid && half == 0) loss_acc += -(double)(use1 ? s1 : s2);
+            if (valid && half == 0) {
+                loss_acc += -(double)(use1 ? s1 : s2);
+                // d log N(a; mean, std) / d std summed over the four action dimensions = sum_k (d_k^2 / std^2 - 1) / std
+                float dls = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dls += d[k] * d[k] * a.inv_var - 1.f;
+                if (live) std_acc += (double)(-A * ratio) * (double)(dls * a.inv_std);
+            }
         } else {  // critic: c_value * (V - ret)^2
             const float err = outv[0] - (a.returns + (size_t)c * a.N)[ec];
             sd[0] = 2.f * a.c_value * err * a.inv_B;
@@ -252,6 +261,11 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_xor(loss_acc, off);
         if (lane == 0) atomicAdd(&a.sums[a.loss_mode], loss_acc);
+        if (a.loss_mode == 1) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) std_acc += __shfl_xor(std_acc, off);
+            if (lane == 0) atomicAdd(&a.sums[4], std_acc);
+        }
     }
 }
 
@@ -466,7 +480,7 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
     a.obs = obs; a.seed = seed; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
     a.h1 = h1; a.h2 = h2; a.dz2 = dz2; a.dz1 = dz1; a.dz3 = dz3;
     a.loss_mode = 0; a.actions = a.old_logprob = a.adv = a.returns = nullptr; a.sums = nullptr;
-    a.inv_var = a.log_norm = a.eps_clip = a.c_value = a.inv_B = 0.f;
+    a.inv_var = a.inv_std = a.log_norm = a.eps_clip = a.c_value = a.inv_B = 0.f;
     return launch_bwd(a, hidden, stream);
 }
 
@@ -487,7 +501,7 @@ int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, in
     a.obs = obs; a.seed = nullptr; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
     a.h1 = h1; a.h2 = h2; a.dz2 = dz2; a.dz1 = dz1; a.dz3 = dz3;
     a.loss_mode = head == 0 ? 1 : 2; a.actions = actions; a.old_logprob = old_logprob; a.adv = adv; a.returns = returns;
-    a.inv_var = (float)(1.0 / (std * std)); a.log_norm = (float)(-std::log(std) - 0.9189385332046727);
+    a.inv_var = (float)(1.0 / (std * std)); a.inv_std = (float)(1.0 / std); a.log_norm = (float)(-std::log(std) - 0.9189385332046727);
     a.eps_clip = (float)eps_clip; a.c_value = (float)c_value; a.inv_B = 1.f / (float)batch;
     a.sums = sums;
     return launch_bwd(a, hidden, stream);

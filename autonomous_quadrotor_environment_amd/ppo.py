@@ -193,11 +193,15 @@ class PpoLearner:
     the learner -- a tensor taken from the lists before that no longer follows the updates."""
 
     def __init__(self, weights: ActorCriticWeights, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, eps_clip=0.2, c_value=0.5,
-                 c_entropy=0.006, K_epochs=10, group=None, deterministic=False):
+                 c_entropy=0.006, K_epochs=10, group=None, deterministic=False, learn_std=False):
         """group: torch.distributed group of the data-parallel learners (None = the default group if one is
         initialised, False = never reduce).  Each rank holds an equal shard of the batch; gradients are averaged
-        with one bucketed all-reduce per epoch, so every rank applies the same Adam step."""
+        with one bucketed all-reduce per epoch, so every rank applies the same Adam step.
+        learn_std: the action std is a trained parameter (model.py:45-48 with fixed_std=False; the reference's default is
+        FIXED_STD, ppo.py:301): d loss / d std = mean_s d actor_s / d std - 4 c_entropy / std joins the gradient bucket
+        as its last element, Adam updates it with the weights, `weights.std` follows after every step."""
         assert weights.critic is not None
+        self.learn_std = bool(learn_std)
         self.w, self.lr, self.betas, self.eps = weights, lr, betas, eps
         self.eps_clip, self.c_value, self.c_entropy, self.K_epochs = eps_clip, c_value, c_entropy, K_epochs
         self.step = 0
@@ -212,12 +216,17 @@ class PpoLearner:
         # parameters, gradients and both Adam moments each live in ONE flat buffer (the weight tensors become views of
         # it): one zeroing launch and one Adam launch per step instead of twelve of each, one all-reduce bucket
         params = [weights.head(h)[k] for h, k in keys]
-        self.flat_p = torch.cat([p.reshape(-1) for p in params]).contiguous()
+        extra = [torch.tensor([float(weights.std)], device=params[0].device, dtype=torch.float32)] if self.learn_std else []
+        self.flat_p = torch.cat([p.reshape(-1) for p in params] + extra).contiguous()
         off = 0
         for (h, k), p in zip(keys, params):
             weights.head(h)[k] = self.flat_p[off:off + p.numel()].view_as(p)
             off += p.numel()
-        self.bucket = GradBucket([weights.head(h)[k] for h, k in keys])  # every .grad is a slice of one flat buffer
+        if self.learn_std and not self.fused_loss:
+            raise ValueError("learn_std needs the fused-loss backward (hidden 16, 32, 64 or 128)")
+        self.std_param = self.flat_p[-1:] if self.learn_std else None
+        # every .grad is a slice of one flat buffer (the std's gradient last)
+        self.bucket = GradBucket([weights.head(h)[k] for h, k in keys] + ([self.std_param] if self.learn_std else []))
         self.flat_m, self.flat_v = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
         self._state = {}
         off = 0
@@ -291,7 +300,7 @@ class PpoLearner:
         no loss launch, no [n, r, N] <-> [r, n N] copies."""
         n, K, N = obs.shape
         w, H, stream = self.w, self.w.hidden, _stream(obs.device)
-        sums = torch.zeros(4, dtype=torch.float64, device=obs.device)
+        sums = torch.zeros(5, dtype=torch.float64, device=obs.device)  # [4]: sum_s d actor_s / d std
         std = float(w.std)
         for hid, head in enumerate(("actor", "critic")):
             W = w.head(head)
@@ -306,8 +315,10 @@ class PpoLearner:
             for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
                 self._weight_grad(N, n, rows_a, rows_b, A, Bm, gw, gb, stream)
-        self.bucket.all_reduce_mean_(self.group)
         B = float(n * N)
+        if self.learn_std:  # before the all-reduce: the std's gradient travels in the same bucket
+            self.bucket.flat[-1] = (sums[4] / B - self.c_entropy * 4.0 / std).to(torch.float32)
+        self.bucket.all_reduce_mean_(self.group)
         actor = sums[1] / B
         critic = self.c_value * sums[2] / B
         entropy = torch.full((), -self.c_entropy * 4.0 * (0.5 + 0.9189385332046727 + float(np.log(std))), dtype=torch.float64,
@@ -320,6 +331,8 @@ class PpoLearner:
         L.check(L.lib.qenv_adam_step(p.numel(), L.ptr(p), L.ptr(self.bucket.flat), L.ptr(self.flat_m), L.ptr(self.flat_v),
                                      self.lr, self.betas[0], self.betas[1], self.eps, self.step, _stream(p.device)),
                 "qenv_adam_step")
+        if self.learn_std:  # the kernels take std by value: one small device-to-host read per Adam step
+            self.w.std = float(self.std_param.item())
 
     def update(self, rollout, returns, adv, minibatch=None, generator=None):
         """K_epochs passes over the collected rollout, returning the list of loss dicts.

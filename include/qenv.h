@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-/* 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
+/* 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
+ * 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
 #define QENV_ABI_VERSION 4
 
@@ -415,8 +416,10 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
  * forward launch nor qenv_ppo_loss.  head 0 = actor (75-H-H-4, tanh; clipped surrogate from actions / old_logprob
  * [c][4][N] and adv [c][N]; adds the surrogate sum to sums[1]), head 1 = critic (75-H-H-1; c_value * MSE against
  * returns [c][N]; adds the sum of squared errors to sums[2]).  batch = number of samples the loss is averaged over
- * (n_chunks * n_envs on one learner).  sums as in qenv_ppo_loss (caller zeroes; [0] and [3] are the caller's).
- * Same arithmetic and operation order as qenv_ppo_loss + qenv_mlp_backward. */
+ * (n_chunks * n_envs on one learner).  sums: FIVE doubles, [0..3] as in qenv_ppo_loss (caller zeroes; [0] and [3] are
+ * the caller's); the actor head also adds sum_s d actor_s / d std to sums[4] -- with the entropy term's -c_entropy * 4 / std
+ * that is the gradient of the learned action std (model.py:45-48, fixed_std = False): d loss.mean() / d std =
+ * sums[4] / batch - 4 c_entropy / std.  Same arithmetic and operation order as qenv_ppo_loss + qenv_mlp_backward. */
 int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float *obs,
                           const float *actions, const float *old_logprob, const float *adv, const float *returns,
                           double std, double eps_clip, double c_value, int64_t batch, double *sums, const float *W1,

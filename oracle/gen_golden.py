@@ -816,14 +816,20 @@ def g20():
     save("g20_landing_baseline", **rec)
 
 
-def g21():
+def g23():
+    """g21 with the action std LEARNED (model.py:45-48, fixed_std = False; ppo.py:301 sets FIXED_STD = True by default,
+    flipping the module global is the reference's own switch): after PPO.update the state dict holds the trained std."""
+    g21(fixed_std=False, name="g23_ppo_update_learned_std")
+
+
+def g21(fixed_std=True, name="g21_ppo_update"):
     """PPO.update itself (environment/controller/ppo.py:143-209: get_advantages, K_epochs x {evaluate, clipped surrogate +
     0.5 MSE - 0.006 entropy, Adam}) run by the reference's own classes.  ppo.py is a script (pool, training loop, file
     writes at import), so `Memory` and `PPO` are taken out of it with ast and executed with the module globals they
     close over; the memory is filled the way worker_f.work / the main loop do (:232-262, :371-385)."""
     tree = ast.parse(open(os.path.join(REF, "environment/controller/ppo.py")).read())
     ns = {"torch": torch, "nn": torch.nn, "np": np, "ActorCritic": ActorCritic, "device": torch.device("cpu"),
-          "network_size": 16, "FIXED_STD": True, "seed": "_golden_none"}
+          "network_size": 16, "FIXED_STD": fixed_std, "seed": "_golden_none"}
     for node in tree.body:
         if isinstance(node, ast.ClassDef) and node.name in ("Memory", "PPO"):
             exec(compile(ast.Module([node], []), "ppo." + node.name, "exec"), ns)
@@ -856,7 +862,7 @@ def g21():
     w1 = {k.replace(".", "_"): v.detach().clone().numpy() for k, v in ppo.policy.state_dict().items()}
     for k in w0:
         rec["w0_" + k] = w0[k]; rec["w1_" + k] = w1[k]
-    save("g21_ppo_update", **rec)
+    save(name, **rec)
 
 
 def g11():
@@ -913,6 +919,6 @@ def g22():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
     for name in todo:
         globals()[name]()

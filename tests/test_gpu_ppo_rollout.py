@@ -407,6 +407,33 @@ def test_ppo_update_against_the_reference_update(aq):
     assert np.median(d) < 2e-6
 
 
+def test_ppo_update_with_learned_std_against_the_reference(aq):
+    """g23 = the reference's PPO.update with fixed_std = False (model.py:45-48: std is an nn.Parameter with grad, ppo.py:105
+    hands it to Adam with the weights): PpoLearner(learn_std=True) moves the action std to the reference's value (0.1 ->
+    0.095643 in ten epochs) and the weights with it."""
+    import types
+    g = golden("g23_ppo_update_learned_std")
+    assert abs(float(g["w1_std"]) - float(g["w0_std"])) > 3e-3  # the reference did train it
+    w = aq.ActorCriticWeights.from_state_dict({k[3:]: g[k] for k in g.files if k.startswith("w0_") and k != "w0_std"})
+    w.std = float(g["w0_std"])
+    B = g["obs"].shape[0]
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", torch.float32)
+    ret, adv = aq.gae(f(g["values"]).reshape(B + 1, 1), f(1.0 - g["is_terminals"]).reshape(B, 1), f(g["rewards"]).reshape(B, 1),
+                      ddof=0, group=False)
+    ro = types.SimpleNamespace(t=B, obs=f(g["obs"]).reshape(B, 75, 1), actions=f(g["actions"]).reshape(B, 4, 1),
+                               logprobs=f(g["logprobs"]).reshape(B, 4, 1))
+    learner = aq.PpoLearner(w, lr=5e-4, K_epochs=10, group=False, learn_std=True)
+    learner.update(ro, ret, adv)
+    assert abs(w.std - float(g["w1_std"])) < 2e-6, (w.std, float(g["w1_std"]))
+    names = [f"{h}_{l}_{p}" for h in ("actor", "critic") for l in (0, 2, 4) for p in ("weight", "bias")]
+    got = np.concatenate([_np(t).ravel() for h in ("actor", "critic") for t in w.head(h)])
+    ref = np.concatenate([g["w1_" + n].ravel() for n in names])
+    d = np.abs(got - ref)
+    assert np.mean(d < 1e-5) > 0.97 and np.median(d) < 2e-6 and d.max() < 2.5e-3
+    with pytest.raises(ValueError):
+        aq.PpoLearner(aq.ActorCriticWeights.random(256), learn_std=True)
+
+
 @pytest.mark.parametrize("hidden", [16, 32, 64, 128, 256])
 @pytest.mark.parametrize("T,N", [(5, 4097), (5, 63), (3, 1000), (1, 1)])
 def test_mlp_forward_every_instantiation_vs_torch_fp64(aq, hidden, T, N):
