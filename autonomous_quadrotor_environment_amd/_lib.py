@@ -99,6 +99,7 @@ SYMBOLS = {
     "qenv_gae_workspace_bytes": (C.c_size_t, [_i64]),
     "qenv_gae_deterministic": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adam_step": (_i, [_i64, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp]),
+    "qenv_adam_step_counted": (_i, [_i64, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "qenv_debug_copy_rows": (_i, [_i, _vp, _vp, _i, _i64, _vp]),
 }
 

@@ -460,6 +460,23 @@ __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, const float* 
     }
 }
 
+// The same update with the step count in device memory (hipGraph replays must see a new count each time): the counter
+// is advanced by its own one-thread launch in front of this kernel, and 1 - beta^step is evaluated here in double, as
+// torch does on the host.
+__global__ void k_count(int32_t* c) { *c += 1; }
+__global__ __launch_bounds__(256) void k_adam_counted(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1,
+                                                      float b2, float eps, double beta1, double beta2, const int32_t* step) {
+    const double st = (double)*step;
+    const float bc1 = (float)(1.0 - pow(beta1, st)), bc2 = (float)(1.0 - pow(beta2, st));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    }
+}
+
 }  // namespace qenv
 
 using namespace qenv;
@@ -590,6 +607,17 @@ int qenv_adam_step(int64_t n, float* param, const float* grad, float* m, float* 
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, param, grad, m, v, (float)lr,
                        (float)beta1, (float)beta2, (float)eps, (float)bc1, (float)bc2);
     return check_launch("k_adam");
+}
+
+int qenv_adam_step_counted(int64_t n, float* param, const float* grad, float* m, float* v, double lr, double beta1, double beta2,
+                           double eps, int32_t* step_counter, void* stream) {
+    if (!param || !grad || !m || !v || !step_counter || n <= 0) return fail(QENV_ERR_ARG, "qenv_adam_step_counted: bad argument");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_count, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+    hipLaunchKernelGGL(k_adam_counted, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, param, grad, m, v, (float)lr,
+                       (float)beta1, (float)beta2, (float)eps, beta1, beta2, (const int32_t*)step_counter);
+    return check_launch("k_adam_counted");
 }
 
 }  // extern "C"

@@ -334,8 +334,45 @@ class PpoLearner:
         if self.learn_std:  # the kernels take std by value: one small device-to-host read per Adam step
             self.w.std = float(self.std_param.item())
 
-    def update(self, rollout, returns, adv, minibatch=None, generator=None):
+    def _adam_counted(self):
+        p = self.flat_p
+        L.check(L.lib.qenv_adam_step_counted(p.numel(), L.ptr(p), L.ptr(self.bucket.flat), L.ptr(self.flat_m), L.ptr(self.flat_v),
+                                             self.lr, self.betas[0], self.betas[1], self.eps, L.ptr(self._step_dev),
+                                             _stream(p.device)), "qenv_adam_step_counted")
+
+    def _update_graph(self, obs, actions, logprobs, adv, returns):
+        """One epoch {zero, backward x2, weight gradients x6, Adam} captured once as a hipGraph and replayed K_epochs times.
+        The Adam step count lives in device memory so every replay sees the next one; the captured tensors are the
+        rollout's own buffers (a new rollout object / horizon re-captures).  Measured (tools/time_learner_small.py): the
+        replay frees the host (no Python / launch work per epoch) but is NOT faster on the device -- 296 vs 281 us per
+        epoch at 8 192 samples, 727 vs 702 at 65 536: the epoch is bound by the dependent-kernel latencies of its ~20
+        small launches (weight staging, split-K tails), which a graph replays unchanged."""
+        key = tuple(t.data_ptr() for t in (obs, actions, logprobs, adv, returns)) + tuple(obs.shape)
+        dev = obs.device
+        if getattr(self, "_graph_key", None) != key:
+            if getattr(self, "_step_dev", None) is None:
+                self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.gradients(obs, actions, logprobs, adv, returns)  # eager once: lazily allocated buffers exist afterwards
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, stream=side):
+                loss = self.gradients(obs, actions, logprobs, adv, returns)
+                self._adam_counted()
+                self._graph_loss = torch.stack([loss[k].to(torch.float64).reshape(()) for k in ("loss", "actor", "critic", "entropy")])
+            self._graph_key = key
+        self._step_dev.fill_(self.step)
+        out = []
+        for _ in range(self.K_epochs):
+            self._graph.replay()
+            v = self._graph_loss.clone()
+            out.append({"loss": v[0], "actor": v[1], "critic": v[2], "entropy": v[3]})
+        self.step += self.K_epochs
+        return out
+
+    def update(self, rollout, returns, adv, minibatch=None, generator=None, graph=False):
         """K_epochs passes over the collected rollout, returning the list of loss dicts.
+        graph=True (full-batch epochs, fixed std, one learner): the epoch is replayed from a hipGraph.
         minibatch=None: full-batch epochs (ppo.py:172-203; the reference's randperm of a full batch does not change
         loss.mean()).  minibatch=B: the schedule of visual_landing/ppo_trainer.py:187-196 -- every epoch walks a fresh
         random permutation in batches of B samples, one Adam step per batch, the remainder as a last smaller batch;
@@ -343,6 +380,13 @@ class PpoLearner:
         of a step stay together, so nothing is gathered sample by sample)."""
         n = rollout.t
         out = []
+        if graph and minibatch is None and not self.learn_std and self.fused_loss and not (
+                self.group is not False and torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size(self.group if self.group is not None else None) > 1):
+            f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else None
+            args = [f32(t) for t in (rollout.obs[:n], rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n])]
+            if all(a is not None for a in args):  # the captured pointers must be the caller's own (no conversion copies)
+                return self._update_graph(*args)
         if minibatch is None:
             for _ in range(self.K_epochs):
                 out.append(self.gradients(rollout.obs[:n], rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n]))

@@ -435,6 +435,11 @@ int qenv_weight_grad_deterministic(int64_t n_envs, int n_chunks, int m_rows, int
                                    const float *B, float *C, float *rowsum, void *workspace, void *stream);
 int qenv_adam_step(int64_t n, float *param, const float *grad, float *m, float *v, double lr, double beta1,
                    double beta2, double eps, int step, void *stream);
+/* qenv_adam_step with the step count kept in device memory: *step_counter is incremented on the device first (its own
+ * one-thread launch) and the bias corrections 1 - beta^step are evaluated there, so a hipGraph that captured this call
+ * advances the count on every replay (PpoLearner.update(graph=True)). */
+int qenv_adam_step_counted(int64_t n, float *param, const float *grad, float *m, float *v, double lr, double beta1,
+                           double beta2, double eps, int32_t *step_counter, void *stream);
 
 /* Replaces visual_reward (visual_landing/rl_reward_fuction.py:3-102), batched.
  * marker,pos,vel,control,ang,v_ang [3][N]; last_shaping [N] (0 = none, like the

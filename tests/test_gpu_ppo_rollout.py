@@ -407,6 +407,28 @@ def test_ppo_update_against_the_reference_update(aq):
     assert np.median(d) < 2e-6
 
 
+def test_ppo_update_from_a_hip_graph_equals_the_eager_update(aq):
+    """PpoLearner.update(graph=True): one epoch captured as a hipGraph (Adam's step count in device memory) and replayed
+    K_epochs times, two updates in a row -- the same weights, bit for bit, as the eager launches (deterministic sums)."""
+    import types
+    torch.manual_seed(3)
+    n, N = 16, 64
+    ro = types.SimpleNamespace(t=n, obs=torch.randn(n, 75, N, device="cuda") * 0.3, actions=torch.randn(n, 4, N, device="cuda") * 0.3,
+                               logprobs=torch.randn(n, 4, N, device="cuda") * 0.1 + 1.3)
+    adv, ret = torch.randn(n, N, device="cuda"), torch.randn(n, N, device="cuda")
+    got = {}
+    for graph in (False, True):
+        w = aq.ActorCriticWeights.random(32, seed=5)
+        learner = aq.PpoLearner(w, K_epochs=4, group=False, deterministic=True)
+        l1 = learner.update(ro, ret, adv, graph=graph)
+        l2 = learner.update(ro, ret, adv, graph=graph)
+        assert learner.step == 8 and len(l1) == 4 and len(l2) == 4
+        got[graph] = (learner.flat_p.clone(), torch.stack([x["loss"] for x in l1 + l2]).clone())
+    assert torch.equal(got[True][0], got[False][0])
+    assert torch.allclose(got[True][1], got[False][1], rtol=0, atol=1e-12)  # the reported loss sums are double atomics
+    assert float((got[True][1][0] - got[True][1][-1]).abs()) > 1e-3  # the loss did move over the eight steps
+
+
 def test_ppo_update_with_learned_std_against_the_reference(aq):
     """g23 = the reference's PPO.update with fixed_std = False (model.py:45-48: std is an nn.Parameter with grad, ppo.py:105
     hands it to Adam with the weights): PpoLearner(learn_std=True) moves the action std to the reference's value (0.1 ->

@@ -22,3 +22,16 @@ for fused in (True, False):
         ln.gradients(obs, act, lp, adv, ret)
     b.record(); torch.cuda.synchronize()
     print(json.dumps(dict(n_envs=N, steps=n, fused_loss=fused, us_per_gradients_call=round(a.elapsed_time(b) * 1000 / 50, 1))), flush=True)
+
+# a whole update (K epochs of gradients + Adam) eager vs replayed from a hipGraph
+import types, time
+ro = types.SimpleNamespace(t=n, obs=obs, actions=act, logprobs=lp)
+for graph in (False, True):
+    ln2 = aq.PpoLearner(aq.ActorCriticWeights.random(128, 75, 4, seed=1), K_epochs=10, group=False)
+    for _ in range(2):
+        ln2.update(ro, ret, adv, graph=graph)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        ln2.update(ro, ret, adv, graph=graph)
+    torch.cuda.synchronize()
+    print(json.dumps(dict(n_envs=N, steps=n, hip_graph=graph, us_per_epoch=round((time.perf_counter() - t0) / 100 * 1e6, 1))), flush=True)
