@@ -11,7 +11,7 @@ from .quadrotor_env import BatchedQuad, quad, random_init_states, euler_quat, qu
 from .controllers import LqrController, PidController, PidPosController, pid_control  # noqa: F401
 from .ppo import ActorCriticWeights, dense_tail, dl_in_gen, gae, ppo_loss, visual_reward, PolicyRollout, PpoLearner  # noqa: F401
 from .mission import mission  # noqa: F401
-from .sensor import BatchedSensor  # noqa: F401
+from .sensor import BatchedSensor, sensor  # noqa: F401
 from .position_control import MissionTracker, LandingBaseline  # noqa: F401
 from .distributed import shard_range, ShardedQuad, all_gather_returns, GradBucket  # noqa: F401
 

@@ -24,7 +24,7 @@ VARIANTS = {"main": MAIN, "opt": OPT}
 CTRL_CONST, CTRL_LQR, CTRL_PID, CTRL_PIDPOS = 0, 1, 2, 3
 STEP_FULL, STEP_DYNAMICS_ONLY, STEP_NO_AUX = 0, 1, 2
 STEP_PUSH_WINDOW = 4
-SENSOR_ROWS = 25
+SENSOR_ROWS = 31
 FLAG_DONE, FLAG_SOLVED, FLAG_HAS_SHAPING = 1, 2, 4
 
 (FIELD_STATE, FIELD_ANG, FIELD_PREV_ANG, FIELD_ANG_VEL, FIELD_VQ, FIELD_W, FIELD_STEP_EFFORT,
@@ -71,8 +71,11 @@ SYMBOLS = {
     "qenv_pidpos_action": (_i, [_vp, _dptr, _vp]),
     "qenv_window_push": (_i, [_vp, _vp, _vp, _i]),
     "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "qenv_sensor_reset": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i]),
-    "qenv_sensor_read": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _vp]),
+    "qenv_sensor_reset": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _dptr]),
+    "qenv_sensor_read": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _dptr, _vp]),
+    "qenv_sensor_ops": (_i, [_vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, _dptr, _vp]),
+    "qenv_sensor_bias_reset": (_i, [_vp, _vp, _vp, _i, _dptr]),
+    "qenv_attach_sensor": (_i, [_vp, _vp, _vp, C.c_uint64, _i64, _i, _dptr, _vp, C.c_uint64]),
     "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_dense_tail_chunks": (_i, [_i64, C.c_int32, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),

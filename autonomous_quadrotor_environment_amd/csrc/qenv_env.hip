@@ -54,6 +54,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->packed = getenv("QENV_PACKED") ? atoi(getenv("QENV_PACKED")) : -1;  // -1: automatic (see launch_rollout)
     q->robust = 0;
     q->count_cur = 0; q->count_used = 0;
+    q->sens = qenv_sensor_link{};
     q->side = nullptr; q->ev_main = nullptr; q->ev_side = nullptr;
     q->env_flags[0] = (uint8_t*)workspace + L.flag_off; q->env_flags[1] = q->env_flags[0] + L.flag_stride;
     q->ar_pending = 0; q->ar_parity = 0;
@@ -126,6 +127,17 @@ int qenv_outer_pospi(qenv_t q, const void* targets, double P, double D, double I
     q->outer.kind = targets ? QENV_OUTER_POSPI : QENV_OUTER_NONE;
     q->outer.target = targets; q->outer.rows = 0;
     q->outer.gain[0] = P; q->outer.gain[1] = D; q->outer.gain[2] = I;
+    return QENV_OK;
+}
+
+int qenv_attach_sensor(qenv_t q, void* sens, const void* z27, uint64_t seed, int64_t env_offset, int error, const double* params,
+                       void* out24, uint64_t calls) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_attach_sensor: null handle");
+    q->sens = qenv_sensor_link{};
+    if (!sens) return QENV_OK;  // detach
+    q->sens.ws = sens; q->sens.z27 = z27; q->sens.out = out24; q->sens.seed = seed; q->sens.calls = calls;
+    q->sens.env_offset = env_offset; q->sens.error = error ? 1 : 0; q->sens.has_params = params ? 1 : 0;
+    if (params) for (int k = 0; k < 8; ++k) q->sens.params[k] = params[k];
     return QENV_OK;
 }
 

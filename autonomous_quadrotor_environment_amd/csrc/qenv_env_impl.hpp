@@ -8,6 +8,7 @@
 // (4 waves); the state never leaves VGPRs inside a step (or inside a fused rollout).
 #pragma once
 #include "qenv_host.hpp"
+#include "qenv_sensor.hpp"
 #include <type_traits>
 
 namespace qenv {
@@ -40,6 +41,12 @@ template <typename T, typename S = T> struct StepArgs {
     int32_t outer_rows;
     const S* outer_target; // VELPID: [rows][7] mission table (wave-uniform rows); POSPI: [3][N]
     T outer_gain[3];       // POSPI: P, D, I
+    // sensor in the loop (position.py:240-242, REAL_CTRL = False): the window slice of a PUSH_WINDOW step comes from
+    // sensor_sp evaluated right here on the state the step ended in (null: the true state)
+    S* sens; const S* sens_z; S* sens_out;
+    SensParams<S> sens_p;
+    uint64_t sens_seed, sens_step;
+    int64_t sens_env_offset;
     // overlapped PPO step: envs whose byte in env_skip is set are left to the side stream (null: none) ...
     const uint8_t* env_skip;
     // ... and the auto-reset of the worker loop (ppo.py:232-262) happens in this kernel's epilogue: an env that ends its
@@ -285,9 +292,52 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, 
 #pragma unroll
             for (int k = 0; k < 3; ++k) { st(a.ws, ROW_OUTER + k, N, e, integ[k]); st(a.ws, ROW_OUTER + 6 + k, N, e, cmd[k]); }
         }
+        if (a.sens) {
+            // states_sens = [dead-reckoned x, vx, y, vy, z, vz; quaternion_gyro; deriv_quat(gyro, quaternion_gyro)] - error_mission
+            // (position.py:233-242); the sensor's arithmetic runs in the handle's storage type, as k_sensor_read's does
+            S zz[28];
+            if (a.sens_z) {
+#pragma unroll
+                for (int k = 0; k < 27; ++k) zz[k] = a.sens_z[(int64_t)k * N + e];
+            } else {
+                sens_philox_normals<S>(a.sens_seed, a.sens_step, (uint64_t)(a.sens_env_offset + e), zz);
+            }
+            Sens<S> sn;
+            sens_load(a.sens, N, e, a.sens_p, (S)cfg.t_step, bk.i, sn);  // (bk.i: a step has just happened, the view is dead)
+            S yS[13], accS[3], wS[4];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) yS[k] = MIXED ? ys[k] : (S)y[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) accS[k] = (S)kq[1 + 2 * k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wS[k] = (S)w[k];
+            SensEnv<S> ev;
+            sens_env<S>(yS, accS, wS, ev);
+            S o[24];
+            bool wrote_env;
+            sens_sp<S>(sn, ev, zz, o, wrote_env);
+            if (wrote_env) {  // quaternion_t0 aliased quad.state: the env's own quaternion advances (quirk of :630, :719)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    st(a.ws, ROW_STATE + 6 + k, N, e, ev.y[6 + k]);
+                    a.sens[(int64_t)(SR_QSAVE + k) * N + e] = yS[6 + k];  // mat_rot stays that of the un-advanced quaternion
+                }
+                a.sens[(int64_t)SR_ISAVE * N + e] = (S)(bk.i + 1);
+            }
+            sens_store(a.sens, N, e, sn);
+            a.sens[(int64_t)SR_ALIAS * N + e] = S(0);
+            if (a.sens_out) {
+#pragma unroll
+                for (int k = 0; k < 24; ++k) a.sens_out[(int64_t)k * N + e] = o[k];
+            }
+            wv[4 * N] = (float)((T)o[1] - voff[0]); wv[5 * N] = (float)((T)o[3] - voff[1]); wv[6 * N] = (float)((T)o[5] - voff[2]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)o[6 + k]; wv[(int64_t)(11 + k) * N] = (float)o[10 + k]; }
+        } else {
         wv[4 * N] = (float)(y[1] - voff[0]); wv[5 * N] = (float)(y[3] - voff[1]); wv[6 * N] = (float)(y[5] - voff[2]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
+        }
     }
     if (a.ar_on) {  // wave-uniform; the lanes still here are the envs this launch stepped
         const bool fin = (bk.flags & FLAG_DONE) != 0;
@@ -870,6 +920,20 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
     a.outer_target = (const S*)q->outer.target;
     for (int k = 0; k < 3; ++k) a.outer_gain[k] = (T)q->outer.gain[k];
     a.ang_ok = q->ang_ok;
+    a.sens = nullptr; a.sens_z = nullptr; a.sens_out = nullptr; a.sens_seed = a.sens_step = 0; a.sens_env_offset = 0;
+    for (int k = 0; k < 5; ++k) a.sens_p.std[k] = S(0);
+    for (int k = 0; k < 3; ++k) a.sens_p.bd[k] = S(0);
+    if (q->sens.ws && win_slot >= 0 && q->outer.kind != QENV_OUTER_POSPI && !(mask || ex)) {
+        // (reset warm-up pushes and the landing baseline's pos_pi loop see the true state, as in the reference)
+        static const double dflt[8] = {0.1, 0.035, 15, 1.71, 0.5, 0.0005, 0.00015, 0.075};
+        const double* v = q->sens.has_params ? q->sens.params : dflt;
+        const double er = q->sens.error ? 1.0 : 0.0;
+        for (int k = 0; k < 5; ++k) a.sens_p.std[k] = (S)(v[k] * er);
+        for (int k = 0; k < 3; ++k) a.sens_p.bd[k] = (S)(v[5 + k] * er);
+        a.sens = (S*)q->sens.ws; a.sens_z = (const S*)q->sens.z27; a.sens_out = (S*)q->sens.out;
+        a.sens_seed = q->sens.seed; a.sens_step = q->sens.calls; a.sens_env_offset = q->sens.env_offset;
+        q->sens.calls += 1;
+    }
     a.env_skip = nullptr; a.ar_on = 0; a.ar_seed = a.ar_episode = 0; a.ar_env_offset = 0;
     a.ar_idx = nullptr; a.ar_count = nullptr; a.ar_flags_next = nullptr;
     if (ex) {

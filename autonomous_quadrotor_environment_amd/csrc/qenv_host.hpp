@@ -78,9 +78,21 @@ struct qenv_outer {
     double gain[3];           // POSPI: P, D, I
 };
 
+// sensor fused into the PUSH_WINDOW steps (qenv_attach_sensor)
+struct qenv_sensor_link {
+    void* ws;                 // [QENV_SENSOR_ROWS][N] sensor state, null = not attached
+    const void* z27;          // null = Philox
+    void* out;                // null or [24][N]
+    uint64_t seed, calls;
+    int64_t env_offset;
+    int32_t error, has_params;
+    double params[8];
+};
+
 struct qenv_s {
     qenv_config cfg;
     qenv_outer outer;
+    qenv_sensor_link sens;
     int32_t robust;           // env.robust_control
     qenv_gust_src gust;
     int64_t N;

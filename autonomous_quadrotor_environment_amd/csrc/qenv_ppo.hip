@@ -8,6 +8,7 @@
 //   visual_landing/rl_reward_fuction.py:3-102      visual_reward
 #include "qenv_host.hpp"
 #include "qenv_mlp_common.hpp"
+#include "qenv_sensor.hpp"
 
 namespace qenv {
 
@@ -894,27 +895,24 @@ __global__ __launch_bounds__(256) void k_sample_init(int64_t N, uint64_t seed, u
 }
 
 // ---- sensor model, quadrotor_env.py:579-724 ------------------------------------------------------------
-enum { SR_ABD = 0, SR_GBD = 1, SR_MBD = 2, SR_AB = 3, SR_GB = 4, SR_POS = 5, SR_VEL = 8, SR_Q = 11, SR_R = 15, SR_ALIAS = 24 };
-
 template <typename T>
-__global__ __launch_bounds__(256) void k_sensor_reset(int64_t N, const T* ws, T* sens, const T* u3, uint64_t seed,
-                                                      uint64_t episode, int64_t env_offset, int error) {
+__global__ __launch_bounds__(256) void k_sensor_reset(int64_t N, const T* ws, const int32_t* wsi, T* sens, const T* u3, uint64_t seed,
+                                                      uint64_t episode, int64_t env_offset, SensParams<T> p) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= N) return;
-    float u[3];
+    T u[3];
     if (u3) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) u[k] = (float)u3[(int64_t)k * N + e];
+        for (int k = 0; k < 3; ++k) u[k] = u3[(int64_t)k * N + e];
     } else {
         const uint64_t g = (uint64_t)(env_offset + e);
         uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)episode, (uint32_t)(episode >> 32)};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5E45u);
-        u[0] = u01(c[0]); u[1] = u01(c[1]); u[2] = u01(c[2]);
+        u[0] = (T)u01(c[0]); u[1] = (T)u01(c[1]); u[2] = (T)u01(c[2]);
     }
-    const T er = error ? T(1) : T(0);
-    const T bd[3] = {T(0.0005), T(0.00015), T(0.075)};
+    // bias_reset :601-609 (p.bd already carries sensor.error)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) sens[(int64_t)(SR_ABD + k) * N + e] = ((T)u[k] - T(0.5)) * T(2) * bd[k] * er;
+    for (int k = 0; k < 3; ++k) sens[(int64_t)(SR_ABD + k) * N + e] = (u[k] - T(0.5)) * T(2) * p.bd[k];
     sens[(int64_t)SR_AB * N + e] = T(0);
     sens[(int64_t)SR_GB * N + e] = T(0);
 #pragma unroll
@@ -924,76 +922,43 @@ __global__ __launch_bounds__(256) void k_sensor_reset(int64_t N, const T* ws, T*
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) sens[(int64_t)(SR_Q + k) * N + e] = ws[(int64_t)(ROW_STATE + 6 + k) * N + e];
-    sens[(int64_t)SR_ALIAS * N + e] = T(1);  // quaternion_t0 is a view of quad.state until the first gyro_int
+    sens[(int64_t)SR_ALIAS * N + e] = T(1);  // quaternion_t0 is a view of quad.state's array until the first gyro_int ...
+    sens[(int64_t)SR_IRESET * N + e] = (T)(wsi[IROW_I * N + e] + 1);  // ... which is the env's state only until its next step
     // R keeps its value (the reference's reset() does not touch self.R)
 }
 
-template <typename T> struct Sens {
-    T std[5], a_b_d, g_b_d, a_b, g_b, R[9], dt;
-};
+// only bias_reset (:601-609): the N = 1 class calls it on its own at construction
+template <typename T>
+__global__ __launch_bounds__(256) void k_sensor_bias_reset(int64_t N, T* sens, const T* u3, SensParams<T> p) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sens[(int64_t)(SR_ABD + k) * N + e] = (u3[(int64_t)k * N + e] - T(0.5)) * T(2) * p.bd[k];
+}
 
 template <typename T>
-__device__ __forceinline__ void s_accel(Sens<T>& s, const T Rm[9], const T a_in[3], const T* z, T out[3]) {
-    s.a_b = s.a_b + s.a_b_d * s.dt;
+__device__ __forceinline__ void sens_env_from_rows(const T* ws, const int32_t* wsi, const T* sens, int64_t N, int64_t e, SensEnv<T>& ev) {
+    T y[13], acc[3], w[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        out[k] = (Rm[k] * a_in[0] + Rm[3 + k] * a_in[1] + Rm[6 + k] * a_in[2]) + (s.a_b + s.std[0] * z[k]);
-}
-template <typename T> __device__ __forceinline__ void unit3(T a[3]) {
-    const T n = Mth<T>::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    a[0] /= n; a[1] /= n; a[2] /= n;
-}
-template <typename T> __device__ __forceinline__ void cross3(const T a[3], const T b[3], T c[3]) {
-    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
-}
-// triad() :641-694, including scipy's Rotation.from_matrix(R.T).as_quat() (Shepperd's method)
-template <typename T>
-__device__ __forceinline__ void s_triad(Sens<T>& s, const T Rm[9], const T a_in[3], T f_thrust, const T* z, T q[4]) {
-    const T mag[3] = {T(-40.47), T(129.11), T(-98.99)};
-    T acc[3], gb[3], mb[3];
-    const T ind[3] = {s.R[2] * T(phys::G), s.R[5] * T(phys::G), f_thrust * T(1.0 / phys::M) + s.R[8] * T(phys::G)};
-    s_accel(s, Rm, a_in, z, acc);
-    const T mn[3] = {mag[0] + s.std[2] * z[3], mag[1] + s.std[2] * z[4], mag[2] + s.std[2] * z[5]};
+    for (int k = 0; k < 13; ++k) y[k] = ws[(int64_t)(ROW_STATE + k) * N + e];
+    // mat_rot of the step's last RHS call: if an aliased gyro_int has advanced the env's quaternion since, rotate with the saved one
+    const bool saved = sens[(int64_t)SR_ISAVE * N + e] == (T)(wsi[IROW_I * N + e] + 1);
+    T yq[13];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        gb[k] = acc[k] - ind[k];
-        mb[k] = Rm[k] * mn[0] + Rm[3 + k] * mn[1] + Rm[6 + k] * mn[2];
-    }
-    unit3(gb); unit3(mb);
-    T t1b[3] = {gb[0], gb[1], gb[2]}, t2b[3], t3b[3];
-    unit3(t1b);
-    cross3(gb, mb, t2b); unit3(t2b);
-    cross3(t1b, t2b, t3b); unit3(t3b);
-    T gi[3] = {T(0), T(0), T(-1)}, mi[3] = {mag[0], mag[1], mag[2]}, t2i[3], t3i[3];
-    unit3(mi);
-    cross3(gi, mi, t2i); unit3(t2i);
-    cross3(gi, t2i, t3i); unit3(t3i);
+    for (int k = 0; k < 13; ++k) yq[k] = (saved && k >= 6 && k < 10) ? sens[(int64_t)(SR_QSAVE + k - 6) * N + e] : y[k];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 3; ++k) acc[k] = ws[(int64_t)(ROW_ACCEL + k) * N + e];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s.R[3 * r + c] = t1b[r] * gi[c] + t2b[r] * t2i[c] + t3b[r] * t3i[c];
-    // quaternion of M = R^T
-    const T M[9] = {s.R[0], s.R[3], s.R[6], s.R[1], s.R[4], s.R[7], s.R[2], s.R[5], s.R[8]};
-    const T tr = M[0] + M[4] + M[8];
-    T x[4];
-    if (tr > M[0] && tr > M[4] && tr > M[8]) {  // argmax([M00, M11, M22, trace]) takes the FIRST maximum
-        x[0] = M[7] - M[5]; x[1] = M[2] - M[6]; x[2] = M[3] - M[1]; x[3] = T(1) + tr;
-    } else if (M[0] >= M[4] && M[0] >= M[8]) {
-        x[0] = T(1) - tr + T(2) * M[0]; x[1] = M[3] + M[1]; x[2] = M[6] + M[2]; x[3] = M[7] - M[5];
-    } else if (M[4] >= M[8]) {
-        x[1] = T(1) - tr + T(2) * M[4]; x[2] = M[7] + M[5]; x[0] = M[1] + M[3]; x[3] = M[2] - M[6];
-    } else {
-        x[2] = T(1) - tr + T(2) * M[8]; x[0] = M[2] + M[6]; x[1] = M[5] + M[7]; x[3] = M[3] - M[1];
-    }
-    const T n = Mth<T>::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-    q[0] = x[3] / n; q[1] = x[0] / n; q[2] = x[1] / n; q[3] = x[2] / n;
+    for (int k = 0; k < 4; ++k) w[k] = ws[(int64_t)(ROW_W + k) * N + e];
+    sens_env<T>(yq, acc, w, ev);
+#pragma unroll
+    for (int k = 6; k < 10; ++k) ev.y[k] = y[k];  // quad.state itself is the current one
 }
 
 // sensor_sp of rl_worker.py:164-175: accel_int, gyro_int, gyro, gps, triad -- 27 normals in that order
 template <typename T>
-__global__ __launch_bounds__(256) void k_sensor_read(int64_t N, T* ws, T* sens, const T* z27, uint64_t seed, uint64_t step,
-                                                     int64_t env_offset, int error, T t_step, T* out) {
-    using m = Mth<T>;
+__global__ __launch_bounds__(256) void k_sensor_read(int64_t N, T* ws, const int32_t* wsi, T* sens, const T* z27, uint64_t seed,
+                                                     uint64_t step, int64_t env_offset, SensParams<T> p, T t_step, T* out) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= N) return;
     T z[28];
@@ -1001,98 +966,78 @@ __global__ __launch_bounds__(256) void k_sensor_read(int64_t N, T* ws, T* sens, 
 #pragma unroll
         for (int k = 0; k < 27; ++k) z[k] = z27[(int64_t)k * N + e];
     } else {
-        const uint64_t g = (uint64_t)(env_offset + e);
-#pragma unroll
-        for (int blk = 0; blk < 7; ++blk) {
-            uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)step, ((uint32_t)(step >> 32) & 0x0FFFFFFFu) | ((uint32_t)blk << 28)};
-            philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5E50u);
-            float a0, a1, a2, a3;
-            box_muller(c[0], c[1], a0, a1); box_muller(c[2], c[3], a2, a3);
-            z[4 * blk] = (T)a0; z[4 * blk + 1] = (T)a1; z[4 * blk + 2] = (T)a2; z[4 * blk + 3] = (T)a3;
-        }
+        sens_philox_normals<T>(seed, step, (uint64_t)(env_offset + e), z);
     }
     Sens<T> s;
-    const T er = error ? T(1) : T(0);
-    s.std[0] = T(0.1) * er; s.std[1] = T(0.035) * er; s.std[2] = T(15) * er; s.std[3] = T(1.71) * er; s.std[4] = T(0.5) * er;
-    s.a_b_d = sens[(int64_t)SR_ABD * N + e]; s.g_b_d = sens[(int64_t)SR_GBD * N + e];
-    s.a_b = sens[(int64_t)SR_AB * N + e]; s.g_b = sens[(int64_t)SR_GB * N + e];
-    s.dt = t_step;
+    sens_load(sens, N, e, p, t_step, wsi[IROW_I * N + e], s);
+    SensEnv<T> ev;
+    sens_env_from_rows(ws, wsi, sens, N, e, ev);
+    T q_before[4];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s.R[k] = sens[(int64_t)(SR_R + k) * N + e];
-    T y[13];
+    for (int k = 0; k < 4; ++k) q_before[k] = ev.y[6 + k];
+    T o[24];
+    bool wrote_env;
+    sens_sp<T>(s, ev, z, o, wrote_env);
+    if (wrote_env) {
 #pragma unroll
-    for (int k = 0; k < 13; ++k) y[k] = ws[(int64_t)(ROW_STATE + k) * N + e];
-    // quad.mat_rot, quad.accel, quad.f_in of the last RHS call (all at the state the step ended in)
-    const T inv = m::rsqrt(y[6] * y[6] + y[7] * y[7] + y[8] * y[8] + y[9] * y[9]);
-    const T a = y[6] * inv, b = y[7] * inv, c = y[8] * inv, d = y[9] * inv;
-    const T Rm[9] = {a * a + b * b - c * c - d * d, T(2) * (b * c - a * d), T(2) * (b * d + a * c),
-                     T(2) * (b * c + a * d), a * a - b * b + c * c - d * d, T(2) * (c * d - a * b),
-                     T(2) * (b * d - a * c), T(2) * (c * d + a * b), a * a - b * b - c * c + d * d};
-    const T a_in[3] = {ws[(int64_t)(ROW_ACCEL + 0) * N + e], ws[(int64_t)(ROW_ACCEL + 1) * N + e],
-                       ws[(int64_t)(ROW_ACCEL + 2) * N + e] - T(phys::G)};
-    T f_thrust = T(0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const T w = ws[(int64_t)(ROW_W + k) * N + e]; f_thrust += w * w; }
-    f_thrust *= T(phys::K_F);
-    // accel_int :697-710
-    T acc_b[3], qd[4], acc[3], pos[3], vel[3];
-    s_accel(s, Rm, a_in, z, acc_b);
-    s_triad(s, Rm, a_in, f_thrust, z + 3, qd);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        acc[k] = s.R[k] * acc_b[0] + s.R[3 + k] * acc_b[1] + s.R[6 + k] * acc_b[2] + (k == 2 ? T(phys::G) : T(0));
-        vel[k] = sens[(int64_t)(SR_VEL + k) * N + e] + acc[k] * t_step;
-        pos[k] = sens[(int64_t)(SR_POS + k) * N + e] + vel[k] * t_step;
-        sens[(int64_t)(SR_VEL + k) * N + e] = vel[k];
-        sens[(int64_t)(SR_POS + k) * N + e] = pos[k];
+        for (int k = 0; k < 4; ++k) {
+            ws[(int64_t)(ROW_STATE + 6 + k) * N + e] = ev.y[6 + k];
+            sens[(int64_t)(SR_QSAVE + k) * N + e] = q_before[k];
+        }
+        sens[(int64_t)SR_ISAVE * N + e] = (T)(wsi[IROW_I * N + e] + 1);
     }
-    // gyro_int :712-722 (z[9..11]) with the aliasing quirk, then gyro() (z[12..14])
-    const bool alias = sens[(int64_t)SR_ALIAS * N + e] != T(0);
-    T qg[4], w3[3], vq[4];
-    s.g_b = s.g_b + s.g_b_d * t_step;
+    sens[(int64_t)SR_ALIAS * N + e] = T(0);  // gyro_int rebinds quaternion_t0 to a new array (q / |q|, :721)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) w3[k] = (s.g_b + s.std[1] * z[9 + k]) + y[10 + k];
+    for (int k = 0; k < 24; ++k) out[(int64_t)k * N + e] = o[k];
+    sens_store(sens, N, e, s);
+}
+
+// any sequence of the class's methods (the N = 1 drop-in `sensor` calls them one at a time): ops[0..n_ops), their normals
+// consecutively in z, their outputs consecutively in out (sop_normals / sop_outputs rows each)
+struct SensProgram { int32_t n_ops; int32_t ops[8]; };
+template <typename T>
+__global__ __launch_bounds__(256) void k_sensor_ops(int64_t N, T* ws, const int32_t* wsi, T* sens, const T* zin, SensProgram prog,
+                                                    SensParams<T> p, T t_step, T* out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    Sens<T> s;
+    sens_load(sens, N, e, p, t_step, wsi[IROW_I * N + e], s);
+    SensEnv<T> ev;
+    sens_env_from_rows(ws, wsi, sens, N, e, ev);
+    int zi = 0, oi = 0;
+    for (int k = 0; k < prog.n_ops; ++k) {
+        const int op = prog.ops[k];  // wave-uniform
+        T z[9], o[13];
+        const int nz = sop_normals(op), no = sop_outputs(op);
+        for (int j = 0; j < nz; ++j) z[j] = zin[(int64_t)(zi + j) * N + e];
+        if (op == SOP_ACCEL) sop_accel(s, ev, z, o);
+        else if (op == SOP_GYRO) sop_gyro(s, ev, z, o);
+        else if (op == SOP_GPS) sop_gps(s, ev, z, o, o + 3);
+        else if (op == SOP_TRIAD) {
+            sop_triad<T>(s, ev, z, o);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) qg[k] = alias ? y[6 + k] : sens[(int64_t)(SR_Q + k) * N + e];
-    vq[0] = T(0.5) * (-w3[0] * qg[1] - w3[1] * qg[2] - w3[2] * qg[3]);
-    vq[1] = T(0.5) * (w3[0] * qg[0] + w3[2] * qg[2] - w3[1] * qg[3]);
-    vq[2] = T(0.5) * (w3[1] * qg[0] - w3[2] * qg[1] + w3[0] * qg[3]);
-    vq[3] = T(0.5) * (w3[2] * qg[0] + w3[1] * qg[1] - w3[0] * qg[2]);
+            for (int j = 0; j < 9; ++j) o[4 + j] = s.R[j];
+        } else if (op == SOP_ACCEL_INT) sop_accel_int<T>(s, ev, z, o, o + 3, o + 6);
+        else {
+            bool wrote_env;
+            T q_before[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) qg[k] = qg[k] + vq[k] * t_step;
-    if (alias) {
+            for (int j = 0; j < 4; ++j) q_before[j] = ev.y[6 + j];
+            sop_gyro_int<T>(s, ev, z, o, wrote_env);
+            if (wrote_env) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ws[(int64_t)(ROW_STATE + 6 + k) * N + e] = qg[k];
-        sens[(int64_t)SR_ALIAS * N + e] = T(0);
+                for (int j = 0; j < 4; ++j) {
+                    ws[(int64_t)(ROW_STATE + 6 + j) * N + e] = ev.y[6 + j];
+                    sens[(int64_t)(SR_QSAVE + j) * N + e] = q_before[j];
+                }
+                sens[(int64_t)SR_ISAVE * N + e] = (T)(wsi[IROW_I * N + e] + 1);
+            }
+            sens[(int64_t)SR_ALIAS * N + e] = T(0);  // gyro_int rebinds quaternion_t0 to a new array (q / |q|, :721)
+        }
+        for (int j = 0; j < no; ++j) out[(int64_t)(oi + j) * N + e] = o[j];
+        zi += nz; oi += no;
     }
-    const T nq = m::sqrt(qg[0] * qg[0] + qg[1] * qg[1] + qg[2] * qg[2] + qg[3] * qg[3]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sens[(int64_t)(SR_Q + k) * N + e] = qg[k] / nq;
-    s.g_b = s.g_b + s.g_b_d * t_step;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) w3[k] = (s.g_b + s.std[1] * z[12 + k]) + y[10 + k];
-    vq[0] = T(0.5) * (-w3[0] * qg[1] - w3[1] * qg[2] - w3[2] * qg[3]);
-    vq[1] = T(0.5) * (w3[0] * qg[0] + w3[2] * qg[2] - w3[1] * qg[3]);
-    vq[2] = T(0.5) * (w3[1] * qg[0] - w3[2] * qg[1] + w3[0] * qg[3]);
-    vq[3] = T(0.5) * (w3[2] * qg[0] + w3[1] * qg[1] - w3[0] * qg[2]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { out[(int64_t)(2 * k) * N + e] = pos[k]; out[(int64_t)(2 * k + 1) * N + e] = vel[k]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { out[(int64_t)(6 + k) * N + e] = qg[k]; out[(int64_t)(10 + k) * N + e] = vq[k]; }
-    // gps :633-638 (z[15..20])
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        out[(int64_t)(14 + k) * N + e] = s.std[3] * z[15 + k] + y[2 * k];
-        out[(int64_t)(17 + k) * N + e] = s.std[4] * z[18 + k] + y[2 * k + 1];
-    }
-    // triad again (z[21..26])
-    T qt[4];
-    s_triad(s, Rm, a_in, f_thrust, z + 21, qt);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[(int64_t)(20 + k) * N + e] = qt[k];
-    sens[(int64_t)SR_AB * N + e] = s.a_b; sens[(int64_t)SR_GB * N + e] = s.g_b;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) sens[(int64_t)(SR_R + k) * N + e] = s.R[k];
+    sens_store(sens, N, e, s);
 }
 
 // ---- GAE ---------------------------------------------------------------------------------------
@@ -1282,6 +1227,17 @@ __global__ __launch_bounds__(256) void k_visual_reward(int64_t N, int total_step
 
 using namespace qenv;
 
+// sensor.__init__'s defaults (:588-592) times sensor.error, or the caller's eight values {accel_std, gyro_std, magnet_std,
+// gps_std_p, gps_std_v, accel_bias_drift, gyro_bias_drift, magnet_bias_drift}
+template <typename T> static SensParams<T> sens_params(const double* params, int error) {
+    static const double dflt[8] = {0.1, 0.035, 15, 1.71, 0.5, 0.0005, 0.00015, 0.075};
+    const double* v = params ? params : dflt;
+    SensParams<T> p;
+    for (int k = 0; k < 5; ++k) p.std[k] = (T)(v[k] * (error ? 1.0 : 0.0));
+    for (int k = 0; k < 3; ++k) p.bd[k] = (T)(v[5 + k] * (error ? 1.0 : 0.0));
+    return p;
+}
+
 extern "C" {
 
 int qenv_window_push(qenv_t q, const void* obs, const void* actions, int reset_first) {
@@ -1428,29 +1384,63 @@ int qenv_sample_init_states(qenv_t q, uint64_t seed, uint64_t episode, int64_t e
     return check_launch("k_sample_init");
 }
 
-int qenv_sensor_reset(qenv_t q, void* sens, const void* u3, uint64_t seed, uint64_t episode, int64_t env_offset, int error) {
+int qenv_sensor_reset(qenv_t q, void* sens, const void* u3, uint64_t seed, uint64_t episode, int64_t env_offset, int error,
+                      const double* params) {
     if (!q || !sens) return fail(QENV_ERR_ARG, "qenv_sensor_reset: null argument");
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     const dim3 g((unsigned)((q->N + 255) / 256)), b(256);
     if (q->cfg.dtype == QENV_F64)
-        hipLaunchKernelGGL((k_sensor_reset<double>), g, b, 0, q->stream, q->N, (const double*)q->ws, (double*)sens, (const double*)u3,
-                           seed, episode, env_offset, error);
+        hipLaunchKernelGGL((k_sensor_reset<double>), g, b, 0, q->stream, q->N, (const double*)q->ws, q->wsi, (double*)sens, (const double*)u3,
+                           seed, episode, env_offset, sens_params<double>(params, error));
     else
-        hipLaunchKernelGGL((k_sensor_reset<float>), g, b, 0, q->stream, q->N, (const float*)q->ws, (float*)sens, (const float*)u3, seed,
-                           episode, env_offset, error);
+        hipLaunchKernelGGL((k_sensor_reset<float>), g, b, 0, q->stream, q->N, (const float*)q->ws, q->wsi, (float*)sens, (const float*)u3, seed,
+                           episode, env_offset, sens_params<float>(params, error));
     return check_launch("k_sensor_reset");
 }
 
-int qenv_sensor_read(qenv_t q, void* sens, const void* z27, uint64_t seed, uint64_t step, int64_t env_offset, int error,
-                     void* out) {
-    if (!q || !sens || !out) return fail(QENV_ERR_ARG, "qenv_sensor_read: null argument");
+int qenv_sensor_bias_reset(qenv_t q, void* sens, const void* u3, int error, const double* params) {
+    if (!q || !sens || !u3) return fail(QENV_ERR_ARG, "qenv_sensor_bias_reset: null argument");
     const dim3 g((unsigned)((q->N + 255) / 256)), b(256);
     if (q->cfg.dtype == QENV_F64)
-        hipLaunchKernelGGL((k_sensor_read<double>), g, b, 0, q->stream, q->N, (double*)q->ws, (double*)sens, (const double*)z27, seed,
-                           step, env_offset, error, q->cfg.t_step, (double*)out);
+        hipLaunchKernelGGL((k_sensor_bias_reset<double>), g, b, 0, q->stream, q->N, (double*)sens, (const double*)u3, sens_params<double>(params, error));
     else
-        hipLaunchKernelGGL((k_sensor_read<float>), g, b, 0, q->stream, q->N, (float*)q->ws, (float*)sens, (const float*)z27, seed, step,
-                           env_offset, error, (float)q->cfg.t_step, (float*)out);
+        hipLaunchKernelGGL((k_sensor_bias_reset<float>), g, b, 0, q->stream, q->N, (float*)sens, (const float*)u3, sens_params<float>(params, error));
+    return check_launch("k_sensor_bias_reset");
+}
+
+int qenv_sensor_read(qenv_t q, void* sens, const void* z27, uint64_t seed, uint64_t step, int64_t env_offset, int error,
+                     const double* params, void* out) {
+    if (!q || !sens || !out) return fail(QENV_ERR_ARG, "qenv_sensor_read: null argument");
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+    const dim3 g((unsigned)((q->N + 255) / 256)), b(256);
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_sensor_read<double>), g, b, 0, q->stream, q->N, (double*)q->ws, q->wsi, (double*)sens, (const double*)z27, seed,
+                           step, env_offset, sens_params<double>(params, error), q->cfg.t_step, (double*)out);
+    else
+        hipLaunchKernelGGL((k_sensor_read<float>), g, b, 0, q->stream, q->N, (float*)q->ws, q->wsi, (float*)sens, (const float*)z27, seed, step,
+                           env_offset, sens_params<float>(params, error), (float)q->cfg.t_step, (float*)out);
     return check_launch("k_sensor_read");
+}
+
+int qenv_sensor_ops(qenv_t q, void* sens, const int32_t* ops, int n_ops, const void* z, int error, const double* params,
+                    void* out) {
+    if (!q || !sens || !ops || !z || !out) return fail(QENV_ERR_ARG, "qenv_sensor_ops: null argument");
+    if (n_ops < 1 || n_ops > 8) return fail(QENV_ERR_ARG, "qenv_sensor_ops: 1..8 methods per call");
+    SensProgram prog;
+    prog.n_ops = n_ops;
+    for (int k = 0; k < n_ops; ++k) {
+        if (ops[k] < 0 || ops[k] >= SOP_COUNT) return fail(QENV_ERR_ARG, "qenv_sensor_ops: unknown method id");
+        prog.ops[k] = ops[k];
+    }
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+    const dim3 g((unsigned)((q->N + 255) / 256)), b(256);
+    if (q->cfg.dtype == QENV_F64)
+        hipLaunchKernelGGL((k_sensor_ops<double>), g, b, 0, q->stream, q->N, (double*)q->ws, q->wsi, (double*)sens, (const double*)z, prog,
+                           sens_params<double>(params, error), q->cfg.t_step, (double*)out);
+    else
+        hipLaunchKernelGGL((k_sensor_ops<float>), g, b, 0, q->stream, q->N, (float*)q->ws, q->wsi, (float*)sens, (const float*)z, prog,
+                           sens_params<float>(params, error), (float)q->cfg.t_step, (float*)out);
+    return check_launch("k_sensor_ops");
 }
 
 static int gae_impl(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,

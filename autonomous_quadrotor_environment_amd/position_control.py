@@ -1,7 +1,8 @@
 """Outer position loops around the PPO velocity policy, for N quadrotors at once, everything on the device:
 
-* MissionTracker  -- environment/position.py:216-244 (REAL_CTRL branch): policy -> step -> mission.get_error ->
-  vel_pid (environment/controller/velocity_pid.py:16-35) -> window of `states - error`.
+* MissionTracker  -- environment/position.py:216-244: policy -> step -> mission.get_error -> vel_pid
+  (environment/controller/velocity_pid.py:16-35) -> window of `states - error` (REAL_CTRL), or of the SENSED state
+  `states_sens - error` (REAL_CTRL = False, :240-242) with a BatchedSensor fused into the step kernel (`sensor=`).
 * LandingBaseline -- visual_landing/math_trajectory.py:34-157: random marker / start, PD position loop (pos_pi) ->
   clipped velocity command -> policy, visual_reward (rl_reward_fuction.py) deciding the end of each episode.
 
@@ -24,10 +25,12 @@ class MissionTracker:
         self.env, self.w = env, weights
         self.action = torch.zeros(4, env.n_envs, device=env.device, dtype=env.dtype)
 
-    def run(self, table, n_steps, init_state=None, log=False):
+    def run(self, table, n_steps, init_state=None, log=False, sensor=None):
         """Reset (hover unless init_state is given), then n_steps of policy + outer loop on the mission table
         [n, 7] (mission.table()).  Returns the position error norm summed over the steps (position.py:221,
-        `error_sum`) per env, and the [n_steps, 3, N] positions if log."""
+        `error_sum`) per env, and the [n_steps, 3, N] positions if log.  sensor: a BatchedSensor of this env -- the
+        policy then flies on the dead-reckoned / gyro-integrated state (position.py's REAL_CTRL = False), still two
+        launches per step."""
         env = self.env
         if init_state is None:
             init_state = np.array([0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0])
@@ -35,6 +38,9 @@ class MissionTracker:
         env.outer_velpid(table)
         env.outer_reset()
         env.reset(init_state, return_history=False, push_window=True)
+        if sensor is not None:
+            sensor.reset()      # self.sensor.reset() after env.reset (:206)
+            sensor.attach()
         tdev = env._outer_target
         err_sum = torch.zeros(env.n_envs, device=env.device, dtype=env.dtype)
         pos_log = torch.empty(n_steps, 3, env.n_envs, device=env.device, dtype=env.dtype) if log else None
@@ -48,6 +54,8 @@ class MissionTracker:
             if log:
                 pos_log[k] = pos
         env.outer_velpid(None)
+        if sensor is not None:
+            sensor.detach()
         return (err_sum, pos_log) if log else err_sum
 
 

@@ -278,6 +278,8 @@ class BatchedQuad:
         self._bind()
         if push_window:
             flags |= L.STEP_PUSH_WINDOW
+            if getattr(self, "_sensor", None) is not None and getattr(self, "_outer_kind", None) != "pospi":
+                self._sensor.calls += 1  # mirrors the handle's count of fused sensor evaluations (BatchedSensor.attach)
         if (flags & 3) == L.STEP_DYNAMICS_ONLY:
             L.check(L.lib.qenv_step(self._h, L.ptr(act), None, None, None, None, flags), "qenv_step")
             return None, None, None
@@ -455,6 +457,7 @@ class BatchedQuad:
             if table.dim() != 2 or table.shape[1] != 7:
                 raise ValueError(f"mission table: expected [n, 7], got {tuple(table.shape)}")
         self._outer_target = table
+        self._outer_kind = None if table is None else "velpid"
         L.check(L.lib.qenv_outer_velpid(self._h, L.ptr(table), 0 if table is None else int(table.shape[0])),
                 "qenv_outer_velpid")
 
@@ -462,6 +465,7 @@ class BatchedQuad:
         """pos_pi + velocity clip (math_trajectory.py:46-62,:123) towards per-env targets [3, N]; None = off."""
         t = self._as_rows(targets, 3, "targets")
         self._outer_target = t
+        self._outer_kind = None if t is None else "pospi"
         L.check(L.lib.qenv_outer_pospi(self._h, L.ptr(t), float(P), float(D), float(I)), "qenv_outer_pospi")
 
     def outer_reset(self, mask=None):
@@ -546,6 +550,11 @@ class quad:
         self.direct_control_flag = direct_control
         self.J_mat = J
         self.robust_parameters = _RobustParameters()
+        if variant == "main":  # robust_control.__init__ calls its own reset() (:85-91): the constructor consumes 12 draws
+            params = draw_robust_params(np.random)
+            rp = self.robust_parameters
+            rp.episode_kf, rp.episode_m, rp.episode_ir = params[0:4], params[4:5], params[5:9]
+            rp.episode_J = np.eye(3) * params[9:12]
         self.i = 0
         self.done = True
         self.solved = 0

@@ -239,13 +239,35 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
  * (seed; global env index, step).  error = sensor.error (0 disables noise and drift).
  * qenv_sensor_read writes out [24][N] = states_sens[14] {x,vx,y,vy,z,vz dead-reckoned, quaternion_gyro[4],
  * quaternion_vel[4]}, gps_pos[3], gps_vel[3], quaternion_triad[4].  It needs the ACCEL / W rows, i.e. the env must be
- * stepped with QENV_STEP_FULL.  Faithful to the reference's aliasing quirk: after a reset, the first gyro
- * integration advances the ENV's own quaternion rows in place (quaternion_t0 is a view of quad.state, :630,:719). */
-#define QENV_SENSOR_ROWS 25
+ * stepped with QENV_STEP_FULL.  Faithful to the reference's aliasing quirk: sensor.reset() makes quaternion_t0 a view
+ * of the array quad.state is bound to (:630), so the first gyro integration after it advances the ENV's own
+ * quaternion rows in place (:719) -- but only if the env has not been stepped in between (quad.step rebinds quad.state
+ * to a new array; the view then points at an orphan and the env is left alone). */
+#define QENV_SENSOR_ROWS 31
+/* params: NULL = sensor.__init__'s defaults (:588-592), or eight doubles {accel_std, gyro_std, magnet_std, gps_std_p,
+ * gps_std_v, accel_bias_drift, gyro_bias_drift, magnet_bias_drift}; every one is multiplied by `error` (0 / 1). */
 int qenv_sensor_reset(qenv_t q, void *sens, const void *u3, uint64_t seed, uint64_t episode,
-                      int64_t env_offset, int error);
+                      int64_t env_offset, int error, const double *params);
 int qenv_sensor_read(qenv_t q, void *sens, const void *z27, uint64_t seed, uint64_t step,
-                     int64_t env_offset, int error, void *out);
+                     int64_t env_offset, int error, const double *params, void *out);
+/* The class's methods one by one (the N = 1 drop-in `sensor` of the host package calls them like the reference's
+ * scripts do): ops[0..n_ops) with 0 accel (:612), 1 gyro (:623), 2 gps (:633), 3 triad (:641), 4 accel_int (:697),
+ * 5 gyro_int (:712).  z: the standard normals the methods draw, consecutive rows [sum][N] in call order (accel 3,
+ * gyro 3, gps 3 + 3, triad 3 + 3, accel_int 3 + 6, gyro_int 3); out: consecutive rows [sum][N]: accel 3, gyro 3,
+ * gps pos 3 + vel 3, triad q 4 + R 9 (row-major), accel_int acceleration 3 + velocity 3 + position 3, gyro_int q 4.
+ * qenv_sensor_bias_reset: bias_reset (:601-609) alone, from three uniforms u3 [3][N]. */
+int qenv_sensor_ops(qenv_t q, void *sens, const int32_t *ops, int n_ops, const void *z, int error,
+                    const double *params, void *out);
+int qenv_sensor_bias_reset(qenv_t q, void *sens, const void *u3, int error, const double *params);
+/* Sensor in the loop (environment/position.py:226-242, REAL_CTRL = False): with a sensor attached, every
+ * qenv_step(... | QENV_STEP_PUSH_WINDOW) evaluates qenv_sensor_read's sequence inside the step kernel, on the state the
+ * step ended in (no ACCEL / W rows needed: QENV_STEP_NO_AUX works), and pushes [action, dead-reckoned velocity - velocity
+ * command of the outer loop, quaternion_gyro, quaternion_vel] into the policy window instead of the true state's slice.
+ * z27 nullable [27][N] (read at every step: the caller refills it; NULL = Philox keyed by (seed; env, calls + k) for the
+ * k-th fused step), out24 nullable [24][N] receiving qenv_sensor_read's outputs.  sens = NULL detaches.  The reset
+ * warm-up pushes and the pos_pi landing loop keep the true state, as in the reference. */
+int qenv_attach_sensor(qenv_t q, void *sens, const void *z27, uint64_t seed, int64_t env_offset, int error,
+                       const double *params, void *out24, uint64_t calls);
 
 /* Dense tail of the legacy landing policy (visual_landing/rl_nn_model.py:58-66 actor, :77-84 critic):
  * Linear(K,H) tanh Linear(H,H) tanh Linear(H,n_out) [tanh] on flattened conv features (K = 800, H = 64,

@@ -816,6 +816,108 @@ def g20():
     save("g20_landing_baseline", **rec)
 
 
+def g24():
+    """class sensor (quadrotor_env.py:579-724) method by method, in orders rl_worker.py does NOT use, on the GLOBAL numpy
+    stream seeded once: what a script that seeds, builds env + sensor and calls the methods gets back.  Pins the N = 1
+    drop-in `sensor` (same constructor, same draws from np.random in the same places)."""
+    arng = np.random.RandomState(24)
+    acts = np.clip(arng.normal(0, 0.3, (36, 4)), -1, 1)
+    x0 = rand_state(np.random.RandomState(8), 0.3)
+    np.random.seed(2024)
+    env = make_env(t_step=0.01, n=1000, training=False, euler=0, direct_control=1, T=1)
+    with quiet:
+        env.reset(x0.copy())
+    sens = qe.sensor(env, accel_std=0.12, gyro_std=0.03, gps_std_p=1.5)   # non-default parameters travel too
+    sens.reset()
+    orders = (("gps", "accel", "gyro_int", "triad"), ("gyro", "accel_int"), ("triad", "gyro_int", "gps", "accel"),
+              ("accel_int", "gyro_int", "gyro", "gps", "triad"))
+    rows, states = [], []
+    for k in range(36):
+        if k == 20:
+            sens.error = False     # takes effect at the reset below
+            sens.reset()
+        out = []
+        for name in orders[k % 4]:
+            r = getattr(sens, name)()
+            for piece in (r if isinstance(r, tuple) else (r,)):
+                out.append(np.array(piece, dtype=float).ravel())
+        rows.append(np.concatenate(out))
+        states.append(np.array(env.state, dtype=float))
+        with quiet:
+            env.step(acts[k])
+    width = max(len(r) for r in rows)
+    pad = np.full((36, width), np.nan)
+    for k, r in enumerate(rows):
+        pad[k, :len(r)] = r
+    save("g24_sensor_methods", x0=x0, actions=acts, out=pad, state_after_calls=np.array(states),
+         R_final=np.array(sens.R, dtype=float), orders=np.array(["|".join(o) for o in orders]))
+
+
+def g25():
+    """Sensor in the loop: the else-branch of environment/position.py:216-244 with REAL_CTRL = False -- policy on the
+    window, env.step, the sensor sequence (:226-232), mission error + vel_pid on the TRUE state, and the window fed with
+    states_sens - error_mission (:240-242).  position.py needs panda3d; the loop below is the harness's, every called
+    piece the reference's.  Noise recorded as in g17 (inputs of the fixture)."""
+    from environment.controller.velocity_pid import vel_pid
+    from mission_control.mission_control import mission
+    rng = np.random.RandomState(125)
+    env, pol = _policy_loop_env()
+    mc = mission(0.01)
+    mc.gen_trajectory(5000, int(2.0 / 0.01), np.array([0.8, -0.4, 0.6]))
+    aux = dl_in_gen(5, 13, 4)
+    x0 = np.array([0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0])
+    with quiet:
+        states, action = env.reset(x0.copy())
+    net_in = aux.dl_input(states, action)
+    sens = qe.sensor(env)
+    zs, us = [], []
+    real_normal, real_random = np.random.normal, np.random.random
+
+    def fake_normal(loc=0.0, scale=1.0, size=None):
+        n = int(np.prod(size)) if size is not None else int(np.size(loc))
+        z = rng.normal(0, 1, n)
+        zs.append(z)
+        return np.asarray(loc) + np.asarray(scale) * (z if n > 1 or size is not None else z[0])
+
+    def fake_random(size=None):
+        u = rng.random_sample()
+        us.append(u)
+        return u
+    np.random.normal, np.random.random = fake_normal, fake_random
+    rows, acts, sens_rows, wins, tgts = [], [], [], [], []
+    try:
+        sens.reset()
+        cumm, der = 0, np.array([0, 0])
+        for k in range(120):
+            with torch.no_grad():
+                action = pol.actor(torch.FloatTensor(net_in)).cpu().detach().numpy()
+            # position.py hands env.step the float32 array as it is, which makes numpy evaluate f2F's thrusts in float32
+            # ((action + 1) * T2WR * M * G / 8 with python scalars keeps the array's dtype); the fixture widens it first,
+            # so that the env arithmetic is the fp64 one every other fixture pins and the comparison isolates the loop
+            action = action.astype(np.float64)
+            with quiet:
+                states, _, _ = env.step(action)
+            _, vel_a, pos_a = sens.accel_int()
+            q_gyro = sens.gyro_int()
+            ang_vel = sens.gyro()
+            q_vel = qu.deriv_quat(ang_vel, q_gyro)
+            sens.gps()
+            sens.triad()
+            err = mc.get_error(env.i * env.t_step)
+            tgts.append(err.copy())
+            pid_error, cumm, der = vel_pid(env.state, err, cumm, der)
+            err = err + pid_error
+            pos_vel = np.array([pos_a[0], vel_a[0], pos_a[1], vel_a[1], pos_a[2], vel_a[2]])
+            states_sens = [np.concatenate((pos_vel, np.array(q_gyro, dtype=float), np.array(q_vel, dtype=float).ravel()))] - err
+            net_in = aux.dl_input(states_sens, [action])
+            rows.append(np.array(env.state, dtype=float)); acts.append(np.array(action, dtype=float))
+            sens_rows.append(np.array(states_sens[0] + err, dtype=float)); wins.append(np.array(net_in, dtype=np.float32))
+    finally:
+        np.random.normal, np.random.random = real_normal, real_random
+    save("g25_sensor_in_loop", x0=x0, u3=np.array(us[-3:]), z=np.concatenate(zs).reshape(120, 27), targets=np.array(tgts),
+         state=np.array(rows), actions=np.array(acts), states_sens=np.array(sens_rows), window=np.array(wins))
+
+
 def g23():
     """g21 with the action std LEARNED (model.py:45-48, fixed_std = False; ppo.py:301 sets FIXED_STD = True by default,
     flipping the module global is the reference's own switch): after PPO.update the state dict holds the trained std."""
@@ -919,6 +1021,6 @@ def g22():
 
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25"]
     for name in todo:
         globals()[name]()

@@ -86,3 +86,68 @@ def test_landing_baseline_batch_statistics(aq):
     assert landed > 0.99 and solved > 0.9, (landed, solved)
     t = out["steps"].float() * 0.01
     assert 1.0 < float(t.mean()) < 6.0
+
+
+def test_sensor_dropin_methods_golden(aq):
+    """g24: the reference's `sensor` class called method by method (orders rl_worker.py does not use, non-default
+    parameters, error switched off mid-run) on a seeded GLOBAL numpy stream, against the N = 1 drop-in `aq.sensor` on the
+    `quad` drop-in: the same script, the same draws, the same numbers -- and the aliasing quirk's effect on the env."""
+    g = golden("g24_sensor_methods")
+    np.random.seed(2024)
+    env = aq.quad(0.01, 1000, training=False, euler=0, direct_control=1, T=1)
+    env.reset(g["x0"].copy())
+    sens = aq.sensor(env, accel_std=0.12, gyro_std=0.03, gps_std_p=1.5)
+    sens.reset()
+    orders = [tuple(o.split("|")) for o in g["orders"]]
+    for k in range(36):
+        if k == 20:
+            sens.error = False
+            sens.reset()
+        out = []
+        for name in orders[k % 4]:
+            r = getattr(sens, name)()
+            for piece in (r if isinstance(r, tuple) else (r,)):
+                out.append(np.array(piece, dtype=float).ravel())
+        out = np.concatenate(out)
+        ref = g["out"][k][:len(out)]
+        assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-9, (k, orders[k % 4])
+        assert scaled_err(np.asarray(env.state), g["state_after_calls"][k], STATE_SCALE) < 1e-9, k
+        env.step(g["actions"][k])
+    assert np.max(np.abs(sens.R - g["R_final"])) < 1e-9
+    assert sens.a_std == 0 and sens.gps_std_p == 0 and abs(sens.a_b_d) == 0  # error = False reached bias_reset
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+def test_sensor_in_the_loop_fused_step_golden(aq, dt, tol):
+    """g25 = position.py:216-244 with REAL_CTRL = False run by the reference's pieces: env.step, the sensor sequence,
+    mission error + vel_pid on the true state, window <- states_sens - error_mission.  Here ONE step launch does all of
+    it (sensor attached to the handle, vel_pid inside the window push); teacher-forced with the reference's actions and
+    recorded noise: sensed state, env state (aliasing quirk included) and the 75-float policy window at every step."""
+    g = golden("g25_sensor_in_loop")
+    n = g["state"].shape[0]
+    N = 4
+    table = np.concatenate([g["targets"][:, 0:5:2], g["targets"][:, 1:6:2], np.zeros((n, 1))], 1)
+    env = aq.BatchedQuad(N, 0.01, 3000, training=False, direct_control=1, T=5, dtype=dt)
+    env.outer_velpid(table)
+    env.outer_reset()
+    env.reset(np.repeat(g["x0"][:, None], N, 1), return_history=False, push_window=True)
+    sens = aq.BatchedSensor(env)
+    sens.reset(torch.from_numpy(np.repeat(g["u3"][:, None], N, 1)))
+    z27 = torch.zeros(27, N, device="cuda", dtype=dt)
+    out24 = torch.zeros(24, N, device="cuda", dtype=dt)
+    sens.attach(z27, out24)
+    act = torch.zeros(4, N, device="cuda", dtype=dt)
+    for k in range(n):
+        z27.copy_(torch.from_numpy(np.repeat(g["z"][k][:, None], N, 1)))
+        act.copy_(torch.from_numpy(np.repeat(g["actions"][k][:, None], N, 1)))
+        env.step(act, flags=2, push_window=True)   # NO_AUX: the fused sensor needs no ACCEL / W rows
+        ss = _np(out24[:14, 1])
+        assert np.max(np.abs(ss - g["states_sens"][k]) / np.maximum(np.abs(g["states_sens"][k]), 1.0)) < tol * (1 + k), k
+        assert scaled_err(_np(env.state)[:, 2], g["state"][k], STATE_SCALE) < tol * 10, k
+        ring = _np(env.window[:, 0]).reshape(5, 15)
+        head = (k + 1) % 5  # five warm-up pushes, then one per step: the oldest slice sits at the ring head
+        win = np.concatenate([ring[(head + j) % 5] for j in range(5)])
+        assert np.max(np.abs(win - g["window"][k])) < max(tol * 50, 2e-6), k
+    assert sens.calls == n
+    sens.detach()
+    assert torch.equal(env.state[:, 0], env.state[:, 3])

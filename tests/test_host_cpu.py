@@ -37,10 +37,10 @@ def test_argument_validation_without_a_device(built):
     cfg.dtype = L.F64
     n64 = L.lib.qenv_workspace_bytes(C.byref(cfg))
     # 88 rows of T (61 + 12 robust parameters + 6 gust + 9 outer loop) + 6 int rows + the 256-byte tail of the two
-    # reset-list counters (their own slot, valid for n_envs = 1 too) + two byte-per-tile flag arrays (256-byte aligned)
+    # reset-list counters (their own slot, valid for n_envs = 1 too) + two byte-per-env flag arrays (256-byte aligned)
     # + 15*T float rows, 256-byte aligned sections
-    assert n32 == 88 * 1024 * 4 + 6 * 1024 * 4 + 256 + 2 * 256 + 75 * 1024 * 4
-    assert n64 == 88 * 1024 * 8 + 6 * 1024 * 4 + 256 + 2 * 256 + 75 * 1024 * 4
+    assert n32 == 88 * 1024 * 4 + 6 * 1024 * 4 + 256 + 2 * 1024 + 75 * 1024 * 4
+    assert n64 == 88 * 1024 * 8 + 6 * 1024 * 4 + 256 + 2 * 1024 + 75 * 1024 * 4
     one = L.QenvConfig(1, 0.01, 1000, 5, 1, 1, 1, L.MAIN, L.RK45, L.F32, 0)
     assert L.lib.qenv_workspace_bytes(C.byref(one)) == 512 + 256 + 256 + 512 + 512  # rows, int rows, counters, flags, ring
     lean = L.QenvConfig(1024, 0.01, 1000, 5, 1, 1, 1, L.MAIN, L.RK45, L.F64, 2)
@@ -60,7 +60,10 @@ def test_argument_validation_without_a_device(built):
     assert L.lib.qenv_robust_gusts(None, None, 1, 1, 0, 0) == -1
     assert L.lib.qenv_outer_velpid(None, None, 0) == -1 and L.lib.qenv_outer_pospi(None, None, 0.0, 0.0, 0.0) == -1
     assert L.lib.qenv_outer_reset(None, None) == -1
-    assert L.lib.qenv_sensor_read(None, None, None, 0, 0, 0, 1, None) == -1
+    assert L.lib.qenv_sensor_read(None, None, None, 0, 0, 0, 1, None, None) == -1
+    assert L.lib.qenv_sensor_ops(None, None, None, 1, None, 1, None, None) == -1
+    assert L.lib.qenv_ppo_step(None, None) == -1 and L.lib.qenv_ppo_flush(None) == -1
+    assert L.lib.qenv_attach_sensor(None, None, None, 0, 0, 0, None, None, 0) == -1
     assert L.lib.qenv_dense_tail_chunks(64, 0, 75, 128, 4, 1, *([None] * 8), None) == -1
     assert L.lib.qenv_mlp_backward(0, 1, 75, 128, 4, 1, *([None] * 13), None) == -1
     with pytest.raises(L.QenvError):

@@ -379,6 +379,30 @@ def test_g19_mission_tracking_with_vel_pid(oracle, tag):
     assert np.abs(obs - g[f"{tag}_window_last"]).max() < 5e-4
 
 
+def test_g25_sensor_in_the_loop(oracle):
+    """position.py:216-244 with REAL_CTRL = False (teacher-forced with the fixture's actions): step -> sensor sequence ->
+    mission error + vel_pid on the true state -> window of states_sens - error.  The sensor is reset BEFORE the first
+    step and first read AFTER it, so quaternion_t0's numpy view points at an orphaned array: the env must stay untouched."""
+    g = golden("g25_sensor_in_loop")
+    env = oracle.OracleQuad(0.01, 3000, training=False, direct_control=1, T=5)
+    s, a = env.reset(g["x0"])
+    win = oracle.OracleWindow(5)
+    win.dl_input(s, a)
+    sens = oracle.OracleSensor(env)
+    sens.reset(g["u3"], True)
+    pid = oracle.OracleVelPid()
+    for k in range(g["state"].shape[0]):
+        act = g["actions"][k]
+        env.step(act)
+        out = np.concatenate(sens.sensor_sp(g["z"][k]))
+        assert np.max(np.abs(out[:14] - g["states_sens"][k])) < 1e-11, k
+        assert scaled_err(env.state, g["state"][k], STATE_SCALE) < 1e-11, k
+        err = g["targets"][k].copy()
+        err = err + pid(env.state, err)
+        obs = win.dl_input((out[:14] - err)[None, :], act[None, :])
+        assert np.max(np.abs(obs - g["window"][k])) < 1e-6, k
+
+
 def test_g19_tables_match_the_mission_mirror():
     """The fixture's target rows are what the package's own mission mirror hands out (host logic, no device)."""
     import importlib.util, os, sys, types
