@@ -616,6 +616,219 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
     }
 }
 
+// ---- the same MLP for WIDE hidden layers (N = 256: W2 alone is 256 KiB, more than the LDS) -------------------------
+// k_mlp<256> read W2 from global memory inside the MFMA chain: 128 dependent 4-byte loads per output tile, which hipcc
+// hoisted until the kernel held 256 VGPRs + 256 AGPRs and still spilled 912 B per lane.  Here the four waves of a
+// workgroup march over the eight layer-2 output tiles together (each on its own 32-env tile) and the 32 weight rows of
+// the CURRENT output tile -- a contiguous 32 KiB block of W2 -- are staged through LDS by the whole workgroup, rows
+// padded by one word so the A-operand reads (lane = weight row) are conflict-free and the coalesced staging writes too.
+// NBUF = 2 double-buffers the block (the global loads of tile t+1 are issued before the MFMAs of tile t and written to
+// LDS after them: one barrier per output tile); NBUF = 1 when the window is too long for two buffers.  MFMA order, k
+// pairing and operands are k_mlp's, so the results are bit-identical to the kernel this one replaces.
+template <int H, int TW, int NBUF, bool SAMPLE = false>
+__global__ __launch_bounds__(256) void k_mlp_wide(const MlpArgs a) {
+    static_assert(H % 32 == 0 && H > 128, "the wide kernel is for hidden layers that do not fit the LDS");
+    constexpr int NT = H / 32, PITCH = H + 1, TILE_WORDS = 32 * PITCH, PER_LANE = 32 * H / 256;
+    static_assert(NT % 2 == 0 || NBUF == 1, "buffer parity wraps across rounds");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K1 = TW ? 15 * TW : 15 * a.T, K1P = (K1 + 1) & ~1;
+    float* W1t = lds;                    // [K1P][H]  (k-major)
+    float* W3t = W1t + (size_t)K1P * H;  // [H][4]    (the four real output rows)
+    float* b1s = W3t + 4 * H;
+    float* b2s = b1s + H;
+    float* b3s = b2s + H;                // [32]
+    float* W2s = b3s + 32;               // [NBUF][32][PITCH]: output rows 32 t .. 32 t + 31 of W2, k contiguous
+    {
+        constexpr int KL = 8, HL = 8;
+        const int kl = threadIdx.x % KL, hl = (threadIdx.x / KL) % HL, wv = threadIdx.x >> 6;
+        const int kb1 = (K1P + KL - 1) / KL;
+        for (int blk = wv; blk < (H / HL) * kb1; blk += 4) {
+            const int h = (blk / kb1) * HL + hl, k = (blk % kb1) * KL + kl;
+            if (k < K1P) W1t[k * H + h] = k < K1 ? a.W1[(size_t)h * K1 + k] : 0.f;
+        }
+    }
+    for (int idx = threadIdx.x; idx < 4 * H; idx += 256) {
+        const int h = idx / 4, o = idx % 4;
+        W3t[idx] = o < a.n_out ? a.W3[(size_t)o * H + h] : 0.f;
+    }
+    for (int h = threadIdx.x; h < H; h += 256) {
+        b1s[h] = a.b1[h];
+        b2s[h] = a.b2[h];
+    }
+    if (threadIdx.x < 32) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    // staging: wave w moves rows 8 w .. 8 w + 7 of the block, 64 consecutive k per instruction
+    float st[PER_LANE];
+    auto stage_load = [&](int t) {
+        // the element offset is made opaque per use: left to itself hipcc computes the 64-bit address of every one of
+        // the NT * PER_LANE loads once, outside the round loop, and spills them (180 pairs)
+        uint32_t off = (uint32_t)((32 * t + 8 * wave) * H + lane);
+        asm volatile("" : "+v"(off));
+        const float* src = a.W2 + off;
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) st[i] = src[(i / (H / 64)) * H + 64 * (i % (H / 64))];
+    };
+    auto stage_write = [&](int buf) {
+        float* dst = W2s + buf * TILE_WORDS + (8 * wave) * PITCH + lane;
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) dst[(i / (H / 64)) * PITCH + 64 * (i % (H / 64))] = st[i];
+    };
+    stage_load(0);
+    stage_write(0);
+
+    const int64_t tiles_per_chunk = (a.N + 31) / 32;
+    const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
+    const int64_t per_round = (int64_t)gridDim.x * 4;
+    const int64_t rounds = (n_tiles + per_round - 1) / per_round;  // block-uniform: every wave reaches every barrier
+    for (int64_t round = 0; round < rounds; ++round) {
+        asm volatile("" ::: "memory");  // as in k_mlp: keeps the LDS operand reads inside the loop
+        const int64_t gtile = round * per_round + (int64_t)blockIdx.x * 4 + wave;
+        const bool tile_ok = gtile < n_tiles;
+        const int64_t chunk = (tile_ok && a.n_chunks > 1) ? gtile / tiles_per_chunk : 0;
+        const int64_t tile = tile_ok ? gtile - chunk * tiles_per_chunk : 0;
+        const float* __restrict__ winc = a.win + chunk * (int64_t)K1 * a.N;
+        const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
+        const int64_t e = tile * 32 + col;
+        const bool valid = tile_ok && e < a.N && !(a.env_skip && a.env_skip[e < a.N ? e : 0]);
+        f32x16 acc1[NT];
+        if (round == 0) __syncthreads();  // W1 / W3 / biases staged (the W2 block has its own barrier below)
+        if constexpr (TW > 0) {
+            // the reference's window: the whole observation of the tile is in flight before the first MFMA (k_mlp's
+            // prefetch; the run-time-T loop below waits for one load per k-step)
+            constexpr int KS = (15 * (TW ? TW : 1) + 1) / 2;
+            float xs[KS];
+            uint32_t N32 = (uint32_t)a.N;
+            int hsel = half;
+            asm volatile("" : "+s"(N32), "+v"(hsel));
+            const uint32_t e32 = (uint32_t)(valid ? e : a.N - 1);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k0 = 2 * s, k1 = 2 * s + 1;
+                int sl0 = a.head + k0 / 15, sl1 = a.head + k1 / 15;
+                if (sl0 >= TW) sl0 -= TW;
+                if (sl1 >= TW) sl1 -= TW;
+                const uint32_t r0 = (uint32_t)(sl0 * 15 + k0 % 15);
+                const uint32_t r1 = k1 < 15 * TW ? (uint32_t)(sl1 * 15 + k1 % 15) : r0;
+                float x = winc[(hsel ? r1 : r0) * N32 + e32];
+                if (k1 >= 15 * TW) x = hsel ? 0.f : x;
+                xs[s] = x;
+            }
+            if (a.obs_store && valid) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const uint32_t k = (uint32_t)(2 * s + half);
+                    if (2 * s + 1 < 15 * TW || half == 0) a.obs_store[k * N32 + e32] = xs[s];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[(2 * s + half) * H + 32 * t + col], xs[s], acc1[t], 0, 0, 0);
+                    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+        for (int s = 0; s < K1P / 2; ++s) {
+            const int k = 2 * s + half;
+            float x = 0.f;
+            if (valid && k < K1) {
+                int slice = a.head + k / 15;
+                if (slice >= a.T) slice -= a.T;
+                x = winc[(int64_t)(slice * 15 + k % 15) * a.N + e];
+                if (a.obs_store) a.obs_store[(int64_t)k * a.N + e] = x;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1t[k * H + 32 * t + col], x, acc1[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
+        }
+        f32x16 acc3;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc3[j] = b3s[acc_row(j, half)];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            constexpr int dummy = 0; (void)dummy;
+            const int buf = NBUF == 2 ? (t & 1) : 0;
+            __syncthreads();  // block t is in LDS; nobody still reads the buffer block t + 1 goes to
+            if constexpr (NBUF == 2) stage_load((t + 1) % NT);
+            f32x16 acc2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+            const float* wrow = W2s + buf * TILE_WORDS + col * PITCH;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32 * ti + acc_row(j, half)], acc1[ti][j], acc2, 0, 0, 0);
+                    if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh(acc2[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float w3 = col < 4 ? W3t[(32 * t + acc_row(j, half)) * 4 + col] : 0.f;
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3, acc2[j], acc3, 0, 0, 0);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (NBUF == 2) {
+                stage_write((t + 1) & 1);
+            } else {
+                __syncthreads();  // every wave is done with block t
+                stage_load((t + 1) % NT);
+                stage_write(0);
+            }
+        }
+        float outv[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = acc3[o];
+            if (a.final_tanh) v = tanhf(v);
+            outv[o] = v;
+            if (valid && half == 0 && o < a.n_out && a.out) {
+                if (a.out_f64) ((double*)a.out)[out_off + (int64_t)o * a.N + e] = (double)v;
+                else ((float*)a.out)[out_off + (int64_t)o * a.N + e] = v;
+            }
+        }
+        if constexpr (SAMPLE) {
+            if (valid && half == 0) sample_store(a, e, outv);
+        }
+    }
+}
+
+template <int H, int TW, bool SAMPLE> static int launch_mlp_wide(const MlpArgs& a, int T, hipStream_t stream, bool& fits) {
+    const int K1P = (15 * T + 1) & ~1;
+    const size_t fixed = sizeof(float) * ((size_t)K1P * H + 4 * H + 2 * H + 32), blockb = sizeof(float) * 32 * (H + 1);
+    const int nbuf = fixed + 2 * blockb <= 160 * 1024 ? 2 : (fixed + blockb <= 160 * 1024 ? 1 : 0);
+    fits = nbuf > 0 && (TW == 0 || (int64_t)15 * TW * a.N < ((int64_t)1 << 31));
+    if (!fits) return QENV_OK;
+    const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
+    int64_t blocks = (n_tiles + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    const size_t lds = fixed + nbuf * blockb;
+    const void* fn = nbuf == 2 ? (const void*)k_mlp_wide<H, TW, 2, SAMPLE> : (const void*)k_mlp_wide<H, TW, 1, SAMPLE>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_wide)");
+    if (nbuf == 2) hipLaunchKernelGGL((k_mlp_wide<H, TW, 2, SAMPLE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((k_mlp_wide<H, TW, 1, SAMPLE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return check_launch("k_mlp_wide");
+}
+
 // tiles (32 envs) up to which the split kernel is used: measured crossover (tools/time_mlp_sizes.py)
 #ifndef QENV_MLP_SMALL_TILES
 #define QENV_MLP_SMALL_TILES 512
@@ -690,6 +903,18 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
     hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
     return check_launch("k_mlp");
+}
+
+// N = 256: the LDS-staged wide kernel whenever W1 and one W2 block fit (T <= 8); QENV_MLP_WIDE=0 keeps the kernel it
+// replaced (W2 read from global memory inside the MFMA chain) for A/B runs
+template <bool SAMPLE> static int launch_mlp_256(const MlpArgs& a, int T, hipStream_t stream) {
+    static const int wide = getenv("QENV_MLP_WIDE") ? atoi(getenv("QENV_MLP_WIDE")) : 1;
+    if (wide && !a.list_idx) {
+        bool fits = false;
+        const int rc = T == 5 ? launch_mlp_wide<256, 5, SAMPLE>(a, T, stream, fits) : launch_mlp_wide<256, 0, SAMPLE>(a, T, stream, fits);
+        if (fits) return rc;
+    }
+    return launch_mlp<256, 0, 256, false, SAMPLE>(a, T, stream);
 }
 
 // ---- dense tail of rl_nn_model.py: K -> H -> H -> n_out with K too large for LDS-resident W1 ------
@@ -1276,7 +1501,7 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
         case 32: return t5 ? launch_mlp<32, 5, 512, true>(a, 5, q->stream) : launch_mlp<32, 0, 512, true>(a, q->cfg.T, q->stream);
         case 64: return t5 ? launch_mlp<64, 5, 512, true>(a, 5, q->stream) : launch_mlp<64, 0, 512, true>(a, q->cfg.T, q->stream);
         case 128: return t5 ? launch_mlp<128, 5, 512, true>(a, 5, q->stream) : launch_mlp<128, 0, 512, true>(a, q->cfg.T, q->stream);
-        case 256: return launch_mlp<256, 0, 256, false>(a, q->cfg.T, q->stream);
+        case 256: return launch_mlp_256<false>(a, q->cfg.T, q->stream);
         default: return fail(QENV_ERR_ARG, "qenv_mlp_forward: hidden must be one of 16, 32, 64, 128, 256");
     }
 }
@@ -1313,7 +1538,7 @@ int qenv::policy_act_subset(qenv_s* q, int hidden, const float* W1, const float*
         case 32: return t5 ? launch_mlp<32, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<32, 0, 512, true, true>(a, q->cfg.T, q->stream);
         case 64: return t5 ? launch_mlp<64, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<64, 0, 512, true, true>(a, q->cfg.T, q->stream);
         case 128: return t5 ? launch_mlp<128, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<128, 0, 512, true, true>(a, q->cfg.T, q->stream);
-        case 256: return launch_mlp<256, 0, 256, false, true>(a, q->cfg.T, q->stream);
+        case 256: return launch_mlp_256<true>(a, q->cfg.T, q->stream);
         default: return fail(QENV_ERR_ARG, "qenv_policy_act: hidden must be one of 16, 32, 64, 128, 256");
     }
 }
