@@ -45,7 +45,7 @@ class QenvError(RuntimeError):
 
 
 class PpoStepArgs(C.Structure):  # qenv_ppo_step_args (include/qenv.h)
-    _fields_ = [("hidden", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3")] + \
+    _fields_ = [("k_in", C.c_int32), ("hidden", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3")] + \
                [("std", C.c_double), ("noise", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_uint64), ("env_offset", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("out_mean", "out_action", "out_logprob", "obs_store", "out_reward", "out_done", "out_mask")]
 
@@ -70,7 +70,7 @@ SYMBOLS = {
     "qenv_pid_reset": (_i, [_vp, _vp]),
     "qenv_pidpos_action": (_i, [_vp, _dptr, _vp]),
     "qenv_window_push": (_i, [_vp, _vp, _vp, _i]),
-    "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sensor_reset": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _dptr]),
     "qenv_sensor_read": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _dptr, _vp]),
     "qenv_sensor_ops": (_i, [_vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, _dptr, _vp]),
@@ -79,7 +79,7 @@ SYMBOLS = {
     "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_dense_tail_chunks": (_i, [_i64, C.c_int32, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
-    "qenv_policy_act": (_i, [_vp, _i] + [_vp] * 6 + [C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp]),
+    "qenv_policy_act": (_i, [_vp, _i, _i] + [_vp] * 6 + [C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_reset_sampled": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i]),
     "qenv_ppo_step": (_i, [_vp, _vp]),

@@ -267,7 +267,7 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     const int32_t* list = q->wsi + (cur ? IROW_IDX2 : IROW_IDX) * N;
     const int32_t* list_n = q->counters + cur;
     auto act = [&](const uint8_t* skip, const int32_t* li, const int32_t* ln) {
-        return policy_act_subset(q, p->hidden, p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->std, p->noise, p->seed, p->step,
+        return policy_act_subset(q, p->k_in, p->hidden, p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->std, p->noise, p->seed, p->step,
                                  p->env_offset, p->out_mean, p->out_action, p->out_logprob, p->obs_store, skip, li, ln);
     };
     auto step = [&](const uint8_t* skip, const int32_t* li, const int32_t* ln) {

@@ -140,7 +140,7 @@ int ppo_flush(qenv_s* q);
 // qenv_ppo.hip: qenv_policy_act on a subset of the envs (the overlapped PPO step of qenv_env.hip): either every env whose
 // byte in env_skip is 0 (the others are computed with their tile but nothing of theirs is stored), or the envs of a
 // compacted list (list_idx[0 .. *list_count), gathered into dense 32-env tiles by the tile-per-workgroup kernel)
-int policy_act_subset(qenv_s* q, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+int policy_act_subset(qenv_s* q, int k_in, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                       const float* b3, double std, const void* noise, uint64_t seed, uint64_t step, int64_t env_offset,
                       void* out_mean, void* out_action, void* out_logprob, float* obs_store, const uint8_t* env_skip,
                       const int32_t* list_idx, const int32_t* list_count);

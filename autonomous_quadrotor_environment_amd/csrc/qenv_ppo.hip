@@ -1484,11 +1484,12 @@ int qenv_window_push(qenv_t q, const void* obs, const void* actions, int reset_f
     return check_launch("k_window_push");
 }
 
-int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const float* W1, const float* b1, const float* W2,
+int qenv_mlp_forward(qenv_t q, int k_in, int hidden, int n_out, int final_tanh, const float* W1, const float* b1, const float* W2,
                      const float* b2, const float* W3, const float* b3, void* out, float* obs_store) {
     if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_mlp_forward: null argument");
     if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
     if (n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_forward: n_out must be 1..4");
+    if (k_in != 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_mlp_forward: k_in (row length of W1) must be 15*T of the handle");
     MlpArgs a{};
     a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = n_out; a.final_tanh = final_tanh;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
@@ -1506,23 +1507,24 @@ int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const floa
     }
 }
 
-int qenv_policy_act(qenv_t q, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+int qenv_policy_act(qenv_t q, int k_in, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                     const float* b3, double std, const void* noise, uint64_t seed, uint64_t step, int64_t env_offset,
                     void* out_mean, void* out_action, void* out_logprob, float* obs_store) {
     if (q && q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
-    return qenv::policy_act_subset(q, hidden, W1, b1, W2, b2, W3, b3, std, noise, seed, step, env_offset, out_mean, out_action,
+    return qenv::policy_act_subset(q, k_in, hidden, W1, b1, W2, b2, W3, b3, std, noise, seed, step, env_offset, out_mean, out_action,
                                    out_logprob, obs_store, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"
 
 // qenv_policy_act on a subset of the envs (see qenv_host.hpp): the overlapped PPO step of qenv_env.hip
-int qenv::policy_act_subset(qenv_s* q, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
+int qenv::policy_act_subset(qenv_s* q, int k_in, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, double std, const void* noise, uint64_t seed, uint64_t step,
                             int64_t env_offset, void* out_mean, void* out_action, void* out_logprob, float* obs_store,
                             const uint8_t* env_skip, const int32_t* list_idx, const int32_t* list_count) {
     if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out_action) return fail(QENV_ERR_ARG, "qenv_policy_act: null argument");
     if (!(std > 0)) return fail(QENV_ERR_ARG, "qenv_policy_act: std must be positive");
+    if (k_in != 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_policy_act: k_in (row length of W1) must be 15*T of the handle");
     MlpArgs a{};
     a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = 4; a.final_tanh = 1;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out_mean;

@@ -382,7 +382,7 @@ class BatchedQuad:
         self._check_buf(out, n_out, "out")
         self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
         self._bind()
-        L.check(L.lib.qenv_mlp_forward(self._h, W1.shape[0], n_out, int(head == "actor"), L.ptr(W1), L.ptr(b1),
+        L.check(L.lib.qenv_mlp_forward(self._h, W1.shape[1], W1.shape[0], n_out, int(head == "actor"), L.ptr(W1), L.ptr(b1),
                                        L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), L.ptr(obs_store)),
                 "qenv_mlp_forward")
         return out
@@ -399,7 +399,7 @@ class BatchedQuad:
             self._check_buf(t, 4, nm)
         self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
         self._bind()
-        L.check(L.lib.qenv_policy_act(self._h, W1.shape[0], L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3),
+        L.check(L.lib.qenv_policy_act(self._h, W1.shape[1], W1.shape[0], L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3),
                                       float(weights.std), L.ptr(nz), int(seed), int(step), int(env_offset), L.ptr(mean),
                                       L.ptr(out), L.ptr(logprob), L.ptr(obs_store)), "qenv_policy_act")
         return out
@@ -419,7 +419,7 @@ class BatchedQuad:
         for t, nm in ((reward, "reward"), (mask, "mask")):
             self._check_buf(t, 0, nm)
         nz = None if noise is None else self._as_rows(noise, 4, "noise")
-        a = L.PpoStepArgs(int(W[0].shape[0]), *[t.data_ptr() for t in W], float(weights.std),
+        a = L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[t.data_ptr() for t in W], float(weights.std),
                           None if nz is None else nz.data_ptr(), int(seed), int(step), int(env_offset),
                           None if mean is None else mean.data_ptr(), actions.data_ptr(),
                           None if logprob is None else logprob.data_ptr(), None if obs_store is None else obs_store.data_ptr(),

@@ -267,21 +267,28 @@ def timed_regions(run, per_call, steps, world, dev, min_seconds, max_regions=500
             return ts
 
 
-def kernel_launch_us(run, per_call, launch, reps=20):
-    """Average duration of ONE launch of the dominant kernel from HIP events on the launch stream
-    (the env launches on torch's current stream, so torch.cuda.Event brackets it).  launch='fused':
-    one event pair per launch.  launch='step': the kernels are a few microseconds long, less than
-    an event pair costs, so the pair brackets one hipGraph replay of `per_call` back-to-back
-    launches and the result is divided by per_call (it therefore includes the ~0.5 us dependent
-    launch boundary, which makes `achieved` conservative)."""
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+def kernel_launch_us(run, per_call, launch, reps=8):
+    """Average duration of ONE launch of the dominant kernel from HIP events on the launch stream (the env launches on
+    torch's current stream, so torch.cuda.Event brackets it).  An event pair costs more than a short kernel (its two
+    marker packets added ~20 us to a 70 us launch when every launch had its own pair), so one pair brackets a train of
+    back-to-back launches -- at least 2 ms of them -- and the elapsed time is divided by the number of launches: the
+    average launch duration in the steady state, including the dependent launch boundary (~1 us), which makes
+    `achieved` conservative; rocprofv3 --kernel-trace of the same command gives the same figure (profiles/).
+    launch='step': `run` is one hipGraph replay of `per_call` launches, the result is divided by per_call as well."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    for a, b in evs:
+    a.record(); run(); b.record()
+    torch.cuda.synchronize()
+    train = int(min(2000, max(4, np.ceil(2000.0 / max(a.elapsed_time(b) * 1e3, 1.0)))))
+    ts = []
+    for _ in range(reps):
         a.record()
-        run()
+        for _ in range(train):
+            run()
         b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / train)
+    ts.sort()
     us = float(np.mean(ts[: max(1, len(ts) * 3 // 4)]))  # drop the slowest quarter (clock ramps, interrupts)
     return us if launch == "fused" else us / per_call
 
@@ -377,18 +384,23 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
                             "issue_frac": spw * v["valu_per_wave_step"] * v["active_valu_cycles_per_inst"] / (1024 * v["clock_ghz"] * 1e9)}
     if ppo:  # the dominant kernel of the PPO workloads is the fp32-MFMA MLP forward
         heads = 2 if controller == "ppo_rollout" else 1
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        torch.cuda.synchronize()
-        for a_, b_ in evs:
-            a_.record(); env.mlp_forward(ro.w, "actor", out=ro.mean); b_.record()
-        torch.cuda.synchronize()
-        ts = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in evs)
-        mlp_us = float(np.mean(ts[:15]))
+        mlp_us = kernel_launch_us(lambda: env.mlp_forward(ro.w, "actor", out=ro.mean), 1, "fused")
         tfl = MLP_FLOPS * (hi - lo) / (mlp_us * 1e-6) / 1e12
         roofline = {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tfl / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "k_mlp<128,5> (actor forward)",
                     "kernel_us": mlp_us, "flops_per_launch": MLP_FLOPS * (hi - lo), "mlp_forwards_per_env_step": heads,
-                    "hbm_algorithmic_GBps_whole_step": bytes_per_step * value / world / 1e9}
+                    "hbm_algorithmic_GBps_whole_step": bytes_per_step * value / world / 1e9,
+                    "achieved_is": "algorithmic fp32 flops (53.0 kflop per env) / launch time against the fp32-MFMA peak; "
+                                   "layers 1 and 2 execute as 6 bf16 MFMA products of 3-way split operands (fp32-accurate, "
+                                   "see `executed`), so this fraction may exceed what an fp32-MFMA kernel could reach",
+                    "executed": {
+                        # per 32-env tile: layer 1 4x5x6 + layer 2 4x4x2x6 v_mfma_f32_32x32x16_bf16 (32 cycles each),
+                        # layer 3 64 v_mfma_f32_32x32x2_f32 (64 cycles each)
+                        "bf16_tflops": 6 * 2 * (128 * 80 + 128 * 128) * (hi - lo) / (mlp_us * 1e-6) / 1e12,
+                        "bf16_dense_peak_tflops": 2516.0,
+                        "mfma_cycles_per_tile": 120 * 32 + 192 * 32 + 64 * 64,
+                        "mfma_pipe_busy_frac_at_2.4GHz": ((hi - lo + 31) // 32) * (120 * 32 + 192 * 32 + 64 * 64)
+                                                          / (1024 * 2.4e9 * mlp_us * 1e-6)}}
     res = {"value": value, "ms_per_step": secs / steps * 1e3, "regions": len(regions),
            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3,
            "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,

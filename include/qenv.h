@@ -224,10 +224,11 @@ int qenv_window_push(qenv_t q, const void *obs, const void *actions, int reset_f
 /* Replaces ActorCritic.actor / .critic forward (environment/controller/model.py:27-42):
  * y = [tanh](W3 tanh(W2 tanh(W1 x + b1) + b2) + b3) on the observation ring, fp32
  * MFMA.  Weights: float32 device, row-major [out][in] exactly as torch's nn.Linear
- * (W1 [H][15*T], W2 [H][H], W3 [n_out][H]); H in {16,32,64,128,256}; n_out <= 4.
- * out [n_out][N] in the handle's dtype.  obs_store nullable float32 [15*T][N]: the window in
+ * (W1 [H][k_in], W2 [H][H], W3 [n_out][H]); H in {16,32,64,128,256}; n_out <= 4; k_in = the row length of W1 as the
+ * caller allocated it, which must be the handle's 15*T (QENV_ERR_ARG otherwise: a weight set built for another window
+ * would be read out of bounds or mis-strided).  out [n_out][N] in the handle's dtype.  obs_store nullable float32 [15*T][N]: the window in
  * time order, as read by the first layer (the `states` a PPO rollout keeps, ppo.py:250). */
-int qenv_mlp_forward(qenv_t q, int hidden, int n_out, int final_tanh, const float *W1,
+int qenv_mlp_forward(qenv_t q, int k_in, int hidden, int n_out, int final_tanh, const float *W1,
                      const float *b1, const float *W2, const float *b2, const float *W3,
                      const float *b3, void *out, float *obs_store);
 
@@ -295,8 +296,8 @@ int qenv_sample_action(qenv_t q, const void *mean, double std, const void *noise
 /* ActorCritic.act in ONE launch (model.py:52-72): qenv_mlp_forward of the actor (75-H-H-4, tanh) with
  * qenv_sample_action in its epilogue -- the same means, the same Philox streams / injected noise, the same
  * arithmetic, bit-identical actions and log-probs.  out_mean nullable [4][N]; out_action [4][N]; out_logprob
- * nullable [4][N]; obs_store as in qenv_mlp_forward; arrays other than obs_store in the handle's dtype. */
-int qenv_policy_act(qenv_t q, int hidden, const float *W1, const float *b1, const float *W2, const float *b2,
+ * nullable [4][N]; k_in and obs_store as in qenv_mlp_forward; arrays other than obs_store in the handle's dtype. */
+int qenv_policy_act(qenv_t q, int k_in, int hidden, const float *W1, const float *b1, const float *W2, const float *b2,
                     const float *W3, const float *b3, double std, const void *noise, uint64_t seed,
                     uint64_t step, int64_t env_offset, void *out_mean, void *out_action, void *out_logprob,
                     float *obs_store);
@@ -328,7 +329,7 @@ int qenv_reset_sampled(qenv_t q, uint64_t seed, uint64_t episode, int64_t env_of
  * and loses when many do; without it the same launches run in sequence on the handle's stream.
  * Arrays as in qenv_policy_act / qenv_step: out_mean, out_logprob, obs_store, out_mask, noise nullable. */
 typedef struct {
-    int32_t hidden;
+    int32_t k_in, hidden;                       /* W1 is [hidden][k_in], k_in = 15*T of the handle */
     const float *W1, *b1, *W2, *b2, *W3, *b3;   /* actor, torch layout */
     double std;
     const void *noise;                          /* null = Philox */

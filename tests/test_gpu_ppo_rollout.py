@@ -661,3 +661,27 @@ def test_ppo_step_fused_call_is_bit_identical(overlap):
                            env=dict(os.environ, QENV_PPO_OVERLAP=overlap), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
         assert '"mismatches": []' in r.stdout
+
+
+@pytest.mark.gpu
+def test_weights_of_another_window_are_refused(aq):
+    """A weight set built for T = 5 (75 inputs) on a T = 3 handle would be mis-strided by the kernels: the host mirror
+    refuses it by shape, and the C-ABI itself by k_in (the row length of W1 the caller passes)."""
+    import torch
+    from autonomous_quadrotor_environment_amd import _lib as L
+    env = aq.BatchedQuad(64, 0.01, 100, training=True, direct_control=1, T=3)
+    env.reset(env.sample_init_states(0, 0, 0), return_history=False, push_window=True)
+    w75 = aq.ActorCriticWeights.random(64, 75, 4, device="cuda", seed=0)
+    with pytest.raises(ValueError, match="T=3"):
+        env.mlp_forward(w75, "actor")
+    with pytest.raises(ValueError, match="T=3"):
+        env.policy_act(w75)
+    W = w75.head("actor")
+    out = torch.empty(4, 64, device="cuda")
+    env._bind()
+    rc = L.lib.qenv_mlp_forward(env._h, 75, 64, 4, 1, *[L.ptr(t) for t in W], L.ptr(out), None)
+    assert rc == -1 and b"k_in" in L.lib.qenv_last_error()
+    rc = L.lib.qenv_policy_act(env._h, 75, 64, *[L.ptr(t) for t in W], 0.1, None, 0, 0, 0, None, L.ptr(out), None, None)
+    assert rc == -1 and b"k_in" in L.lib.qenv_last_error()
+    w45 = aq.ActorCriticWeights.random(64, 45, 4, device="cuda", seed=0)
+    assert torch.isfinite(env.mlp_forward(w45, "actor")).all()

@@ -22,7 +22,7 @@ for case in range(n_cases):
     n_max = int(rng.choice([40, 1000]))
     N, S = 12, int(rng.choice([30, 80]))
     kw = dict(training=training, direct_control=0, T=T, clipped=clipped, variant=variant, integrator=integ)
-    env = aq.BatchedQuad(N, 0.01, n_max, dtype=torch.float64, **kw)
+    env = aq.BatchedQuad(N, 0.01, n_max, dtype=torch.float64, compute=({"lean": "lean"}.get(os.environ.get("QENV_FUZZ_HANDLE", "f64"))), **kw)
     x0 = aq.random_init_states(rng, N, variant) * rng.choice([0.1, 0.5])
     x0[:, 6:10] /= np.linalg.norm(x0[:, 6:10], axis=1, keepdims=True)
     env.reset(x0.T.copy())
@@ -80,5 +80,5 @@ for case in range(n_cases):
     worst = max(worst, err); bad += 0 if ok else 1
     print(json.dumps(dict(case=case, ctrl=ctrl, integ=integ, variant=variant, clipped=clipped, training=training, T=T, n_max=n_max,
                           S=S, err=float(err), oracle_self_divergence_1e13=float(sens), flags_ok=bool(flags_ok), ok=bool(ok))), flush=True)
-print(json.dumps(dict(cases=n_cases, mismatching=bad, worst_scaled_err=float(worst))))
+print(json.dumps(dict(handle=os.environ.get("QENV_FUZZ_HANDLE", "f64"), cases=n_cases, mismatching=bad, worst_scaled_err=float(worst))))
 sys.exit(1 if bad else 0)

@@ -19,7 +19,7 @@ for case in range(n_cases):
     integ = ["rk45", "dp5", "rk4"][rng.randint(3)]
     N, S, T = 8, int(rng.choice([20, 60])), 5
     kw = dict(training=False, direct_control=1, T=T, integrator=integ)
-    env = aq.BatchedQuad(N, 0.01, 100000, dtype=torch.float64, **kw)
+    env = aq.BatchedQuad(N, 0.01, 100000, dtype=torch.float64, compute=({"lean": "lean"}.get(os.environ.get("QENV_FUZZ_HANDLE", "f64"))), **kw)
     x0 = aq.random_init_states(rng, N) * 0.3
     x0[:, 6:10] /= np.linalg.norm(x0[:, 6:10], axis=1, keepdims=True)
     n_rows = int(rng.choice([S // 2, S + 5]))  # shorter than the run: the last row is held
@@ -63,5 +63,5 @@ for case in range(n_cases):
     ok = err < 1e-6  # float32 observations of values up to ~10: 5e-7
     worst = max(worst, err); bad += 0 if ok else 1
     print(json.dumps(dict(case=case, kind=kind, integ=integ, S=S, rows=n_rows, gains=gains, err=err, ok=bool(ok))), flush=True)
-print(json.dumps(dict(cases=n_cases, mismatching=bad, worst_err=float(worst))))
+print(json.dumps(dict(handle=os.environ.get("QENV_FUZZ_HANDLE", "f64"), cases=n_cases, mismatching=bad, worst_err=float(worst))))
 sys.exit(1 if bad else 0)

@@ -24,7 +24,7 @@ for case in range(n_cases):
     n_max = int(rng.choice([8, 30, 1000]))
     N, S = 24, int(rng.choice([12, 40]))
     kw = dict(training=training, direct_control=direct, T=T, clipped=clipped, variant=variant, integrator=integ)
-    env = aq.BatchedQuad(N, t_step, n_max, dtype=torch.float64, **kw)
+    env = aq.BatchedQuad(N, t_step, n_max, dtype=torch.float64, compute=({"lean": "lean"}.get(os.environ.get("QENV_FUZZ_HANDLE", "f64"))), **kw)
     refs = [O.OracleQuad(t_step, n_max, euler=0, **kw) for _ in range(N)]
     err, flags_ok = 0.0, True
     for ep in range(2):
@@ -53,5 +53,5 @@ for case in range(n_cases):
     worst = max(worst, err); bad += 0 if ok else 1
     print(json.dumps(dict(case=case, variant=variant, integ=integ, direct=direct, T=T, clipped=clipped, training=training,
                           t_step=t_step, n_max=n_max, err=float(err), flags_ok=flags_ok, ok=ok)), flush=True)
-print(json.dumps(dict(cases=n_cases, mismatching=bad, worst_scaled_err=float(worst))))
+print(json.dumps(dict(handle=os.environ.get("QENV_FUZZ_HANDLE", "f64"), cases=n_cases, mismatching=bad, worst_scaled_err=float(worst))))
 sys.exit(1 if bad else 0)

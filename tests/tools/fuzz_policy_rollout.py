@@ -23,7 +23,7 @@ for case in range(n_cases):
     kw = dict(training=training, direct_control=1, T=T, variant=variant, integrator=integ)
     w = aq.ActorCriticWeights.random(hidden, 75, 4, seed=int(rng.randint(1 << 30)))
     w.std = float(rng.choice([0.1, 0.6]))  # 0.6: saturating actions, envs leave the box
-    env = aq.BatchedQuad(N, 0.01, n_max, dtype=torch.float64, **kw)
+    env = aq.BatchedQuad(N, 0.01, n_max, dtype=torch.float64, compute=({"lean": "lean"}.get(os.environ.get("QENV_FUZZ_HANDLE", "f64"))), **kw)
     ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=int(rng.randint(1 << 30)), env_offset=int(rng.randint(1000)))
     ro.keep_init = True
     ro.start()
@@ -57,5 +57,5 @@ for case in range(n_cases):
     worst = max(worst, err); bad += 0 if ok else 1
     print(json.dumps(dict(case=case, variant=variant, integ=integ, training=training, n_max=n_max, hidden=hidden, H=H, std=w.std,
                           resets=int(eps.sum()), err=float(err), flags_ok=bool(flags_ok), ok=bool(ok))), flush=True)
-print(json.dumps(dict(cases=n_cases, mismatching=bad, worst_err=float(worst))))
+print(json.dumps(dict(handle=os.environ.get("QENV_FUZZ_HANDLE", "f64"), cases=n_cases, mismatching=bad, worst_err=float(worst))))
 sys.exit(1 if bad else 0)
