@@ -98,8 +98,8 @@ __device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const 
 // BF16L2: layer 2 (the H x H one: 54 % of the fp32 MFMA time at H = 128) on the bf16 matrix cores with every fp32
 // operand split into three bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits) and the six products that matter
 // (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid: everything down to 2^-24 of the product) accumulated in fp32 by
-// v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32 cycles per 16 k instead of 8 fp32 MFMAs of 64 cycles (tools/ubench), and --
-// unlike the fp32 MFMA, which executes on the vector FMA lanes -- they leave the VALU free for the tanh and the splits.
+// v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32 cycles per 16 k instead of 8 fp32 MFMAs of 64 cycles (tools/ubench): 192
+// matrix-pipe cycles instead of 512.  (Neither kind overlaps with another wave's VALU work on this chip: mfma_valu.hip.)
 // The accumulator tile is still the next operand without an LDS round trip: one 32x32x16 step contracts the 16 hidden
 // rows that registers 8 jh .. 8 jh + 7 of the two lane halves hold (MFMA k index 8 half + i  <->  row acc_row(8 jh + i, half)),
 // and the weights are staged in exactly that order, already split, as three 16-byte fragments per lane and step
