@@ -77,7 +77,10 @@ template <typename T, typename S = T> struct RolloutArgs {
     const int32_t* count;
     float* win;             // null, or the observation ring: step s also writes its slice to slot (win_head+s)%win_T
     int32_t win_head, win_T;
-    int32_t half_waves;     // 1: only lanes 0..31 of every wave carry an env (twice the waves: see launch_rollout)
+    int32_t lane_shift;     // 6: every lane of a wave carries an env; < 6: only lanes 0 .. 2^lane_shift - 1 do (more, emptier
+                            // waves: see launch_rollout)
+    int32_t list_min_shift; // list mode (idx): >= 0 spreads the list over the launched waves as thinly as they allow, with at
+                            // least 2^list_min_shift envs per wave; -1: dense (64 list entries per wave)
     LqrGains<T> lqr;
     PidGains<T> pid;
 };
@@ -362,13 +365,25 @@ template <typename T, typename S, int INTEG, int CTRL, bool ROBUST, bool LEAN = 
 __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T, S> a) {
     using M = typename MathSel<T, LEAN>::type;
     int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (a.half_waves) {
-        if (threadIdx.x & 32) return;
-        e = (int64_t)blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
+    if (a.lane_shift < 6) {
+        const int ln = threadIdx.x & 63;
+        if (ln >> a.lane_shift) return;
+        e = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << a.lane_shift) + ln;
     }
-    if (e >= a.N) return;
+    if (!a.idx && e >= a.N) return;
     if (a.idx) {
-        if (e >= *a.count) return;
+        const int64_t cnt = *a.count;  // <= N
+        if (a.list_min_shift >= 0) {
+            // the fewest envs per wave the launched waves allow: a wave runs every env step as many RK45 attempts as its
+            // slowest lane, and the SIMDs a short list leaves idle are free (see do_rollout)
+            const int64_t n_waves = (int64_t)gridDim.x * 4;
+            int sh = a.list_min_shift;
+            while (sh < 6 && (n_waves << sh) < cnt) ++sh;
+            const int ln = threadIdx.x & 63;
+            if (ln >> sh) return;
+            e = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << sh) + ln;
+        }
+        if (e >= cnt) return;
         e = a.idx[e];
     }
     const int64_t N = a.N;
@@ -987,7 +1002,7 @@ template <typename T, typename S, int INTEG, bool LEAN> static void launch_rollo
         // SIMD (N >= 131072), a loss below that, and no gain for rk45 or with a controller in the loop.
         // QENV_PACKED=0/1 overrides the rule.
         const bool auto_packed = q->packed < 0 && INTEG != INT_RK45 && controller == QENV_CTRL_CONST && q->N >= 131072;
-        if ((q->packed > 0 || auto_packed) && (q->N % 2) == 0 && !a.half_waves) {
+        if ((q->packed > 0 || auto_packed) && (q->N % 2) == 0 && a.lane_shift == 6) {
             const dim3 g2 = grid_for(q->N / 2), b2(256);
             switch (controller) {
                 case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_CONST>), g2, b2, 0, q->stream, a); break;
@@ -998,8 +1013,9 @@ template <typename T, typename S, int INTEG, bool LEAN> static void launch_rollo
             return;
         }
     }
-    if (a.half_waves) {
-        const dim3 gh((unsigned)((q->N + 127) / 128));
+    if (a.lane_shift < 6) {
+        const int64_t per_block = (int64_t)4 << a.lane_shift;
+        const dim3 gh((unsigned)((q->N + per_block - 1) / per_block));
         switch (controller) {
             case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST, false, LEAN>), gh, b, 0, q->stream, a); break;
             case QENV_CTRL_LQR: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_LQR, false, LEAN>), gh, b, 0, q->stream, a); break;
@@ -1020,11 +1036,26 @@ template <typename T, typename S, bool LEAN = false> int do_rollout(qenv_s* q, i
                                                        int pid_first, int flags, const void* target_table = nullptr) {
     RolloutArgs<T, S> a;
     a.target_table = (const S*)target_table;
-    a.idx = nullptr; a.count = nullptr; a.win = nullptr; a.win_head = 0; a.win_T = q->cfg.T;
-    a.half_waves = (getenv("QENV_HALF_WAVES") && atoi(getenv("QENV_HALF_WAVES")) && !q->robust) ? 1 : 0;
+    a.idx = nullptr; a.count = nullptr; a.win = nullptr; a.win_head = 0; a.win_T = q->cfg.T; a.list_min_shift = -1;
+    // QENV_HALF_WAVES=1 (experiment of DESIGN.md section 4g): 32 envs per wave everywhere -- 1.7x slower, the idle half is not skipped
+    a.lane_shift = (getenv("QENV_HALF_WAVES") && atoi(getenv("QENV_HALF_WAVES")) && !q->robust) ? 5 : 6;
     if (q->compact_valid) {  // called from a masked qenv_reset: warm-up of the reset envs only
         a.idx = q->wsi + (q->compact_valid == 2 ? IROW_IDX2 : IROW_IDX) * q->N; a.count = q->counters + q->count_used;
         if (q->warmup_push) { a.win = q->window; a.win_head = q->win_head; }
+        // The warm-up of a reset list is the latency of its slowest wavefront (a handful of waves on an otherwise idle
+        // chip), and a wave runs every env step as many RK45 attempts as its slowest lane -- fresh initial states need
+        // 2..6.  The kernel therefore spreads the list over the waves of the (unchanged) grid more thinly: 16 envs per wave
+        // unless the list needs more (tools/time_masked_reset.py, lean handle, 65 536 envs, 300 finished: 66 us dense,
+        // 58 us at 16 per wave; config 5 +9 %).  Measured limits: below 16 active lanes a wave gets SLOWER (4 or 1 env per
+        // wave: 100 us -- the kernel itself, rocprofv3), and a larger grid of mostly empty waves serialises behind the
+        // kernel's one-wave-per-SIMD register footprint (8 192 waves: +40 us).  QENV_WARMUP_LANES = minimum envs per
+        // wave (64 = the dense mapping).
+        if (!q->robust && a.lane_shift == 6) {
+            static const int lanes = getenv("QENV_WARMUP_LANES") ? atoi(getenv("QENV_WARMUP_LANES")) : 16;
+            int sh = 6;
+            while (sh > 0 && (1 << sh) > lanes) --sh;
+            a.list_min_shift = lanes >= 64 ? -1 : sh;
+        }
     }
     a.cfg = make_cfg<T>(q);
     a.gust = q->gust;

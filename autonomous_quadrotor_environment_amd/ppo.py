@@ -111,13 +111,15 @@ class dl_in_gen:
         return self.deep_learning_input
 
 
-def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministic=False):
+def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministic=False, return_stats=False):
     """PPO.get_advantages (ppo.py:125-141 ddof=0; ppo_trainer.py:133-148 ddof=1) on a
     time-major rollout: values [n+1, N], masks [n, N], rewards [n, N] device tensors.
     Returns (returns [n, N], normalised advantages [n, N]).  With `group`
     (torch.distributed) the normalisation moments are all-reduced so every shard uses the
     global mean/std, exactly like a single learner.  deterministic: the moments are summed in a fixed order instead
-    of with double-precision atomics."""
+    of with double-precision atomics.  return_stats (with normalize=False): also return the three float64 moment
+    sums [count, sum, sum of squares] of the raw advantages, for a caller that combines several shards before
+    `adv_normalize`."""
     n, N = rewards.shape
     assert values.shape == (n + 1, N) and masks.shape == (n, N)
     dt = L.F64 if values.dtype == torch.float64 else L.F32
@@ -134,12 +136,21 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministi
         L.check(L.lib.qenv_gae(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(ret), L.ptr(adv),
                                L.ptr(stats), stream), "qenv_gae")
     if not normalize:
-        return ret, adv
+        return (ret, adv, stats) if return_stats else (ret, adv)
     if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size(group) > 1:
         torch.distributed.all_reduce(stats, group=group)
     L.check(L.lib.qenv_adv_normalize(dt, n * N, L.ptr(adv), L.ptr(stats), int(ddof), stream), "qenv_adv_normalize")
     return ret, adv
+
+
+def adv_normalize(adv, stats, ddof=0):
+    """(adv - mean) / (std + 1e-5) in place from the float64 moment sums `gae(..., normalize=False, return_stats=True)`
+    returned (summed over shards / all-reduced over ranks by the caller): ppo.py:139, ppo_trainer.py:146."""
+    dt = L.F64 if adv.dtype == torch.float64 else L.F32
+    L.check(L.lib.qenv_adv_normalize(dt, adv.numel(), L.ptr(adv), L.ptr(stats), int(ddof), _stream(adv.device)),
+            "qenv_adv_normalize")
+    return adv
 
 
 def dense_tail(x, weights, final_tanh=True, out=None):
@@ -532,9 +543,9 @@ class PolicyRollout:
             self.values[:n].copy_(out)
         return self.values[:n]
 
-    def finish(self, ddof=0, group=False, bootstrap=False, deterministic=False):
+    def finish(self, ddof=0, group=False, bootstrap=False, deterministic=False, normalize=True, return_stats=False):
         """GAE over the collected steps.  bootstrap=False appends V=0 like the reference
-        (ppo.py:385); True evaluates the critic on the final window."""
+        (ppo.py:385); True evaluates the critic on the final window.  normalize / return_stats: as `gae`."""
         n = self.t
         self.env.ppo_flush()  # the envs that finished in the last step: their warm-up before anything reads the env
         if self.batched_critic and n:
@@ -543,4 +554,79 @@ class PolicyRollout:
             self.env.mlp_forward(self.w, "critic", out=self.values[n:n + 1])
         else:
             self.values[n].zero_()
-        return gae(self.values[:n + 1], self.masks[:n], self.rewards[:n], ddof=ddof, group=group, deterministic=deterministic)
+        return gae(self.values[:n + 1], self.masks[:n], self.rewards[:n], ddof=ddof, group=group, deterministic=deterministic,
+                   normalize=normalize, return_stats=return_stats)
+
+
+class StreamShardedRollout:
+    """One GPU's env range collected as S independent shards on S HIP streams (each shard its own env handle and
+    `PolicyRollout`).  The rollout step of a shard ends in the latency-bound warm-up of its finished envs -- a handful of
+    wavefronts for ~60 us -- during which a single batch leaves the chip idle; with two shards of half the size the other
+    shard's policy forward and env step run meanwhile (their workgroups cover half the CUs each): 137 -> 118 us per step
+    at 65 536 envs (tools/time_rollout_shards.py; four shards lose again to launch overhead).  Env trajectories, Philox
+    streams and rollout buffers are shard-invariant (keyed by the global env index), so the union of the shards is the
+    single-batch run bit for bit; GAE's normalisation moments are summed over the shards (and all-reduced over `group`)
+    before any shard normalises, so the advantages are those of one learner over the whole range.
+
+    make_env(lo, hi) -> BatchedQuad for the local env range [lo, hi) (already reset if the caller wants its own
+    initial states; otherwise call start())."""
+
+    def __init__(self, make_env, n_envs, weights, horizon, shards=2, seed=0, env_offset=0, device=None, **kw):
+        self.n_envs, self.shards = int(n_envs), int(shards)
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.shards)]
+        self.bounds = [(k * self.n_envs // self.shards, (k + 1) * self.n_envs // self.shards) for k in range(self.shards)]
+        self.ros = []
+        main = torch.cuda.current_stream(dev)
+        for st, (lo, hi) in zip(self.streams, self.bounds):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self.ros.append(PolicyRollout(make_env(lo, hi), weights, horizon, seed=seed, env_offset=env_offset + lo, **kw))
+        self.w = weights
+        self._stats = torch.zeros(3, dtype=torch.float64, device=dev)
+
+    @property
+    def t(self):
+        return self.ros[0].t
+
+    @t.setter
+    def t(self, v):
+        for ro in self.ros:
+            ro.t = v
+
+    def start(self):
+        for st, ro in zip(self.streams, self.ros):
+            with torch.cuda.stream(st):
+                ro.start()
+
+    def step(self, deterministic=False):
+        for st, ro in zip(self.streams, self.ros):
+            with torch.cuda.stream(st):
+                ro.step(deterministic=deterministic)
+
+    def finish(self, ddof=0, group=None, bootstrap=False, deterministic=False):
+        """Per shard: pending warm-ups, critic over the horizon, GAE; then ONE normalisation over all shards (and ranks).
+        Returns [(returns, advantages)] per shard, valid on the caller's current stream."""
+        main = torch.cuda.current_stream(self.device)
+        outs = []
+        for st, ro in zip(self.streams, self.ros):
+            with torch.cuda.stream(st):
+                outs.append(ro.finish(ddof=ddof, group=False, bootstrap=bootstrap, deterministic=deterministic,
+                                      normalize=False, return_stats=True))
+            main.wait_stream(st)
+        torch.sum(torch.stack([o[2] for o in outs]), dim=0, out=self._stats)
+        if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size(group) > 1:
+            torch.distributed.all_reduce(self._stats, group=group)
+        for o in outs:
+            adv_normalize(o[1], self._stats, ddof)
+        return [(o[0], o[1]) for o in outs]
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def last_returns(self):
+        """The banked return of every env's last finished episode, local env order (for the all-gather)."""
+        return torch.cat([ro.env.last_return for ro in self.ros])

@@ -55,7 +55,7 @@ WORKLOADS = {
                 "BASELINE configs[2]: 262144 envs/GPU, LQR inner loop, random init, full step"),
     # PPO workloads: controller names select the runner below; bytes from SURVEY.md section 8d
     "config4": (131072, 1, "ppo_actor", 2, BYTES_FULL + 360, "lean",
-                "BASELINE configs[3]: 131072 envs/GPU (1048576 on 8), PPO actor MLP 75-128-128-4 (fp32 MFMA) in the "
+                "BASELINE configs[3]: 131072 envs/GPU (1048576 on 8), PPO actor MLP 75-128-128-4 (matrix cores, fp32-accurate) in the "
                 "loop, T=5 window, deterministic mean action, random init"),
     "config5": (65536, 1, "ppo_rollout", 2, BYTES_FULL + 360 + 332 + 20, "lean",
                 "BASELINE configs[4]: 65536 envs/GPU (524288 on 8), full PPO rollout (actor+critic, Normal(mean,0.1) "
@@ -89,6 +89,8 @@ def parse(argv=None):
     p.add_argument("--chunk", type=int, default=0, help="env steps per graph replay / fused launch "
                    "(0 = the largest divisor of --steps up to 250)")
     p.add_argument("--no-graph", action="store_true", help="launch=step: eager launches instead of hipGraph replay")
+    p.add_argument("--stream-shards", type=int, default=2,
+                   help="config5: the rank's env range as this many shards on their own HIP streams (1 = one batch)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--extras", action="store_true", help="also time the other integrators / launch modes")
@@ -159,11 +161,13 @@ def build_env(workload, handle, integrator, n_global, lo, hi, dev):
     return env
 
 
-def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_global):
+def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_global, shards=1, make_env=None, n_local=0,
+                    dev=None):
     """config 4 / 5: the rollout collector of ppo.py:223-269 on the device."""
     from autonomous_quadrotor_environment_amd import ActorCriticWeights, PolicyRollout
     from autonomous_quadrotor_environment_amd.distributed import all_gather_returns
-    w = ActorCriticWeights.random(128, 75, 4, device=env.device, seed=1)  # random-init weights of the reference's shape
+    dev = env.device if env is not None else dev
+    w = ActorCriticWeights.random(128, 75, 4, device=dev, seed=1)  # random-init weights of the reference's shape
     w.std = 0.1
     if controller == "ppo_actor":
         ro = PolicyRollout(env, ActorCriticWeights(w.actor, None, env.device), chunk)
@@ -185,6 +189,18 @@ def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_globa
         with torch.cuda.graph(graph, stream=side):
             body()
         return graph.replay, chunk, ro
+    if shards > 1:  # the rank's range as independent shards on their own streams (StreamShardedRollout's docstring)
+        from autonomous_quadrotor_environment_amd import StreamShardedRollout
+        sro = StreamShardedRollout(make_env, n_local, w, chunk, shards=shards, seed=seed, env_offset=env_offset, device=dev,
+                                   store_obs=True, auto_reset=True)
+
+        def sharded_body():
+            sro.t = 0
+            for _ in range(chunk):
+                sro.step()
+            sro.finish(ddof=0, group=None)
+            all_gather_returns(sro.last_returns(), n_global)
+        return sharded_body, chunk, sro
     ro = PolicyRollout(env, w, chunk, store_obs=True, auto_reset=True, seed=seed, env_offset=env_offset)
 
     def body():  # one horizon: rollout, GAE (global normalisation), episode returns all-gathered over RCCL
@@ -307,7 +323,7 @@ def pick(total, cap, mult=1):
 
 
 def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_graph, envs, rank, world, dev,
-            min_seconds):
+            min_seconds, stream_shards=1):
     """One workload on this rank's shard: W untimed warm-up steps, the K-step region repeated (median), the dominant
     kernel's per-launch time by HIP events, and its roofline block.  Returns (result dict, env, runner info)."""
     from autonomous_quadrotor_environment_amd.distributed import all_gather_returns, shard_range
@@ -327,14 +343,22 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
         chunk = pick(steps, cap)
     if steps % chunk:
         raise SystemExit("--chunk must divide --steps")
-    env = build_env(workload, handle, integrator, n_global, lo, hi, dev)
+    shards = stream_shards if controller == "ppo_rollout" else 1
+    shard_envs = {}
+
+    def make_env(a, b):  # one handle per local shard range, shared by the warm-up runner and the timed one
+        if (a, b) not in shard_envs:
+            shard_envs[(a, b)] = build_env(workload, handle, integrator, n_global, lo + a, lo + b, dev)
+        return shard_envs[(a, b)]
+    env = None if shards > 1 else build_env(workload, handle, integrator, n_global, lo, hi, dev)
     if ppo:
         launch = "step"
 
     def runner(c, graph_ok=True):
         if ppo:
             return make_ppo_runner(env, controller, c, graph_ok and (not no_graph) and controller == "ppo_actor",
-                                   seed=4, env_offset=lo, n_global=n_global)
+                                   seed=4, env_offset=lo, n_global=n_global, shards=shards, make_env=make_env,
+                                   n_local=hi - lo, dev=dev)
         return make_runner(env, controller, flags, launch, c, not no_graph) + (None,)
     run, per_call, ro = runner(chunk)
     if warmup and warmup % chunk == 0:
@@ -346,7 +370,8 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
     regions = timed_regions(run, per_call, steps, world, dev, min_seconds)   # each: exactly K timed steps
     secs = float(np.median(regions))
     value = n_global * steps / secs
-    finite = bool(torch.isfinite(env.state).all())
+    envs_run = [env] if shards == 1 else list(shard_envs.values())
+    finite = all(bool(torch.isfinite(e.state).all()) for e in envs_run)
     gathered = None
     if flags != 1 and controller != "ppo_rollout":
         gathered = all_gather_returns(env.episode_return, n_global)  # the path's one exchange step (RCCL over xGMI)
@@ -384,11 +409,14 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
                             "issue_frac": spw * v["valu_per_wave_step"] * v["active_valu_cycles_per_inst"] / (1024 * v["clock_ghz"] * 1e9)}
     if ppo:  # the dominant kernel of the PPO workloads is the fp32-MFMA MLP forward
         heads = 2 if controller == "ppo_rollout" else 1
-        mlp_us = kernel_launch_us(lambda: env.mlp_forward(ro.w, "actor", out=ro.mean), 1, "fused")
-        tfl = MLP_FLOPS * (hi - lo) / (mlp_us * 1e-6) / 1e12
+        e0, r0 = (env, ro) if shards == 1 else (ro.ros[0].env, ro.ros[0])   # one launch = one shard's envs
+        n_l = e0.n_envs
+        mlp_us = kernel_launch_us(lambda: e0.mlp_forward(r0.w, "actor", out=r0.mean), 1, "fused")
+        tfl = MLP_FLOPS * n_l / (mlp_us * 1e-6) / 1e12
         roofline = {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tfl / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "k_mlp<128,5> (actor forward)",
-                    "kernel_us": mlp_us, "flops_per_launch": MLP_FLOPS * (hi - lo), "mlp_forwards_per_env_step": heads,
+                    "kernel_us": mlp_us, "flops_per_launch": MLP_FLOPS * n_l, "envs_per_launch": n_l,
+                    "mlp_forwards_per_env_step": heads,
                     "hbm_algorithmic_GBps_whole_step": bytes_per_step * value / world / 1e9,
                     "achieved_is": "algorithmic fp32 flops (53.0 kflop per env) / launch time against the fp32-MFMA peak; "
                                    "layers 1 and 2 execute as 6 bf16 MFMA products of 3-way split operands (fp32-accurate, "
@@ -396,17 +424,17 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
                     "executed": {
                         # per 32-env tile: layer 1 4x5x6 + layer 2 4x4x2x6 v_mfma_f32_32x32x16_bf16 (32 cycles each),
                         # layer 3 64 v_mfma_f32_32x32x2_f32 (64 cycles each)
-                        "bf16_tflops": 6 * 2 * (128 * 80 + 128 * 128) * (hi - lo) / (mlp_us * 1e-6) / 1e12,
+                        "bf16_tflops": 6 * 2 * (128 * 80 + 128 * 128) * n_l / (mlp_us * 1e-6) / 1e12,
                         "bf16_dense_peak_tflops": 2516.0,
                         "mfma_cycles_per_tile": 120 * 32 + 192 * 32 + 64 * 64,
-                        "mfma_pipe_busy_frac_at_2.4GHz": ((hi - lo + 31) // 32) * (120 * 32 + 192 * 32 + 64 * 64)
+                        "mfma_pipe_busy_frac_at_2.4GHz": ((n_l + 31) // 32) * (120 * 32 + 192 * 32 + 64 * 64)
                                                           / (1024 * 2.4e9 * mlp_us * 1e-6)}}
     res = {"value": value, "ms_per_step": secs / steps * 1e3, "regions": len(regions),
            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3,
            "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,
            "hip_graph": (launch == "step" and not no_graph and controller != "ppo_rollout"),
            "envs_per_gpu": hi - lo, "global_envs": n_global, "controller": controller, "desc": desc, "roofline": roofline,
-           "all_gather_len": None if gathered is None else int(gathered.numel())}
+           "all_gather_len": None if gathered is None else int(gathered.numel()), "stream_shards": shards}
     return res, env, (controller, flags, no_graph, bytes_per_step, n_global)
 
 
@@ -473,7 +501,7 @@ def main():
 
     res, env, (controller, flags, no_graph, bytes_per_step, n_global) = measure(
         args.workload, handle, args.integrator, args.launch, args.steps, args.warmup, args.chunk, args.no_graph,
-        args.envs, rank, world, dev, args.min_seconds)
+        args.envs, rank, world, dev, args.min_seconds, args.stream_shards)
     ppo = controller.startswith("ppo")
     qualified = WORKLOADS[args.workload][5]
     out = {
@@ -488,7 +516,8 @@ def main():
                                  "lean": "fp64 rows, lean fp64 arithmetic", "f64": "fp64 rows, IEEE fp64 arithmetic"}[handle],
                    "parity_qualified": handle in (qualified, "f64"),
                    "steps_per_graph_replay_or_launch": res["chunk"], "hip_graph": res["hip_graph"],
-                   "parallelism": f"env-sharded x{world}", "finite": res["finite"],
+                   "parallelism": f"env-sharded x{world}", "stream_shards_per_gpu": res["stream_shards"],
+                   "finite": res["finite"],
                    "all_gathered_returns": res["all_gather_len"]},
         "timing": {"regions": res["regions"], "statistic": "median of the K-step regions (each barrier+sync bracketed)",
                    "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
@@ -570,13 +599,15 @@ def main():
     if args.workload == "config2" and world == 1 and not args.no_subconfigs and args.envs == 0:
         subs = {}
         for name, k_steps, w_steps in (("config3", 250, 250), ("config4", 250, 50), ("config5", 128, 128)):
-            r, e_, _ = measure(name, WORKLOADS[name][5], "rk45", "fused", k_steps, w_steps, 0, False, 0, 0, 1, dev, 0.1)
+            r, e_, _ = measure(name, WORKLOADS[name][5], "rk45", "fused", k_steps, w_steps, 0, False, 0, 0, 1, dev, 0.1,
+                               args.stream_shards)
             rf = r["roofline"]
             subs[name] = {"value": r["value"], "unit": "env-steps/s (one GPU's slice)", "ms_per_step": r["ms_per_step"],
                           "steps": k_steps, "regions": r["regions"], "envs": r["envs_per_gpu"], "handle": WORKLOADS[name][5],
                           "workload": r["desc"], "finite": r["finite"], "dominant_kernel": rf["kernel"],
                           "kernel_us": rf["kernel_us"], "bound": rf["bound"], "frac": rf["frac"],
-                          "achieved": rf["achieved"], "roofline_unit": rf["unit"]}
+                          "achieved": rf["achieved"], "roofline_unit": rf["unit"], "stream_shards": r["stream_shards"],
+                          "envs_per_kernel_launch": rf.get("envs_per_launch", r["envs_per_gpu"])}
             del e_
         out["configs"] = subs
 

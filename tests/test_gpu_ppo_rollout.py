@@ -685,3 +685,35 @@ def test_weights_of_another_window_are_refused(aq):
     assert rc == -1 and b"k_in" in L.lib.qenv_last_error()
     w45 = aq.ActorCriticWeights.random(64, 45, 4, device="cuda", seed=0)
     assert torch.isfinite(env.mlp_forward(w45, "actor")).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3])
+def test_stream_sharded_rollout_is_the_single_batch_rollout(aq, shards):
+    """StreamShardedRollout (the GPU's env range as S shards on S streams): every rollout buffer of the union equals the
+    single-batch PolicyRollout bit for bit (trajectories, Philox streams and resets are keyed by the global env index),
+    returns too; the advantages are normalised with the moments of ALL shards (summed in another order: 1e-12)."""
+    import torch
+    N, H = 1000, 24
+    w = aq.ActorCriticWeights.random(128, 75, 4, device="cuda", seed=2); w.std = 0.3
+
+    def make_env(lo, hi):
+        return aq.BatchedQuad(hi - lo, 0.01, 40, training=True, direct_control=1, T=5, dtype=torch.float64, compute="lean")
+    one = aq.PolicyRollout(make_env(0, N), w, H, store_obs=True, auto_reset=True, seed=9, env_offset=100)
+    one.start()
+    sh = aq.StreamShardedRollout(make_env, N, w, H, shards=shards, seed=9, env_offset=100, store_obs=True, auto_reset=True)
+    sh.start()
+    for rep in range(2):   # the second horizon starts with resets pending from the first
+        one.t = 0; sh.t = 0
+        for _ in range(H):
+            one.step(); sh.step()
+        ret1, adv1 = one.finish(ddof=0, group=False)
+        outs = sh.finish(ddof=0, group=False)
+        torch.cuda.synchronize()
+        for name in ("actions", "logprobs", "rewards", "masks", "obs", "values"):
+            got = torch.cat([getattr(r, name) for r in sh.ros], dim=-1)
+            assert torch.equal(got, getattr(one, name)), (rep, name)
+        assert torch.equal(torch.cat([o[0] for o in outs], dim=-1), ret1)
+        assert torch.allclose(torch.cat([o[1] for o in outs], dim=-1), adv1, rtol=0, atol=1e-10)
+        assert torch.equal(sh.last_returns(), one.env.last_return)
+    assert float(one.masks.min()) == 0.0  # episodes did end and reset inside the horizons

@@ -6,9 +6,11 @@ import torch
 import autonomous_quadrotor_environment_amd as aq
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-env = aq.BatchedQuad(N, 0.01, 1000, training=True, direct_control=1, T=5)
+lean = len(sys.argv) > 2 and sys.argv[2] == "lean"
+env = aq.BatchedQuad(N, 0.01, 1000, training=True, direct_control=1, T=5, dtype=torch.float64 if lean else torch.float32,
+                     compute="lean" if lean else None)
 env.reset(env.sample_init_states(0, 0, 0), return_history=False, push_window=True)
-for m in (0, 1, 64, 1024, 8192, N):
+for m in (0, 1, 64, 300, 1024, 8192, N):
     mask = torch.zeros(N, dtype=torch.uint8, device="cuda")
     if m:
         mask[torch.randperm(N, device="cuda")[:m]] = 1
@@ -20,4 +22,4 @@ for m in (0, 1, 64, 1024, 8192, N):
     for k in range(200):
         env.reset_sampled(1, k + 2, 0, mask=mask, push_window=True)
     b.record(); torch.cuda.synchronize()
-    print(json.dumps(dict(n_envs=N, n_reset=m, us_per_masked_reset=a.elapsed_time(b) * 1000 / 200)), flush=True)
+    print(json.dumps(dict(n_envs=N, handle="lean" if lean else "f32", warmup_lanes=os.environ.get("QENV_WARMUP_LANES", "8"), n_reset=m, us_per_masked_reset=a.elapsed_time(b) * 1000 / 200)), flush=True)
