@@ -57,7 +57,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->sens = qenv_sensor_link{};
     q->side = nullptr; q->ev_main = nullptr; q->ev_side = nullptr;
     q->env_flags[0] = (uint8_t*)workspace + L.flag_off; q->env_flags[1] = q->env_flags[0] + L.flag_stride;
-    q->ar_pending = 0; q->ar_parity = 0;
+    q->ar_pending = 0; q->ar_parity = 0; q->zero_on_act = nullptr;
     q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
@@ -259,8 +259,16 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     ex.ar_count = q->counters + next;
     ex.ar_flags_next = q->env_flags[next];
     hipStream_t M = q->stream;
-    hipError_t he = hipMemsetAsync(q->counters + next, 0, sizeof(int32_t), M);  // list `next` was walked two steps ago
-    if (he != hipSuccess) return fail_hip(he, "hipMemsetAsync(reset list length)");
+    // list `next` was walked two steps ago: its length restarts at 0 before this step's kernel appends to it.  In the plain
+    // sequence the policy forward that precedes the step kernel on the stream clears the word; with the side stream two
+    // step kernels append concurrently, so the clear is its own operation ahead of the fork.
+    hipError_t he = hipSuccess;
+    if (q->ar_pending && overlap) {
+        he = hipMemsetAsync(q->counters + next, 0, sizeof(int32_t), M);
+        if (he != hipSuccess) return fail_hip(he, "hipMemsetAsync(reset list length)");
+    } else {
+        q->zero_on_act = q->counters + next;
+    }
     const int slot = q->win_head;
     const int mode = QENV_STEP_NO_AUX;
     int rc = QENV_OK;

@@ -115,6 +115,7 @@ struct qenv_s {
     uint8_t* env_flags[2];     // [parity]: 1 for the envs of reset list `parity`
     int32_t ar_pending;        // a reset list (parity ar_parity) still waits for its warm-up
     int32_t ar_parity;
+    int32_t* zero_on_act;      // a word the next policy forward clears in its first thread (see MlpArgs::zero_word)
 };
 
 namespace qenv {
