@@ -250,23 +250,25 @@ def make_runner(env, controller, flags, launch, chunk, use_graph):
 
 # ---- timing ---------------------------------------------------------------------------------------------------------
 def time_region(run, per_call, steps, world, dev):
-    """barrier + sync | exactly `steps` env steps | barrier + sync; returns seconds (max over ranks)."""
+    """barrier + sync | exactly `steps` env steps | sync + barrier; returns seconds (max over ranks).
+    The opening bracket makes the ranks start together; a rank's time ends when ITS GPU has finished the K steps
+    (torch.cuda.synchronize), and the job's time is the maximum over the ranks.  The closing barrier -- the MAX
+    all-reduce itself -- comes after the clock is read: its own latency (tens of microseconds over RCCL, against a
+    92 us region at the driver's K = 20) is not env work."""
     assert steps % per_call == 0
-
-    def sync():
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-    sync()
     t0 = time.perf_counter()
     for _ in range(steps // per_call):
         run()
-    sync()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # closes the bracket: every rank has finished its K steps
+        torch.cuda.synchronize()
         dt = float(t.item())
     return dt
 
