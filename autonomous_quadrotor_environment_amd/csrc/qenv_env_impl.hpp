@@ -185,13 +185,17 @@ __device__ __forceinline__ void store_gust(S* ws, int32_t* wsi, int64_t N, int64
     if (pl.evals >= 0) wsi[IROW_GUST_K * N + e] = pl.evals;  // draws the last redraw step consumed (host RNG replay)
 }
 
+#ifndef QENV_STEP_MIN_WAVES
+#define QENV_STEP_MIN_WAVES 1  // the same for k_step alone (lean rk45 at 2: 256 VGPRs + 236 B scratch; measured: config 5 0.50 ->
+                               // 0.48 G env-steps/s, per-step API 5.8 -> 4.8 G/s, config 4 unchanged -- the spills cost more than the overlap gives)
+#endif
 #ifndef QENV_MIN_WAVES
 #define QENV_MIN_WAVES 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
 #endif
 
 // quad.step for N envs: one launch, one lane per env.
 template <typename T, typename S, int INTEG, bool ROBUST, bool LEAN = false>
-__global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
+__global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
     using M = typename MathSel<T, LEAN>::type;
     int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.N) return;
