@@ -95,6 +95,8 @@ def parse(argv=None):
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--extras", action="store_true", help="also time the other integrators / launch modes")
     p.add_argument("--no-extras", action="store_true", help="skip the extras that the default 1-GPU config-2 run adds")
+    p.add_argument("--no-sustained", action="store_true", help="skip the 250-step-launch `sustained` figure (profiling runs: "
+                   "keeps the kernel trace to the K-step launches)")
     p.add_argument("--no-subconfigs", action="store_true", help="skip the config3/4/5 slices of the default 1-GPU run")
     p.add_argument("--min-seconds", type=float, default=MIN_TIMED_S, help="repeat the K-step region until this much is timed")
     return p.parse_args(argv)
@@ -529,7 +531,7 @@ def main():
 
     # what the same kernel sustains when the launch granularity is not tied to K: 250-step launches, one bracket around
     # >= 0.3 s of them (the driver's K = 20 makes every region a single 20-step launch + its sync)
-    if not ppo and args.launch == "fused":
+    if not ppo and args.launch == "fused" and not args.no_sustained:
         r2, pc = make_runner(env, controller, flags, "fused", 250, False)
         time_region(r2, pc, 250, world, dev)
         t1 = time_region(r2, pc, 250, world, dev)

@@ -10,7 +10,7 @@ run() {  # name, bench args...
   [ -n "$f" ] && head -6 "$f" | cut -c1-170 > $OUT/${name}_kernel_stats_top.csv && cp "$f" $OUT/${name}_kernel_stats.csv
 }
 run config2_default --steps 2000 --warmup 250
-run config2_driver --steps 20 --warmup 5
+run config2_driver --steps 20 --warmup 5 --no-sustained
 run config2_step --steps 2000 --warmup 200 --launch step
 run config2_dp5 --steps 2000 --warmup 250 --integrator dp5
 run config2_f32 --steps 2000 --warmup 250 --dtype f32
