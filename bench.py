@@ -23,7 +23,12 @@ config 2 already (thrust minus weight cancels to 1e-6 m/s^2 in fp32).
 The K-step region (barrier + sync on both sides, exactly K steps) is repeated until >= 0.3 s
 have been timed; `ms_per_step` / `value` are the MEDIAN region.  Rank 0 prints ONE JSON line
 with the contract fields plus `roofline`, `cpu_baseline`, `sustained` and (default 1-GPU run)
-`configs`: short per-GPU slices of BASELINE configs[2..4].
+`configs`: short per-GPU slices of BASELINE configs[2..4].  A rank's clock for a region stops when its own GPU
+has finished (torch.cuda.synchronize); the MAX all-reduce over the ranks closes the bracket afterwards.
+
+--workload config5 collects the rank's env range as `--stream-shards` (default 2) shards on their own HIP streams
+(StreamShardedRollout: bit-identical to one batch, +12 %).  --no-sustained / --no-extras / --no-subconfigs /
+--no-cpu-baseline trim the line for profiling runs (tools/profile_round.sh).
 """
 import argparse
 import json
