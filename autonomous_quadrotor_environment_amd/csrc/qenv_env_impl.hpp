@@ -1006,7 +1006,7 @@ template <typename T, typename S, int INTEG, bool LEAN> static void launch_rollo
         // SIMD (N >= 131072), a loss below that, and no gain for rk45 or with a controller in the loop.
         // QENV_PACKED=0/1 overrides the rule.
         const bool auto_packed = q->packed < 0 && INTEG != INT_RK45 && controller == QENV_CTRL_CONST && q->N >= 131072;
-        if ((q->packed > 0 || auto_packed) && (q->N % 2) == 0 && a.lane_shift == 6) {
+        if ((q->packed > 0 || auto_packed) && (q->N % 2) == 0 && a.lane_shift == 6 && !a.idx) {  // the packed kernel has no list mode
             const dim3 g2 = grid_for(q->N / 2), b2(256);
             switch (controller) {
                 case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout2<INTEG, QENV_CTRL_CONST>), g2, b2, 0, q->stream, a); break;
