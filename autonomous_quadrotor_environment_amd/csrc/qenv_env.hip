@@ -306,6 +306,7 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
         if (rc == QENV_OK) rc = act(nullptr, nullptr, nullptr);
         if (rc == QENV_OK) rc = step(nullptr, nullptr, nullptr);
     }
+    q->zero_on_act = nullptr;  // consumed by act(); cleared here too in case an earlier launch of the sequence failed
     if (rc != QENV_OK) return rc;
     q->win_head = (q->win_head + 1) % q->cfg.T;
     q->ar_pending = 1;
