@@ -293,7 +293,8 @@ def timed_regions(run, per_call, steps, world, dev, min_seconds, max_regions=500
 
 
 def kernel_launch_us(run, per_call, launch, reps=8):
-    """Average duration of ONE launch of the dominant kernel from HIP events on the launch stream (the env launches on
+    """Average launch-to-launch interval (kernel duration + dependent-launch boundary) of the dominant kernel on a
+    saturated stream, from HIP events on the launch stream (the env launches on
     torch's current stream, so torch.cuda.Event brackets it).  An event pair costs more than a short kernel (its two
     marker packets added ~20 us to a 70 us launch when every launch had its own pair), so one pair brackets a train of
     back-to-back launches -- at least 2 ms of them -- and the elapsed time is divided by the number of launches: the
