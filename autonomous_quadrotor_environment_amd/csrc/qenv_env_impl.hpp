@@ -185,6 +185,9 @@ __device__ __forceinline__ void store_gust(S* ws, int32_t* wsi, int64_t N, int64
     if (pl.evals >= 0) wsi[IROW_GUST_K * N + e] = pl.evals;  // draws the last redraw step consumed (host RNG replay)
 }
 
+#ifndef QENV_ENV_BLOCK_DEFAULT
+#define QENV_ENV_BLOCK_DEFAULT 256
+#endif
 #ifndef QENV_STEP_MIN_WAVES
 #define QENV_STEP_MIN_WAVES 1  // the same for k_step alone (lean rk45 at 2: 256 VGPRs + 236 B scratch; measured: config 5 0.50 ->
                                // 0.48 G env-steps/s, per-step API 5.8 -> 4.8 G/s, config 4 unchanged -- the spills cost more than the overlap gives)
@@ -197,7 +200,7 @@ __device__ __forceinline__ void store_gust(S* ws, int32_t* wsi, int64_t N, int64
 template <typename T, typename S, int INTEG, bool ROBUST, bool LEAN = false>
 __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
     using M = typename MathSel<T, LEAN>::type;
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.N) return;
     if (a.idx) {  // masked steps (reset warm-ups) run on the compacted list: only ceil(count/64) waves do any work
         if (e >= *a.count) return;
@@ -368,11 +371,12 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
 template <typename T, typename S, int INTEG, int CTRL, bool ROBUST, bool LEAN = false>
 __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T, S> a) {
     using M = typename MathSel<T, LEAN>::type;
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int wpb = blockDim.x >> 6;  // waves per workgroup (env_block())
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.lane_shift < 6) {
         const int ln = threadIdx.x & 63;
         if (ln >> a.lane_shift) return;
-        e = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << a.lane_shift) + ln;
+        e = (((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) << a.lane_shift) + ln;
     }
     if (!a.idx && e >= a.N) return;
     if (a.idx) {
@@ -380,12 +384,12 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         if (a.list_min_shift >= 0) {
             // the fewest envs per wave the launched waves allow: a wave runs every env step as many RK45 attempts as its
             // slowest lane, and the SIMDs a short list leaves idle are free (see do_rollout)
-            const int64_t n_waves = (int64_t)gridDim.x * 4;
+            const int64_t n_waves = (int64_t)gridDim.x * wpb;
             int sh = a.list_min_shift;
             while (sh < 6 && (n_waves << sh) < cnt) ++sh;
             const int ln = threadIdx.x & 63;
             if (ln >> sh) return;
-            e = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << sh) + ln;
+            e = (((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) << sh) + ln;
         }
         if (e >= cnt) return;
         e = a.idx[e];
@@ -911,6 +915,17 @@ template <typename T> static PidGains<T> make_pid(bool clipped) {
 }
 
 static inline dim3 grid_for(int64_t N) { return dim3((unsigned)((N + 255) / 256)); }
+// Workgroup size of k_step / k_rollout (one lane per env, nothing shared inside a workgroup): QENV_ENV_BLOCK = 64, 128 or 256.
+// Measured (lean handle): config 3 the same at all three (6.06 / 6.06 / 6.08 G env-steps/s: waves of a workgroup finishing
+// at different times do not cost SIMD time), config 4 1.604 / 1.624 / 1.632, config 5 0.505 / 0.415 / 0.462 -- 256 stays.
+static inline int env_block() {
+    static const int b = [] {
+        const int v = getenv("QENV_ENV_BLOCK") ? atoi(getenv("QENV_ENV_BLOCK")) : QENV_ENV_BLOCK_DEFAULT;
+        return (v == 64 || v == 128 || v == 256) ? v : QENV_ENV_BLOCK_DEFAULT;
+    }();
+    return b;
+}
+static inline dim3 env_grid(int64_t N) { return dim3((unsigned)((N + env_block() - 1) / env_block())); }
 
 // extras of the overlapped PPO step (see StepArgs)
 struct StepExtra {
@@ -965,7 +980,7 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
     // touching the angle rows; an unmasked full step re-synchronises all of them
     if (flags == QENV_STEP_DYNAMICS_ONLY) q->ang_ok = 0;
     else if (!mask) q->ang_ok = 1;
-    const dim3 g = grid_for(q->N), b(256);
+    const dim3 g = env_grid(q->N), b(env_block());
     a.gust = q->gust;
     if (q->robust) {
         if (flags == QENV_STEP_DYNAMICS_ONLY)
@@ -990,7 +1005,7 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
 }
 
 template <typename T, typename S, int INTEG, bool LEAN> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T, S>& a) {
-    const dim3 g = grid_for(q->N), b(256);
+    const dim3 g = env_grid(q->N), b(env_block());
     if constexpr (!LEAN) if (q->robust) {
         switch (controller) {
             case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST, true>), g, b, 0, q->stream, a); break;
@@ -1018,7 +1033,7 @@ template <typename T, typename S, int INTEG, bool LEAN> static void launch_rollo
         }
     }
     if (a.lane_shift < 6) {
-        const int64_t per_block = (int64_t)4 << a.lane_shift;
+        const int64_t per_block = (int64_t)(env_block() / 64) << a.lane_shift;
         const dim3 gh((unsigned)((q->N + per_block - 1) / per_block));
         switch (controller) {
             case QENV_CTRL_CONST: hipLaunchKernelGGL((k_rollout<T, S, INTEG, QENV_CTRL_CONST, false, LEAN>), gh, b, 0, q->stream, a); break;
