@@ -51,6 +51,7 @@ BYTES_DYNAMICS = 104   # read state 13x4 + write state 13x4
 BYTES_FULL = 224       # full quad.step (reads 88 + writes 136)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 MIN_TIMED_S = 0.3
+EPISODE_STEPS = 500     # episode length of the closed-loop workloads (lqr_quad.py, ppo.py:301)
 
 WORKLOADS = {
     # name: (envs/GPU, direct_control, controller, flags, bytes/env-step, qualified handle, description)
@@ -370,13 +371,39 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
                                    seed=4, env_offset=lo, n_global=n_global, shards=shards, make_env=make_env,
                                    n_local=hi - lo, dev=dev)
         return make_runner(env, controller, flags, launch, c, not no_graph) + (None,)
+    # Episodes: the closed-loop workloads without an auto-reset (LQR / PID rollouts, actor in the loop) run EPISODES of 500
+    # steps like the reference's scripts (lqr_quad.py / ppo_quad_eval.py run one episode per reset); without this the
+    # repeated K-step regions would carry the same envs for thousands of steps, where the few that the controller (or the
+    # random-init policy) does not stabilise need ever more RK45 sub-steps and every wave waits for them.  The reset to
+    # the initial states is part of the timed work (one launch per 500 steps).
+    episodic = controller in ("lqr", "pid", "ppo_actor")
+    x0_dev = torch.from_numpy(np.ascontiguousarray(make_init(workload, n_global, lo, hi).T)).to(dev) if episodic else None
+    ep = {"n": 0}
+
+    def episodic_run(inner, pc):
+        if not episodic:
+            return inner
+
+        def wrapped():
+            if ep["n"] + pc > EPISODE_STEPS:
+                if controller == "ppo_actor":
+                    env.reset(x0_dev, return_history=False, push_window=True)
+                else:
+                    env.reset(x0_dev)
+                    if controller == "pid":
+                        env.pid_reset()
+                ep["n"] = 0
+            inner()
+            ep["n"] += pc
+        return wrapped
     run, per_call, ro = runner(chunk)
+    run = episodic_run(run, per_call)
     if warmup and warmup % chunk == 0:
         time_region(run, per_call, warmup, world, dev)     # W untimed warm-up steps
     elif warmup:
         cw = pick(warmup, cap, mult)
         rw, pcw, _ = runner(cw, True) if cw else runner(pick(warmup, cap), False)  # no %T divisor: eager warm-up
-        time_region(rw, pcw, warmup, world, dev)
+        time_region(episodic_run(rw, pcw), pcw, warmup, world, dev)
     regions = timed_regions(run, per_call, steps, world, dev, min_seconds)   # each: exactly K timed steps
     secs = float(np.median(regions))
     value = n_global * steps / secs
@@ -446,7 +473,8 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
            "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,
            "hip_graph": (launch == "step" and not no_graph and controller != "ppo_rollout"),
            "envs_per_gpu": hi - lo, "global_envs": n_global, "controller": controller, "desc": desc, "roofline": roofline,
-           "all_gather_len": None if gathered is None else int(gathered.numel()), "stream_shards": shards}
+           "all_gather_len": None if gathered is None else int(gathered.numel()), "stream_shards": shards,
+           "episode_steps": EPISODE_STEPS if episodic else None}
     return res, env, (controller, flags, no_graph, bytes_per_step, n_global)
 
 
@@ -529,6 +557,7 @@ def main():
                    "parity_qualified": handle in (qualified, "f64"),
                    "steps_per_graph_replay_or_launch": res["chunk"], "hip_graph": res["hip_graph"],
                    "parallelism": f"env-sharded x{world}", "stream_shards_per_gpu": res["stream_shards"],
+                   "episode_steps": res["episode_steps"],
                    "finite": res["finite"],
                    "all_gathered_returns": res["all_gather_len"]},
         "timing": {"regions": res["regions"], "statistic": "median of the K-step regions (each barrier+sync bracketed)",
@@ -619,6 +648,7 @@ def main():
                           "workload": r["desc"], "finite": r["finite"], "dominant_kernel": rf["kernel"],
                           "kernel_us": rf["kernel_us"], "bound": rf["bound"], "frac": rf["frac"],
                           "achieved": rf["achieved"], "roofline_unit": rf["unit"], "stream_shards": r["stream_shards"],
+                          "episode_steps": r["episode_steps"],
                           "envs_per_kernel_launch": rf.get("envs_per_launch", r["envs_per_gpu"])}
             del e_
         out["configs"] = subs

@@ -1,10 +1,11 @@
 #!/bin/bash
 # GPU box: VALU / SALU instructions per env step and wave of the fused rollout kernel of a bench.py run.
 #   tools/pmc_valu_count.sh TAG [bench.py arguments]     (default: the headline, config 2 rk45 250-step launches)
+#   PMC_CMD="tools/rollout_driver.py lqr 2 rk45" tools/pmc_valu_count.sh TAG      (any other driver of 250-step launches)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-headline}; shift
 OUT=gpurun_out/pmc_valu_$TAG; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --steps 2000 --warmup 250 --min-seconds 0 --no-extras --no-cpu-baseline --no-subconfigs "$@" > $OUT/a.log 2>&1 || echo failed
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 ${PMC_CMD:-bench.py --steps 2000 --warmup 250 --min-seconds 0 --no-extras --no-cpu-baseline --no-subconfigs} "$@" > $OUT/a.log 2>&1 || echo failed
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys, json
 out = sys.argv[1]
