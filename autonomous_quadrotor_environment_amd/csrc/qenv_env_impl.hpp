@@ -227,6 +227,12 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
         load_plant<T>(a.ws, a.wsi, N, e, a.gust, pl);
         begin_step_wind(pl, a.wsi[IROW_I * N + e] + 1);  // self.i += 1 comes first in step (:467)
     }
+    // the bookkeeping rows are requested BEFORE the integration: one wave per SIMD is resident (register footprint), so a
+    // load issued after the RK45 is a full memory round trip with nothing to hide behind.  (Measured A/B on config 4: neutral,
+    // 32.2 vs 31.5 us per launch -- the 45 % of a wave's cycles that the SQ counters show as waits are the load and store
+    // BURSTS of 2 048 waves that start and finish together: 131 072 envs x ~500 B per step in fp64 rows = 66 MB per launch.)
+    Book<T> bk;
+    if (a.mode != QENV_STEP_DYNAMICS_ONLY) load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
     prepare_action(raw, cfg, pl, w, effort, cl, act, u);
     integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy);
     if constexpr (ROBUST) store_gust(a.ws, a.wsi, N, e, pl);
@@ -237,8 +243,6 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
     }
     if (a.mode == QENV_STEP_DYNAMICS_ONLY) return;
 
-    Book<T> bk;
-    load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
     bk.i += 1;
     euler_update<T, M>(q_old, y, dy, a.ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
     done_reward<T, M>(y, act, effort, cfg, bk);
