@@ -68,8 +68,10 @@ for case in range(n_cases):
             total += rew
         err_e = np.max(np.abs(got[:, e] - r.state) / np.maximum(np.abs(r.state), 1e-3 * SC))
         if err_e > 1e-9:  # how far does the ORACLE move under a perturbation of the size of one step's libm differences?
+            # (IEEE handle: 1e-13; the lean handle's one-step deviation from the oracle is up to 4e-13 on the fixtures: 1e-12)
+            pert = 1e-12 if os.environ.get("QENV_FUZZ_HANDLE") == "lean" else 1e-13
             for sgn in (1.0, -1.0):
-                xp = x0[e] * (1 + sgn * 1e-13)
+                xp = x0[e] * (1 + sgn * pert)
                 sens = max(sens, np.max(np.abs(oracle_run(xp) - r.state) / np.maximum(np.abs(r.state), 1e-3 * SC)))
         err = max(err, err_e)
         flags_ok &= bool(fl[e] & 1) == bool(r.done) and bool(fl[e] & 2) == bool(r.solved)
