@@ -585,6 +585,7 @@ class StreamShardedRollout:
                 self.ros.append(PolicyRollout(make_env(lo, hi), weights, horizon, seed=seed, env_offset=env_offset + lo, **kw))
         self.w = weights
         self._stats = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._fast = None   # built at the first sampling step (see _fast_args)
 
     @property
     def t(self):
@@ -600,7 +601,46 @@ class StreamShardedRollout:
             with torch.cuda.stream(st):
                 ro.start()
 
+    def _fast_args(self):
+        """One prebuilt qenv_ppo_step argument block per (shard, time index): the sampling auto-reset rollout is one C
+        call per shard and step, and with several shards the Python around it (stream context, buffer checks, struct
+        assembly: ~60 us per shard-step) becomes the limit -- here a step costs one ctypes call per shard."""
+        import ctypes as C
+        out = []
+        for st, ro in zip(self.streams, self.ros):
+            env, w = ro.env, ro.w
+            if not (ro.auto_reset and ro.overlap and ro.fused_act and not ro.keep_init and not env.robust_control
+                    and (w.critic is None or ro.batched_critic)):
+                return None
+            with torch.cuda.stream(st):
+                env._check_head(w.head("actor"), "actor", n_out=4)
+                env._bind()  # the handle keeps this shard's stream from here on
+            W = w.head("actor")
+            per_t = []
+            for t in range(ro.horizon):
+                per_t.append(L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[x.data_ptr() for x in W], float(w.std), None,
+                                           int(ro.seed), 0, int(ro.env_offset), ro.mean.data_ptr(), ro.actions[t].data_ptr(),
+                                           ro.logprobs[t].data_ptr(), None if ro.obs is None else ro.obs[t].data_ptr(),
+                                           ro.rewards[t].data_ptr(), ro.done.data_ptr(), ro.masks[t].data_ptr()))
+            out.append((env._h, per_t, float(w.std)))
+        self._C = C
+        return out
+
     def step(self, deterministic=False):
+        if not deterministic:
+            if self._fast is None:
+                self._fast = self._fast_args() or False
+            if self._fast:
+                C = self._C
+                for (h, per_t, std), ro in zip(self._fast, self.ros):
+                    a = per_t[ro.t]
+                    a.step = ro.global_step + 1
+                    if ro.w.std != std:      # a learner moved the action std since the blocks were built
+                        a.std = float(ro.w.std)
+                    L.check(L.lib.qenv_ppo_step(h, C.byref(a)), "qenv_ppo_step")
+                    ro.t += 1
+                    ro.global_step += 1
+                return
         for st, ro in zip(self.streams, self.ros):
             with torch.cuda.stream(st):
                 ro.step(deterministic=deterministic)
