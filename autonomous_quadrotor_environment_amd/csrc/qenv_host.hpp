@@ -122,6 +122,24 @@ namespace qenv {
 
 inline thread_local char g_err[256] = "";
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call (a few microseconds of host time on every launch of the
+// small-batch paths): the opt-in is per function and sticky, so it is made only when a launch needs more than was granted
+static inline hipError_t allow_dynamic_lds(const void* fn, size_t bytes) {
+    struct Slot { const void* fn; size_t bytes; };
+    static thread_local Slot cache[64] = {};
+    static thread_local int n = 0;
+    for (int i = 0; i < n; ++i)
+        if (cache[i].fn == fn) {
+            if (bytes <= cache[i].bytes) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) cache[i].bytes = bytes;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && n < 64) cache[n++] = Slot{fn, bytes};
+    return e;
+}
+
 static inline int fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;

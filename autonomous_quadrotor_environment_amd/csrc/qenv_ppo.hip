@@ -828,7 +828,7 @@ template <int H, int TW, bool SAMPLE> static int launch_mlp_wide(const MlpArgs& 
     if (blocks > 256) blocks = 256;
     const size_t lds = fixed + nbuf * blockb;
     const void* fn = nbuf == 2 ? (const void*)k_mlp_wide<H, TW, 2, SAMPLE> : (const void*)k_mlp_wide<H, TW, 1, SAMPLE>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_dynamic_lds(fn, lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_wide)");
     if (nbuf == 2) hipLaunchKernelGGL((k_mlp_wide<H, TW, 2, SAMPLE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((k_mlp_wide<H, TW, 1, SAMPLE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -887,8 +887,7 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
         if (mlp_bf16_layer2() >= 2) {
             const size_t lds = sizeof(float) * ((size_t)NT * KS16 * 3 * 64 * 4 + (size_t)NT * NT * 2 * 3 * 64 * 4 + 4 * HP + 2 * HP + 32);
             if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS");
-            hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 2>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_dynamic_lds((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 2>, lds);
             if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp bf16)");
             hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 2>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
             return check_launch("k_mlp(bf16 layers 1+2)");
@@ -896,8 +895,7 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
         if (mlp_bf16_layer2() == 1) {
             const size_t lds = sizeof(float) * ((size_t)K1P * HP + (size_t)NT * NT * 2 * 3 * 64 * 4 + 32 * HP + 2 * HP + 32);
             if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS");
-            hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 1>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_dynamic_lds((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 1>, lds);
             if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp bf16)");
             hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE, 1>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
             return check_launch("k_mlp(bf16 layer 2)");
@@ -905,7 +903,7 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
     }
     const size_t lds = sizeof(float) * ((size_t)K1P * HP + (W2_LDS ? (size_t)HP * HP : 0) + 32 * HP + 2 * HP + 32);
     if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS (reduce T)");
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_dynamic_lds((const void*)k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>, lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp)");
     hipLaunchKernelGGL((k_mlp<H, TW, BLOCK, W2_LDS, SAMPLE>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
     return check_launch("k_mlp");
@@ -1056,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
 template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
     const size_t lds = sizeof(float) * (64 * (HP + 1) + HP * HP + 32 * HP + 2 * HP + 32);
-    hipError_t e = hipFuncSetAttribute((const void*)k_dense_tail<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_dynamic_lds((const void*)k_dense_tail<H>, lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_dense_tail)");
     const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
     int64_t blocks = (n_tiles + 3) / 4;

@@ -435,7 +435,7 @@ template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream
     const size_t lds = sizeof(float) * (size_t)(MT + NTN) * 32 * 65;
     const int64_t n_tiles = ((a.N + 63) / 64) * a.n_chunks;
     const int64_t blocks = n_tiles < 512 ? n_tiles : 512;
-    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<MT, NTN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_dynamic_lds((const void*)k_wgrad<MT, NTN, NW>, lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_wgrad)");
     hipLaunchKernelGGL((k_wgrad<MT, NTN, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
     int rc = check_launch("k_wgrad");
@@ -544,11 +544,11 @@ static int launch_bwd(BwdArgs& a, int hidden, void* stream) {
 #define QENV_BWD_CASE(HH)                                                                                                   \
     case HH:                                                                                                                 \
         if (wide) {                                                                                                          \
-            e = hipFuncSetAttribute((const void*)k_mlp_bwd<HH, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            e = allow_dynamic_lds((const void*)k_mlp_bwd<HH, 512>, lds);  \
             if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd)");                                       \
             hipLaunchKernelGGL((k_mlp_bwd<HH, 512>), dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, a);        \
         } else {                                                                                                             \
-            e = hipFuncSetAttribute((const void*)k_mlp_bwd<HH, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            e = allow_dynamic_lds((const void*)k_mlp_bwd<HH, 256>, lds);  \
             if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd)");                                       \
             hipLaunchKernelGGL((k_mlp_bwd<HH, 256>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);        \
         }                                                                                                                    \
