@@ -677,3 +677,32 @@ def test_sharded_quad_slices_reproduce_the_global_batch(aq):
     assert torch.equal(torch.cat([p.env.state for p in parts], 1), full.env.state)
     assert torch.equal(torch.cat([p.env.episode_return for p in parts]), full.env.episode_return)
     assert torch.equal(full.gather_returns(), full.env.episode_return)  # single process: the gather is the identity
+
+
+@pytest.mark.parametrize("N", [1, 63, 65, 1000, 100003])
+def test_ragged_sizes_fused_equals_stepwise_and_masked_reset(aq, N):
+    """Batch sizes that are no multiple of the wavefront / workgroup / list-spreading granularities (lean handle): the fused
+    LQR rollout equals step-by-step launches bit for bit, and a masked reset of a few envs (whose warm-up list is spread
+    16 envs per wave over the launched waves) leaves every other env untouched and equals the same reset in a batch of one."""
+    from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+    kw = dict(training=True, direct_control=0, T=2, dtype=torch.float64, compute="lean")
+    x0 = torch.from_numpy(np.ascontiguousarray(fast_random_init_states(21, N).T)).cuda()
+    a = aq.BatchedQuad(N, 0.01, 1000, **kw); b = aq.BatchedQuad(N, 0.01, 1000, **kw)
+    a.reset(x0); b.reset(x0)
+    a.rollout("lqr", 12)
+    act = torch.empty(4, N, device="cuda", dtype=torch.float64)
+    for _ in range(12):
+        b.lqr_action(act); b.step(act)
+    assert torch.equal(a.state, b.state) and torch.equal(a.flags, b.flags) and torch.equal(a.i, b.i)
+    mask = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    idx = torch.unique(torch.tensor([0, N // 3, N // 2, N - 1], device="cuda"))
+    mask[idx] = 1
+    before = a.state.clone()
+    a.reset_sampled(5, 3, 1000, mask=mask, push_window=True)
+    keep = mask == 0
+    assert torch.equal(a.state[:, keep], before[:, keep])
+    one = aq.BatchedQuad(1, 0.01, 1000, **kw)
+    for e in idx.tolist():
+        one.reset(x0[:, e:e + 1].contiguous())
+        one.reset_sampled(5, 3, 1000 + e, mask=torch.ones(1, dtype=torch.uint8, device="cuda"), push_window=True)
+        assert torch.equal(one.state[:, 0], a.state[:, e]) and int(one.i[0]) == int(a.i[e]), e
