@@ -23,15 +23,18 @@ p.add_argument("--separate-reset", action="store_true", help="auto-reset through
 p.add_argument("--deterministic", action="store_true", help="fixed-order gradient / moment sums: the run is bit-reproducible")
 p.add_argument("--digest", action="store_true", help="print a SHA-256 of the final weights (two --deterministic runs must agree)")
 p.add_argument("--log", default="")
+p.add_argument("--handle", default="f32", choices=["f32", "lean", "f64"], help="env handle (lean = the parity-qualified one)")
+p.add_argument("--learn-std", action="store_true", help="train the action std too (model.py fixed_std=False)")
 a = p.parse_args()
 
 w = aq.ActorCriticWeights.random(a.hidden, 75, 4, seed=a.seed)
 w.std = 0.1
-env = aq.BatchedQuad(a.envs, 0.01, 1000, training=True, direct_control=1, T=5, integrator=a.integrator)
+HKW = {"f32": dict(dtype=torch.float32), "lean": dict(dtype=torch.float64, compute="lean"), "f64": dict(dtype=torch.float64)}[a.handle]
+env = aq.BatchedQuad(a.envs, 0.01, 1000, training=True, direct_control=1, T=5, integrator=a.integrator, **HKW)
 env.robust_control = a.robust  # PolicyRollout then draws the episode parameters / gusts from Philox at every (re)start
 ro = aq.PolicyRollout(env, w, a.horizon, store_obs=True, auto_reset=True, seed=a.seed)
 ro.keep_init = a.separate_reset
-learner = aq.PpoLearner(w, lr=a.lr, deterministic=a.deterministic)
+learner = aq.PpoLearner(w, lr=a.lr, deterministic=a.deterministic, learn_std=a.learn_std)
 ro.start()
 log = open(a.log, "w") if a.log else None
 t0 = time.time()
@@ -47,7 +50,7 @@ for u in range(1, a.updates + 1):
                episodes=int(env.episodes.sum()), mean_last_return=float(env.last_return.mean()),
                loss_first=float(losses[0]["loss"]), loss_last=float(losses[-1]["loss"]))
     if a.eval_every and (u % a.eval_every == 0 or u == 1):
-        ev = aq.BatchedQuad(a.eval_envs, 0.01, 1000, training=False, direct_control=1, T=5, integrator=a.integrator)
+        ev = aq.BatchedQuad(a.eval_envs, 0.01, 1000, training=False, direct_control=1, T=5, integrator=a.integrator, **HKW)
         ev.robust_control = a.eval_robust
         er = aq.PolicyRollout(ev, aq.ActorCriticWeights(w.actor, None), 1, seed=a.seed + 77)
         er.start(ev.sample_init_states(a.seed + 1000, u))
