@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
     }
     // the bookkeeping rows are requested BEFORE the integration: one wave per SIMD is resident (register footprint), so a
     // load issued after the RK45 is a full memory round trip with nothing to hide behind.  (Measured A/B on config 4: neutral,
-    // 32.2 vs 31.5 us per launch -- the 45 % of a wave's cycles that the SQ counters show as waits are the load and store
-    // BURSTS of 2 048 waves that start and finish together: 131 072 envs x ~500 B per step in fp64 rows = 66 MB per launch.)
+    // 32.2 vs 31.5 us per launch -- the compiler had them in the first phase already; the 28 % of a wave's cycles that the
+    // SQ counters show as waits are that one phase's round trip, ~2 us with every SIMD loading at once.)
     Book<T> bk;
     if (a.mode != QENV_STEP_DYNAMICS_ONLY) load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
     prepare_action(raw, cfg, pl, w, effort, cl, act, u);
