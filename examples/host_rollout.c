@@ -1,5 +1,7 @@
 /* A C host driving libqenv.so directly: no Python, no torch -- hipMalloc'ed workspace, reset to a perturbed hover,
- * fused 250-step launches with the reference's integrator, state copied back.  Build and run on an MI355X:
+ * fused 250-step launches with the reference's integrator, state copied back.  Default: the parity-qualified handle
+ * (fp64 rows, lean fp64 arithmetic: QENV_F64 + QENV_COMPUTE_LEAN); `./host_rollout f32` runs the fp32 handle.
+ * Build and run on an MI355X:
  *
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/host_rollout.c \
  *       -Lautonomous_quadrotor_environment_amd -lqenv -L/opt/rocm/lib -lamdhip64 \
@@ -9,30 +11,36 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "qenv.h"
 
 #define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 #define CHECK_Q(x) do { int s_ = (x); if (s_ != 0) { fprintf(stderr, "%s: status %d: %s\n", #x, s_, qenv_last_error()); return 3; } } while (0)
 
-int main(void) {
+int main(int argc, char **argv) {
     const int64_t N = 65536;
+    const int f32 = argc > 1 && strcmp(argv[1], "f32") == 0;
+    const size_t esz = f32 ? sizeof(float) : sizeof(double);
     qenv_config cfg = {0};
     cfg.n_envs = N; cfg.t_step = 0.01; cfg.n_max = 100000; cfg.T = 1;
     cfg.training = 0; cfg.direct_control = 1; cfg.clipped = 1;
-    cfg.variant = QENV_MAIN; cfg.integrator = QENV_RK45; cfg.dtype = QENV_F32; cfg.compute = QENV_COMPUTE_NATIVE;
+    cfg.variant = QENV_MAIN; cfg.integrator = QENV_RK45;
+    cfg.dtype = f32 ? QENV_F32 : QENV_F64; cfg.compute = f32 ? QENV_COMPUTE_NATIVE : QENV_COMPUTE_LEAN;
     const size_t bytes = qenv_workspace_bytes(&cfg);
-    void *ws = NULL; float *x0 = NULL, *state = NULL;
+    void *ws = NULL, *x0 = NULL, *state = NULL;
     hipStream_t stream;
     CHECK_HIP(hipStreamCreate(&stream));
     CHECK_HIP(hipMalloc(&ws, bytes));
-    CHECK_HIP(hipMalloc((void **)&x0, 13 * N * sizeof(float)));
-    float *h = (float *)calloc(13 * N, sizeof(float));
+    CHECK_HIP(hipMalloc(&x0, 13 * N * esz));
+    void *h = calloc(13 * N, esz);
+#define H(i) (f32 ? (double)((float *)h)[i] : ((double *)h)[i])
+#define SETH(i, v) do { if (f32) ((float *)h)[i] = (float)(v); else ((double *)h)[i] = (double)(v); } while (0)
     for (int64_t e = 0; e < N; ++e) {             /* hover + small velocities and body rates, none exactly zero: an */
-        h[6 * N + e] = 1.0f;                      /* EXACT hover is scipy's degenerate h0 = 1e-6 path (5 sub-steps)   */
-        h[1 * N + e] = 0.05f * ((float)((e * 37) % 11 - 5) / 5.0f + 0.013f);
-        h[12 * N + e] = 0.05f * ((float)((e * 13) % 7 - 3) / 3.0f + 0.017f);
+        SETH(6 * N + e, 1.0);                     /* EXACT hover is scipy's degenerate h0 = 1e-6 path (5 sub-steps)   */
+        SETH(1 * N + e, 0.05 * ((double)((e * 37) % 11 - 5) / 5.0 + 0.013));
+        SETH(12 * N + e, 0.05 * ((double)((e * 13) % 7 - 3) / 3.0 + 0.017));
     }
-    CHECK_HIP(hipMemcpyAsync(x0, h, 13 * N * sizeof(float), hipMemcpyHostToDevice, stream));
+    CHECK_HIP(hipMemcpyAsync(x0, h, 13 * N * esz, hipMemcpyHostToDevice, stream));
     qenv_t env;
     CHECK_Q(qenv_create(&cfg, ws, bytes, stream, &env));
     CHECK_Q(qenv_reset(env, x0, NULL, NULL, NULL, 0));
@@ -44,19 +52,20 @@ int main(void) {
     for (int k = 0; k < 8; ++k) CHECK_Q(qenv_rollout(env, QENV_CTRL_CONST, 250, NULL, 0, QENV_STEP_DYNAMICS_ONLY));
     CHECK_HIP(hipEventRecord(t1, stream));
     int32_t rows = 0;
-    CHECK_Q(qenv_field(env, QENV_FIELD_STATE, (void **)&state, &rows));
-    CHECK_HIP(hipMemcpyAsync(h, state, 13 * N * sizeof(float), hipMemcpyDeviceToHost, stream));
+    CHECK_Q(qenv_field(env, QENV_FIELD_STATE, &state, &rows));
+    CHECK_HIP(hipMemcpyAsync(h, state, 13 * N * esz, hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     float ms = 0.f;
     CHECK_HIP(hipEventElapsedTime(&ms, t0, t1));
     double qn_min = 2.0, qn_max = 0.0; int finite = 1;
     for (int64_t e = 0; e < N; ++e) {
         double qn = 0;
-        for (int k = 6; k < 10; ++k) { const double v = h[k * N + e]; qn += v * v; if (!isfinite(v)) finite = 0; }
+        for (int k = 6; k < 10; ++k) { const double v = H(k * N + e); qn += v * v; if (!isfinite(v)) finite = 0; }
         if (qn < qn_min) qn_min = qn;
         if (qn > qn_max) qn_max = qn;
     }
-    printf("rows=%d finite=%d |q|^2 in [%.6f, %.6f]  %.2f G env-steps/s\n", rows, finite, qn_min, qn_max, N * 2000.0 / ms / 1e6);
+    printf("handle=%s rows=%d finite=%d |q|^2 in [%.6f, %.6f]  %.2f G env-steps/s\n", f32 ? "f32" : "lean", rows, finite, qn_min, qn_max,
+           N * 2000.0 / ms / 1e6);
     CHECK_Q(qenv_destroy(env));
     free(h);
     return (finite && rows == 13 && qn_min > 0.99 && qn_max < 1.01) ? 0 : 1;

@@ -655,8 +655,9 @@ def test_c_host_drives_the_library_without_python(tmp_path):
                         os.path.join(ROOT, "examples", "host_rollout.c"), "-L", libdir, "-lqenv", "-L", "/opt/rocm/lib", "-lamdhip64",
                         "-lm", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-800:]
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "finite=1" in r.stdout, (r.stdout, r.stderr[-500:])
+    for args, tag in (([], "handle=lean"), (["f32"], "handle=f32")):   # the parity-qualified handle first
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "finite=1" in r.stdout and tag in r.stdout, (r.stdout, r.stderr[-500:])
 
 
 def test_sharded_quad_slices_reproduce_the_global_batch(aq):
