@@ -64,6 +64,8 @@ SYMBOLS = {
     "qenv_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "qenv_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "qenv_rollout": (_i, [_vp, _i, _i, _dptr, _i, _i]),
+    "qenv_reward_function": (_i, [_vp, _i64] + [_vp] * 10),
+    "qenv_mix": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "qenv_rollout_track": (_i, [_vp, _i, _vp, _i]),
     "qenv_lqr_action": (_i, [_vp, _vp]),
     "qenv_pid_action": (_i, [_vp, _dptr, _vp]),

@@ -244,6 +244,8 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     if (!q || !p || !p->W1 || !p->out_action) return fail(QENV_ERR_ARG, "qenv_ppo_step: null argument");
     if (!q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_ppo_step: the policy commands the four rotors (direct_control=1)");
     if (q->robust) return fail(QENV_ERR_STATE, "qenv_ppo_step: robust_control episodes redraw their plant at reset; use the separate calls");
+    if (q->sens.ws) return fail(QENV_ERR_STATE, "qenv_ppo_step: a sensor is attached (qenv_attach_sensor); the fused call neither evaluates nor resets it -- use the separate calls");
+    if (q->outer.kind != QENV_OUTER_NONE) return fail(QENV_ERR_STATE, "qenv_ppo_step: an outer position loop is active; its state is not reset with the episode here -- use the separate calls");
     // the side-stream schedule is opt-in: measured on config 5 (65 536 envs, random-init policy: 1.8 % of the envs finish
     // per step) it is SLOWER than the plain sequence, 234 vs 162 us per step -- the warm-up wavefronts run 1.5x longer when
     // they share their SIMDs with the policy forward, the gathered forward of the reset envs costs 65 us and the two
@@ -312,6 +314,25 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     q->ar_pending = 1;
     q->ar_parity = next;
     return QENV_OK;
+}
+
+int qenv_reward_function(qenv_t q, int64_t n, const void* state, const void* ang, const void* action, const void* prev_shaping,
+                         const int32_t* i, const uint8_t* done_in, void* out_reward, uint8_t* out_done, int32_t* out_solved,
+                         void* out_shaping) {
+    if (!q || !state || !ang || !action || !prev_shaping || !i || !done_in || !out_reward || !out_done || !out_solved || !out_shaping)
+        return fail(QENV_ERR_ARG, "qenv_reward_function: null argument");
+    if (n <= 0) return n == 0 ? (int)QENV_OK : fail(QENV_ERR_ARG, "qenv_reward_function: negative n");
+    const void* in[6] = {state, ang, action, prev_shaping, i, done_in};
+    void* out[4] = {out_reward, out_done, out_solved, out_shaping};
+    return QENV_DISPATCH(q, do_method, q, 0, n, in, out);
+}
+
+int qenv_mix(qenv_t q, int64_t n, const void* action, void* out_w, void* out_fm, void* out_effort) {
+    if (!q || !action || !out_w || !out_fm || !out_effort) return fail(QENV_ERR_ARG, "qenv_mix: null argument");
+    if (n <= 0) return n == 0 ? (int)QENV_OK : fail(QENV_ERR_ARG, "qenv_mix: negative n");
+    const void* in[1] = {action};
+    void* out[3] = {out_w, out_fm, out_effort};
+    return QENV_DISPATCH(q, do_method, q, 1, n, in, out);
 }
 
 int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_action, int pid_first_action, int flags) {

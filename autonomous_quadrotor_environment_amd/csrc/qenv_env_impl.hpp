@@ -746,6 +746,58 @@ __global__ __launch_bounds__(256) void k_lqr_action(const T* ws, int64_t N, LqrG
     for (int k = 0; k < 4; ++k) out[(int64_t)k * N + e] = act[k];
 }
 
+// quad.done_condition() + quad.reward_function() (quadrotor_env.py:500-573, quadrotor_env_opt.py:410-480) on attributes the
+// CALLER sets -- state, ang, action, prev_shaping (NaN = None), i, done -- exactly as the reference's methods can be called
+// on a hand-set object.  The SAME device function the step kernels run (done_reward); n is the caller's, not the handle's.
+template <typename T, typename S, typename M>
+__global__ __launch_bounds__(256) void k_reward_function(int64_t n, Cfg<T> cfg, const S* state, const S* ang, const S* action,
+                                                         const S* prev_shaping, const int32_t* i_in, const uint8_t* done_in,
+                                                         S* out_reward, uint8_t* out_done, int32_t* out_solved, S* out_shaping) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    T y[13], act[4];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) y[k] = (T)state[(int64_t)k * n + e];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) act[k] = (T)action[(int64_t)k * n + e];
+    Book<T> bk;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { bk.ang[k] = (T)ang[(int64_t)k * n + e]; bk.prev_ang[k] = bk.ang[k]; bk.ang_vel[k] = T(0); }
+    const S ps = prev_shaping[e];
+    const bool has_prev = ps == ps;  // NaN: prev_shaping is None
+    bk.prev_shaping = has_prev ? (T)ps : T(0);
+    bk.abs_sum = T(0); bk.ep_return = T(0); bk.reward = T(0);
+    bk.i = i_in[e];
+    bk.flags = (done_in[e] ? FLAG_DONE : 0) | (has_prev ? FLAG_HAS_SHAPING : 0);
+    done_reward<T, M>(y, act, act, cfg, bk);
+    out_reward[e] = (S)bk.reward;
+    out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
+    out_solved[e] = (bk.flags & FLAG_SOLVED) ? 1 : 0;
+    out_shaping[e] = (S)bk.prev_shaping;
+}
+
+// quad.f2F (direct handles, quadrotor_env.py:247-272) / quad.f2w (indirect, :197-245) through prepare_action, the function
+// every step kernel starts with: rotor speeds w, the thrust / moments the RHS integrates, step_effort.
+template <typename T, typename S, bool LEAN>
+__global__ __launch_bounds__(256) void k_mix(int64_t n, Cfg<T> cfg, const S* action, S* out_w, S* out_fm, S* out_effort) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    T raw[4], w[4], effort[4], cl[4], act[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[k] = (T)action[(int64_t)k * n + e];
+    Act<T> u;
+    Plant<T, false, LEAN> pl;
+    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
+    prepare_action(raw, cfg, pl, w, effort, cl, act, u);
+    const T fm[4] = {u.F, u.Mx, u.My, u.Mz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out_w[(int64_t)k * n + e] = (S)w[k];
+        out_fm[(int64_t)k * n + e] = (S)fm[k];
+        out_effort[(int64_t)k * n + e] = (S)effort[k];
+    }
+}
+
 template <typename T, typename M = Mth<T>>
 __global__ __launch_bounds__(256) void k_pid_action(T* ws, int64_t N, PidGains<T> g, T t0, T t1, T t2, T t3, T t_step,
                                                     T* out) {
@@ -1160,13 +1212,29 @@ template <typename T, typename S, bool LEAN = false> int do_reset(qenv_s* q, con
 }
 
 
+// qenv_reward_function / qenv_mix: the reference's methods on caller-set attributes (what = 0 / 1)
+template <typename T, typename S, bool LEAN> int do_method(qenv_s* q, int what, int64_t n, const void* const* in, void* const* out) {
+    using M = typename MathSel<T, LEAN>::type;
+    const Cfg<T> c = make_cfg<T>(q);
+    const dim3 g = grid_for(n), b(256);
+    if (what == 0) {
+        hipLaunchKernelGGL((k_reward_function<T, S, M>), g, b, 0, q->stream, n, c, (const S*)in[0], (const S*)in[1], (const S*)in[2],
+                           (const S*)in[3], (const int32_t*)in[4], (const uint8_t*)in[5], (S*)out[0], (uint8_t*)out[1],
+                           (int32_t*)out[2], (S*)out[3]);
+        return check_launch("k_reward_function");
+    }
+    hipLaunchKernelGGL((k_mix<T, S, LEAN>), g, b, 0, q->stream, n, c, (const S*)in[0], (S*)out[0], (S*)out[1], (S*)out[2]);
+    return check_launch("k_mix");
+}
+
 // The env kernels are compiled in four translation units (fp32, mixed, fp64, lean fp64), each instantiating the host
 // templates of its own (arithmetic, storage) pair; every other unit only sees these declarations.
 #define QENV_ENV_INSTANCES(X, T, S, LEAN)                                                                                \
     X template int do_step<T, S, LEAN>(qenv_s*, const void*, const uint8_t*, void*, void*, uint8_t*, void*, int, int,    \
                                        const StepExtra*);                                                                \
     X template int do_rollout<T, S, LEAN>(qenv_s*, int, int, const double*, int, int, const void*);                      \
-    X template int do_reset<T, S, LEAN>(qenv_s*, const void*, const uint8_t*, void*, void*, int, const ResetSample*);
+    X template int do_reset<T, S, LEAN>(qenv_s*, const void*, const uint8_t*, void*, void*, int, const ResetSample*);     \
+    X template int do_method<T, S, LEAN>(qenv_s*, int, int64_t, const void* const*, void* const*);
 #ifndef QENV_ENV_UNIT_F32
 QENV_ENV_INSTANCES(extern, float, float, false)
 #endif

@@ -125,18 +125,22 @@ inline thread_local char g_err[256] = "";
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call (a few microseconds of host time on every launch of the
 // small-batch paths): the opt-in is per function and sticky, so it is made only when a launch needs more than was granted
 static inline hipError_t allow_dynamic_lds(const void* fn, size_t bytes) {
-    struct Slot { const void* fn; size_t bytes; };
-    static thread_local Slot cache[64] = {};
+    // the attribute belongs to the function ON THE CURRENT DEVICE: the device is part of the key (one thread may drive
+    // handles on several GPUs)
+    struct Slot { const void* fn; int dev; size_t bytes; };
+    static thread_local Slot cache[128] = {};
     static thread_local int n = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
     for (int i = 0; i < n; ++i)
-        if (cache[i].fn == fn) {
+        if (cache[i].fn == fn && cache[i].dev == dev) {
             if (bytes <= cache[i].bytes) return hipSuccess;
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e == hipSuccess) cache[i].bytes = bytes;
             return e;
         }
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess && n < 64) cache[n++] = Slot{fn, bytes};
+    if (e == hipSuccess && dev >= 0 && n < 128) cache[n++] = Slot{fn, dev, bytes};
     return e;
 }
 

@@ -32,7 +32,10 @@ def init_process_group_from_env(backend=None):
         local = local % max(1, torch.cuda.device_count())  # rehearsals with more ranks than GPUs (gloo only)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:  # every launcher (torchrun, bench.py's self-launch, the tests) sets it: a
+            raise RuntimeError(              # silently assumed fixed port would let two jobs on one host meet
+                "WORLD_SIZE > 1 but MASTER_PORT is not set: launch the ranks with `python -m torch.distributed.run "
+                "--master-addr 127.0.0.1 --master-port <free port> ...` (or `bench.py --gpus N`, which picks one)")
         if backend is None:
             backend = os.environ.get("QENV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":

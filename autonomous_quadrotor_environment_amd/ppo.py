@@ -145,7 +145,7 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministi
 
 
 def adv_normalize(adv, stats, ddof=0):
-    """(adv - mean) / (std + 1e-5) in place from the float64 moment sums `gae(..., normalize=False, return_stats=True)`
+    """(adv - mean) / (std + 1e-10) in place from the float64 moment sums `gae(..., normalize=False, return_stats=True)`
     returned (summed over shards / all-reduced over ranks by the caller): ppo.py:139, ppo_trainer.py:146."""
     dt = L.F64 if adv.dtype == torch.float64 else L.F32
     L.check(L.lib.qenv_adv_normalize(dt, adv.numel(), L.ptr(adv), L.ptr(stats), int(ddof), _stream(adv.device)),
@@ -358,7 +358,10 @@ class PpoLearner:
         replay frees the host (no Python / launch work per epoch) but is NOT faster on the device -- 296 vs 281 us per
         epoch at 8 192 samples, 727 vs 702 at 65 536: the epoch is bound by the dependent-kernel latencies of its ~20
         small launches (weight staging, split-K tails), which a graph replays unchanged."""
-        key = tuple(t.data_ptr() for t in (obs, actions, logprobs, adv, returns)) + tuple(obs.shape)
+        # the capture bakes in the buffer pointers AND every by-value hyper-parameter of the epoch's launches
+        key = tuple(t.data_ptr() for t in (obs, actions, logprobs, adv, returns)) + tuple(obs.shape) + (
+            float(self.w.std), float(self.lr), tuple(self.betas), float(self.eps), float(self.eps_clip), float(self.c_value),
+            float(self.c_entropy), bool(self.deterministic))
         dev = obs.device
         if getattr(self, "_graph_key", None) != key:
             if getattr(self, "_step_dev", None) is None:
@@ -626,7 +629,19 @@ class StreamShardedRollout:
         self._C = C
         return out
 
+    def _join_consumer(self):
+        """First step of a horizon: the shard streams wait for everything the caller's stream has queued on the buffers
+        the next horizon overwrites (a learner update, an all-gather of the returns, adv_normalize of the last finish())."""
+        main = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            st.wait_stream(main)
+
     def step(self, deterministic=False):
+        """One step of every shard.  The rollout buffers (obs / actions / logprobs / rewards / masks / values) and the
+        tensors finish() returned are overwritten from here on: consume them on the caller's stream BEFORE the first step
+        of the next horizon (that step makes the shard streams wait for the caller's stream)."""
+        if self.ros[0].t == 0:
+            self._join_consumer()
         if not deterministic:
             if self._fast is None:
                 self._fast = self._fast_args() or False
@@ -635,8 +650,7 @@ class StreamShardedRollout:
                 for (h, per_t, std), ro in zip(self._fast, self.ros):
                     a = per_t[ro.t]
                     a.step = ro.global_step + 1
-                    if ro.w.std != std:      # a learner moved the action std since the blocks were built
-                        a.std = float(ro.w.std)
+                    a.std = float(ro.w.std)  # always: a learner / schedule may move the std (and move it back) between steps
                     L.check(L.lib.qenv_ppo_step(h, C.byref(a)), "qenv_ppo_step")
                     ro.t += 1
                     ro.global_step += 1
@@ -655,6 +669,8 @@ class StreamShardedRollout:
                 outs.append(ro.finish(ddof=ddof, group=False, bootstrap=bootstrap, deterministic=deterministic,
                                       normalize=False, return_stats=True))
             main.wait_stream(st)
+            for t in outs[-1]:  # allocated on the shard's stream, consumed on the caller's: the caching allocator must not
+                t.record_stream(main)  # hand the block to the shard's next gae() while the caller's stream still reads it
         torch.sum(torch.stack([o[2] for o in outs]), dim=0, out=self._stats)
         if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size(group) > 1:

@@ -113,12 +113,20 @@ class BatchedQuad:
     """
 
     def __init__(self, n_envs, t_step, n, training=True, euler=0, direct_control=1, T=1, clipped=True,
-                 variant="main", integrator="rk45", device="cuda", dtype=torch.float32, compute=None):
-        """compute="f32" on dtype=torch.float64 selects the mixed handle (fp64 rows, fp32 arithmetic), compute="lean"
-        the lean fp64 handle (fp64 multiply-adds, Newton-refined hardware reciprocals / square roots, guard-banded
-        fast step-size control; include/qenv.h QENV_COMPUTE_LEAN)."""
+                 variant="main", integrator="rk45", device="cuda", dtype=None, compute=None):
+        """The handle.  Default (dtype=None, compute=None): the LEAN fp64 handle -- fp64 rows, fp64 multiply-adds,
+        Newton-refined hardware reciprocals / square roots, guard-banded fast step-size control (include/qenv.h
+        QENV_COMPUTE_LEAN) -- the parity-qualified one: it holds the 1e-5 tolerance against the reference's CPU step over
+        every BASELINE config's horizon and is what bench.py measures.  Opt-in alternatives:
+        dtype=torch.float64 (compute None / "native"): IEEE fp64 arithmetic; dtype=torch.float64, compute="f32": the
+        mixed handle (fp64 rows, fp32 arithmetic); dtype=torch.float32: fp32 rows and arithmetic -- the fastest, but
+        NOT parity-qualified (1e-4 off after 100 open-loop steps)."""
+        if dtype is None:
+            dtype = torch.float64
+            if compute is None:
+                compute = "lean"
         if dtype not in (torch.float32, torch.float64):
-            raise ValueError("dtype must be torch.float32 or torch.float64")
+            raise ValueError("dtype must be None (lean fp64 handle), torch.float32 or torch.float64")
         if compute not in (None, "native", "f32", "lean") or (compute in ("f32", "lean") and dtype != torch.float64):
             raise ValueError("compute must be None/'native', or 'f32' / 'lean' together with dtype=torch.float64")
         self.device = torch.device(device)
@@ -128,6 +136,9 @@ class BatchedQuad:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.n_envs = int(n_envs)
         self.dtype = dtype
+        self.compute = compute or "native"
+        # 'lean' | 'f64' | 'mix' | 'f32' (bench.py's handle names)
+        self.handle = {"lean": "lean", "f32": "mix"}.get(compute, "f64" if dtype == torch.float64 else "f32")
         self.t_step = t_step
         self.T = int(T)
         self.n = int(n) + self.T
@@ -313,6 +324,50 @@ class BatchedQuad:
         assert tg.dim() == 2 and tg.shape[1] == 7
         self._bind()
         L.check(L.lib.qenv_rollout_track(self._h, tg.shape[0], L.ptr(tg), flags), "qenv_rollout_track")
+
+    def _rows_n(self, x, rows, name):
+        """[rows, n] (or [n, rows]) array / tensor -> contiguous device tensor [rows, n] in the handle's dtype."""
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
+        x = x.to(device=self.device, dtype=self.dtype)
+        if x.dim() == 1:
+            x = x.view(rows, -1) if rows > 1 else x.view(1, -1)
+        if x.shape[0] != rows and x.shape[1] == rows:
+            x = x.t()
+        if x.dim() != 2 or x.shape[0] != rows:
+            raise ValueError(f"{name}: expected [{rows}, n], got {tuple(x.shape)}")
+        return x.contiguous()
+
+    def reward_function(self, state, ang, action, prev_shaping, i, done):
+        """quad.done_condition() + quad.reward_function() (quadrotor_env.py:500-573 / quadrotor_env_opt.py:410-480) on
+        hand-set attributes for n samples: state [13, n], ang [3, n], action [4, n], prev_shaping [n] (NaN = None),
+        i [n], done [n]; the handle supplies variant / training / n / the done box.  The device function of the step
+        kernels.  Returns (reward [n], done bool [n], solved int32 [n], shaping [n])."""
+        st, an, ac = self._rows_n(state, 13, "state"), self._rows_n(ang, 3, "ang"), self._rows_n(action, 4, "action")
+        n = st.shape[1]
+        ps = self._rows_n(prev_shaping, 1, "prev_shaping")
+        ii = torch.as_tensor(np.asarray(i) if not isinstance(i, torch.Tensor) else i).to(device=self.device, dtype=torch.int32).contiguous()
+        d0 = torch.as_tensor(np.asarray(done) if not isinstance(done, torch.Tensor) else done).to(device=self.device).to(torch.uint8).contiguous()
+        if not (an.shape[1] == ac.shape[1] == ps.shape[1] == ii.numel() == d0.numel() == n):
+            raise ValueError("reward_function: the inputs disagree on n")
+        rew = torch.empty(n, device=self.device, dtype=self.dtype)
+        sh = torch.empty_like(rew)
+        dn = torch.empty(n, device=self.device, dtype=torch.uint8)
+        so = torch.empty(n, device=self.device, dtype=torch.int32)
+        self._bind()
+        L.check(L.lib.qenv_reward_function(self._h, n, L.ptr(st), L.ptr(an), L.ptr(ac), L.ptr(ps), L.ptr(ii), L.ptr(d0),
+                                           L.ptr(rew), L.ptr(dn), L.ptr(so), L.ptr(sh)), "qenv_reward_function")
+        return rew, dn.bool(), so, sh
+
+    def mix(self, action):
+        """quad.f2F (direct handle, quadrotor_env.py:247-272) / quad.f2w (indirect, :197-245) for n actions [4, n]
+        through the step kernels' action pre-processing.  Returns (w [4, n], [F, Mx, My, Mz] [4, n], step_effort [4, n])."""
+        ac = self._rows_n(action, 4, "action")
+        n = ac.shape[1]
+        w, fm, eff = (torch.empty(4, n, device=self.device, dtype=self.dtype) for _ in range(3))
+        self._bind()
+        L.check(L.lib.qenv_mix(self._h, n, L.ptr(ac), L.ptr(w), L.ptr(fm), L.ptr(eff)), "qenv_mix")
+        return w, fm, eff
 
     def lqr_action(self, out=None):
         out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out

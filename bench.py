@@ -27,7 +27,9 @@ with the contract fields plus `roofline`, `cpu_baseline`, `sustained` and (defau
 has finished (torch.cuda.synchronize); the MAX all-reduce over the ranks closes the bracket afterwards.
 
 --workload config5 collects the rank's env range as `--stream-shards` (default 2) shards on their own HIP streams
-(StreamShardedRollout: bit-identical to one batch, +12 %).  --no-sustained / --no-extras / --no-subconfigs /
+(StreamShardedRollout: bit-identical to one batch, +12 %).  --policy trained|random: the actor (and critic) of configs 4 / 5
+are the reference's checked-in N = 128 weights (solved/nn_old_solved_128_*.pth re-exported as arrays) or
+nn.Linear-style random-init weights (the reset-heavy variant: that policy drives envs out of the box within tens of steps).  --no-sustained / --no-extras / --no-subconfigs /
 --no-cpu-baseline trim the line for profiling runs (tools/profile_round.sh).
 """
 import argparse
@@ -62,13 +64,18 @@ WORKLOADS = {
     # PPO workloads: controller names select the runner below; bytes from SURVEY.md section 8d
     "config4": (131072, 1, "ppo_actor", 2, BYTES_FULL + 360, "lean",
                 "BASELINE configs[3]: 131072 envs/GPU (1048576 on 8), PPO actor MLP 75-128-128-4 (matrix cores, fp32-accurate) in the "
-                "loop, T=5 window, deterministic mean action, random init"),
+                "loop, T=5 window, deterministic mean action (ppo_quad_eval.py:44-62), random initial states"),
     "config5": (65536, 1, "ppo_rollout", 2, BYTES_FULL + 360 + 332 + 20, "lean",
                 "BASELINE configs[4]: 65536 envs/GPU (524288 on 8), full PPO rollout (actor+critic, Normal(mean,0.1) "
                 "Philox sampling, reward_fn, masked auto-reset) + GAE per 128-step horizon, returns all-gathered"),
 }
 MLP_FLOPS = 2 * (75 * 128 + 128 * 128 + 128 * 4)  # per env and forward: 53.0 kflop
 MFMA_F32_PEAK_TFLOPS = 157.3
+MAX_CLOCK_GHZ = 2.4
+# matrix-core instructions k_mlp<128,5,BF16=2> executes per 32-env tile: name -> (count, pipe cycles each, flops each)
+# layer 1: 4 output tiles x 5 k-steps x 6 split products; layer 2: 4 x 4 x 2 x 6; layer 3: see csrc/qenv_ppo.hip
+MLP_MFMA = {"v_mfma_f32_32x32x16_bf16": (120 + 192, 32, 2 * 32 * 32 * 16),
+            "v_mfma_f32_32x32x2_f32": (64, 64, 2 * 32 * 32 * 2)}
 HANDLES = {  # --dtype -> (torch dtype of the rows, compute mode, arithmetic type reported as `dtype`)
     "f32": (torch.float32, None, "f32"),
     "mix": (torch.float64, "f32", "f32"),
@@ -97,6 +104,8 @@ def parse(argv=None):
     p.add_argument("--no-graph", action="store_true", help="launch=step: eager launches instead of hipGraph replay")
     p.add_argument("--stream-shards", type=int, default=2,
                    help="config5: the rank's env range as this many shards on their own HIP streams (1 = one batch)")
+    p.add_argument("--policy", default="trained", choices=["trained", "random"],
+                   help="configs 4 / 5: the reference's checked-in N=128 weights (default, SURVEY.md 8d) or random-init weights")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--extras", action="store_true", help="also time the other integrators / launch modes")
@@ -109,12 +118,33 @@ def parse(argv=None):
 
 
 # ---- N > 1 without torchrun: launch the ranks, relay rank 0's line ---------------------------------------------------
+def visible_gpus():
+    """GPUs this process could use, WITHOUT touching the HIP runtime (the launcher parent must stay HIP-free: its children
+    initialise the devices): KFD topology nodes that have SIMDs, narrowed by HIP/ROCR_VISIBLE_DEVICES.  None = unknown."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return 0   # no KFD driver: no AMD GPU on this host
+    try:
+        n = 0
+        for d in os.listdir(root):
+            with open(os.path.join(root, d, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except Exception:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
-    """Parent of a plain `bench.py --gpus N`: no GPU call has happened in this process (importing torch and counting
-    devices does not initialise HIP), so the N ranks start as children through torch.distributed.run."""
+    """Parent of a plain `bench.py --gpus N`: NO HIP / torch.cuda call happens in this process -- the devices are counted
+    from sysfs -- and the N ranks start as children through torch.distributed.run."""
     backend = os.environ.get("QENV_DIST_BACKEND") or "nccl"
-    ndev = torch.cuda.device_count()
-    if backend == "nccl" and ndev < args.gpus:
+    ndev = visible_gpus()
+    if backend == "nccl" and ndev is not None and ndev < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible (one rank per GPU over RCCL; "
                          f"QENV_DIST_BACKEND=gloo rehearses more ranks than GPUs)")
     with socket.socket() as s:  # a free rendezvous port
@@ -169,14 +199,50 @@ def build_env(workload, handle, integrator, n_global, lo, hi, dev):
     return env
 
 
+POLICY_FILE = os.path.join(ROOT, "tests", "golden", "g9_mlp_N128.npz")
+
+
+def policy_arrays(policy):
+    """(actor, critic) as lists [W1, b1, W2, b2, W3, b3] of float64 arrays.  trained: the reference's checked-in
+    solved/nn_old_solved_128_32000_e8f2...pth re-exported as plain arrays by oracle/gen_golden.py (config 4's
+    actor); random: nn.Linear's default init from numpy's RandomState(1) (ActorCriticWeights.random(128, seed=1))."""
+    if policy == "trained":
+        g = np.load(POLICY_FILE, allow_pickle=False)
+        get = lambda head: [np.asarray(g[f"{head}_{l}_{p}"], dtype=np.float64) for l in (0, 2, 4) for p in ("weight", "bias")]
+        return get("actor"), get("critic")
+    rng = np.random.RandomState(1)
+
+    def lin(o, i):
+        b = 1.0 / np.sqrt(i)
+        return rng.uniform(-b, b, (o, i)), rng.uniform(-b, b, o)
+
+    def mlp(out):
+        W1, b1 = lin(128, 75); W2, b2 = lin(128, 128); W3, b3 = lin(out, 128)
+        return [W1, b1, W2, b2, W3, b3]
+    return mlp(4), mlp(1)
+
+
+def policy_label(policy):
+    return {"trained": "trained (reference's checked-in N=128 actor / critic, re-exported: tests/golden/g9_mlp_N128.npz)",
+            "random": "random(seed=1) (nn.Linear default init: the reset-heavy variant)"}[policy]
+
+
+def load_policy(policy, dev):
+    from autonomous_quadrotor_environment_amd import ActorCriticWeights
+    a, c = policy_arrays(policy)
+    w = ActorCriticWeights(a, c, dev)
+    w.std = 0.1   # action_std of ppo.py:301 (FIXED_STD)
+    return w
+
+
 def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_global, shards=1, make_env=None, n_local=0,
-                    dev=None):
+                    dev=None, policy="trained"):
     """config 4 / 5: the rollout collector of ppo.py:223-269 on the device."""
-    from autonomous_quadrotor_environment_amd import ActorCriticWeights, PolicyRollout
+    from autonomous_quadrotor_environment_amd import PolicyRollout
+    from autonomous_quadrotor_environment_amd import ActorCriticWeights
     from autonomous_quadrotor_environment_amd.distributed import all_gather_returns
     dev = env.device if env is not None else dev
-    w = ActorCriticWeights.random(128, 75, 4, device=dev, seed=1)  # random-init weights of the reference's shape
-    w.std = 0.1
+    w = load_policy(policy, dev)
     if controller == "ppo_actor":
         ro = PolicyRollout(env, ActorCriticWeights(w.actor, None, env.device), chunk)
 
@@ -334,7 +400,7 @@ def pick(total, cap, mult=1):
 
 
 def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_graph, envs, rank, world, dev,
-            min_seconds, stream_shards=1):
+            min_seconds, stream_shards=1, policy="trained"):
     """One workload on this rank's shard: W untimed warm-up steps, the K-step region repeated (median), the dominant
     kernel's per-launch time by HIP events, and its roofline block.  Returns (result dict, env, runner info)."""
     from autonomous_quadrotor_environment_amd.distributed import all_gather_returns, shard_range
@@ -369,7 +435,7 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
         if ppo:
             return make_ppo_runner(env, controller, c, graph_ok and (not no_graph) and controller == "ppo_actor",
                                    seed=4, env_offset=lo, n_global=n_global, shards=shards, make_env=make_env,
-                                   n_local=hi - lo, dev=dev)
+                                   n_local=hi - lo, dev=dev, policy=policy)
         return make_runner(env, controller, flags, launch, c, not no_graph) + (None,)
     # Episodes: the closed-loop workloads without an auto-reset (LQR / PID rollouts, actor in the loop) run EPISODES of 500
     # steps like the reference's scripts (lqr_quad.py / ppo_quad_eval.py run one episode per reset); without this the
@@ -409,9 +475,21 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
     value = n_global * steps / secs
     envs_run = [env] if shards == 1 else list(shard_envs.values())
     finite = all(bool(torch.isfinite(e.state).all()) for e in envs_run)
-    gathered = None
-    if flags != 1 and controller != "ppo_rollout":
-        gathered = all_gather_returns(env.episode_return, n_global)  # the path's one exchange step (RCCL over xGMI)
+    # the path's one exchange step (RCCL all-gather over xGMI of per-env episode returns, ppo.py:356-382's Pool gather):
+    # every workload that has rewards gathers once more after the timed region, timed by itself (config 5 also gathers
+    # inside every timed horizon)
+    gathered, gather_us = None, None
+    if flags != 1:
+        local = (torch.cat([e.last_return for e in envs_run]) if controller == "ppo_rollout"
+                 else env.episode_return)
+        all_gather_returns(local, n_global)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        gathered = all_gather_returns(local, n_global)
+        torch.cuda.synchronize()
+        gather_us = (time.perf_counter() - t0) * 1e6
 
     # dominant kernel, per-launch duration by HIP events on the launch stream
     spl = chunk if launch == "fused" else 1
@@ -446,82 +524,110 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
                             "issue_cycles_per_instruction": v["active_valu_cycles_per_inst"], "simds": 1024,
                             "clock_ghz": v["clock_ghz"],
                             "issue_frac": spw * v["valu_per_wave_step"] * v["active_valu_cycles_per_inst"] / (1024 * v["clock_ghz"] * 1e9)}
-    if ppo:  # the dominant kernel of the PPO workloads is the fp32-MFMA MLP forward
+    if ppo:  # the dominant kernel of the PPO workloads is the policy MLP forward on the matrix cores
         heads = 2 if controller == "ppo_rollout" else 1
         e0, r0 = (env, ro) if shards == 1 else (ro.ros[0].env, ro.ros[0])   # one launch = one shard's envs
         n_l = e0.n_envs
         mlp_us = kernel_launch_us(lambda: e0.mlp_forward(r0.w, "actor", out=r0.mean), 1, "fused")
-        tfl = MLP_FLOPS * n_l / (mlp_us * 1e-6) / 1e12
-        roofline = {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tfl / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "k_mlp<128,5> (actor forward)",
-                    "kernel_us": mlp_us, "flops_per_launch": MLP_FLOPS * n_l, "envs_per_launch": n_l,
-                    "mlp_forwards_per_env_step": heads,
-                    "hbm_algorithmic_GBps_whole_step": bytes_per_step * value / world / 1e9,
-                    "achieved_is": "algorithmic fp32 flops (53.0 kflop per env) / launch time against the fp32-MFMA peak; "
-                                   "layers 1 and 2 execute as 6 bf16 MFMA products of 3-way split operands (fp32-accurate, "
-                                   "see `executed`), so this fraction may exceed what an fp32-MFMA kernel could reach",
-                    "executed": {
-                        # per 32-env tile: layer 1 4x5x6 + layer 2 4x4x2x6 v_mfma_f32_32x32x16_bf16 (32 cycles each),
-                        # layer 3 64 v_mfma_f32_32x32x2_f32 (64 cycles each)
-                        "bf16_tflops": 6 * 2 * (128 * 80 + 128 * 128) * n_l / (mlp_us * 1e-6) / 1e12,
-                        "bf16_dense_peak_tflops": 2516.0,
-                        "mfma_cycles_per_tile": 120 * 32 + 192 * 32 + 64 * 64,
-                        "mfma_pipe_busy_frac_at_2.4GHz": ((n_l + 31) // 32) * (120 * 32 + 192 * 32 + 64 * 64)
-                                                          / (1024 * 2.4e9 * mlp_us * 1e-6)}}
+        t_s = mlp_us * 1e-6
+        tiles = (n_l + 31) // 32
+        cyc_tile = sum(n * c for n, c, _ in MLP_MFMA.values())
+        flop_tile = sum(n * f for n, _, f in MLP_MFMA.values())
+        busy = tiles * cyc_tile / (1024 * MAX_CLOCK_GHZ * 1e9 * t_s)
+        executed = tiles * flop_tile / t_s / 1e12
+        tfl = MLP_FLOPS * n_l / t_s / 1e12
+        roofline = {"bound": "mfma", "achieved": executed, "peak": executed / busy, "unit": "TFLOP/s", "frac": busy,
+                    "traffic": None, "kernel": "k_mlp<128,5> (actor forward)", "kernel_us": mlp_us,
+                    "envs_per_launch": n_l, "mlp_forwards_per_env_step": heads,
+                    "achieved_is": "EXECUTED matrix-core flops per launch (the instruction mix below, padded tiles included) / "
+                                   "launch time; `peak` = that same mix with the matrix pipe of all 1024 SIMDs busy every cycle "
+                                   f"at {MAX_CLOCK_GHZ} GHz, so `frac` = matrix-pipe busy fraction (at the nominal clock: a lower "
+                                   "bound of the busy fraction at the clock the chip really holds)",
+                    "mfma_per_32env_tile": {k: {"count": n, "pipe_cycles_each": c} for k, (n, c, _) in MLP_MFMA.items()},
+                    "mfma_cycles_per_tile": cyc_tile,
+                    "bf16_products_tflops": MLP_MFMA["v_mfma_f32_32x32x16_bf16"][0] * MLP_MFMA["v_mfma_f32_32x32x16_bf16"][2]
+                                            * tiles / t_s / 1e12,
+                    "bf16_dense_peak_tflops": 2516.0,
+                    "algorithmic": {"fp32_tflops": tfl, "flops_per_env": MLP_FLOPS,
+                                    "note": "53.0 kflop per env and forward (SURVEY 8a a20) / launch time; NOT a roofline "
+                                            "fraction of anything: layers 1-2 run as 6 bf16 products of 3-way split fp32 "
+                                            "operands (fp32-accurate), i.e. ~6x the algorithmic flops on a 16x faster pipe"},
+                    "hbm_algorithmic_GBps_whole_step": bytes_per_step * value / world / 1e9}
     res = {"value": value, "ms_per_step": secs / steps * 1e3, "regions": len(regions),
            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3,
            "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,
            "hip_graph": (launch == "step" and not no_graph and controller != "ppo_rollout"),
            "envs_per_gpu": hi - lo, "global_envs": n_global, "controller": controller, "desc": desc, "roofline": roofline,
-           "all_gather_len": None if gathered is None else int(gathered.numel()), "stream_shards": shards,
-           "episode_steps": EPISODE_STEPS if episodic else None}
+           "all_gather_len": None if gathered is None else int(gathered.numel()), "all_gather_us": gather_us,
+           "stream_shards": shards, "episode_steps": EPISODE_STEPS if episodic else None,
+           "weights": (policy_label(policy) if ppo else None)}
     return res, env, (controller, flags, no_graph, bytes_per_step, n_global)
 
 
-def cpu_baseline(workload, integrator, seconds):
-    """The fp64 C oracle (a port of the reference's algorithm, pinned by the reference's golden
-    vectors) timed on this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(workload, integrator, seconds, policy="trained", steps=1000):
+    """The C oracle (a port of the reference's algorithm, pinned by the reference's golden vectors) timed on this host's
+    cores on a bounded sample of the same workload: the fp64 build on one thread and on all the cores
+    this process may use, and the fp32 build of the same source on all cores.  `seconds` bounds the whole call."""
     from oracle import quad_oracle as qo
     qo.build()
     _, direct, controller, _, _, _, _ = WORKLOADS[workload]
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box's CPU share for one GPU is 16
     x0 = make_init(workload, 4096 * threads, 0, 4096 * threads)
-    if controller.startswith("ppo"):  # actor (+ critic for config 5) MLP in the loop, same random-init weights
-        rng = np.random.RandomState(1)  # the draw order of ActorCriticWeights.random(128, seed=1)
-
-        def lin(o, i):
-            b = 1.0 / np.sqrt(i)
-            return rng.uniform(-b, b, (o, i)), rng.uniform(-b, b, o)
-
-        def mlp(out):
-            W1, b1 = lin(128, 75); W2, b2 = lin(128, 128); W3, b3 = lin(out, 128)
-            return [W1, b1, W2, b2, W3, b3]
-        actor, critic = mlp(4), mlp(1)
-        batch = lambda c, n: qo.batch_ppo(c, n, actor, critic if controller == "ppo_rollout" else None, T=5,
-                                          integrator=integrator)
+    if controller.startswith("ppo"):  # actor (+ critic for config 5) MLP in the loop, the same weights as the GPU run
+        actor, critic = policy_arrays(policy)
+        batch = lambda c, n, f32=False: qo.batch_ppo(c, n, actor, critic if controller == "ppo_rollout" else None, T=5,
+                                                     integrator=integrator, fp32=f32)
     else:
         ctrl = {"const": 0, "lqr": 1, "pid": 2}[controller]
-        batch = lambda c, n: qo.batch_rollout(c, n, direct=direct, integrator=integrator, controller=ctrl)
-    # calibrate, then size the sample for ~`seconds` of wall time
+        batch = lambda c, n, f32=False: qo.batch_rollout(c, n, direct=direct, integrator=integrator, controller=ctrl,
+                                                         fp32=f32)
+    # calibrate on one thread (this IS the single-thread figure), then size the samples: ~40 % of the budget for fp64 on
+    # all cores, ~30 % for fp32 on all cores
+    n1 = 64 if seconds >= 4 else 16
     t0 = time.perf_counter()
-    batch(x0[:64], 50)
-    rate1 = 64 * 50 / (time.perf_counter() - t0)
-    steps = 1000
-    per_thread = int(max(64, min(4096, rate1 * seconds / steps)))
-    chunks = [x0[k * per_thread:(k + 1) * per_thread] for k in range(threads)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
-        list(ex.map(lambda c: batch(c, steps), chunks))
-    dt = time.perf_counter() - t0
-    total = threads * per_thread * steps
-    return {"value": total / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{threads} threads x {per_thread} envs x {steps} steps of {workload} ({integrator})",
+    batch(x0[:n1], 50)
+    rate1 = n1 * 50 / (time.perf_counter() - t0)
+
+    def all_cores(f32, budget):
+        per_thread = int(max(8, min(4096, rate1 * budget / steps)))
+        chunks = [x0[k * per_thread:(k + 1) * per_thread] for k in range(threads)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
+            list(ex.map(lambda c: batch(c, steps, f32), chunks))
+        dt = time.perf_counter() - t0
+        return threads * per_thread * steps / dt, per_thread, dt
+    v64, per64, dt64 = all_cores(False, 0.4 * seconds)
+    v32, per32, dt32 = all_cores(True, 0.3 * seconds)
+    return {"value": v64, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} threads x {per64} envs x {steps} steps of {workload} ({integrator}), fp64 build",
             "what": "fp64 C restatement of the reference (the oracle/ directory), pinned by reference-generated fixtures",
-            "threads": threads, "envs_per_thread": per_thread, "steps": steps, "seconds": dt,
+            "threads": threads, "envs_per_thread": per64, "steps": steps, "seconds": dt64,
             "single_thread_rate": rate1,
+            "fp32_build": {"value": v32, "cores": threads, "seconds": dt32,
+                           "sample": f"{threads} threads x {per32} envs x {steps} steps, float build of the same source",
+                           "what": "the float build of the same C source (oracle/: double read as float): float storage and arithmetic (timing baseline only; parity is "
+                                   "judged on the fp64 build)"},
+            "weights": policy_label(policy) if controller.startswith("ppo") else None,
             "reference_python_rate": 800.0,
             "reference_python_rate_source": "the reference's own Python step, measured in the survey container per core "
                                             "(BASELINE.md section 3); it cannot travel to the GPU box"}
+
+
+def slice_of(r, name, handle):
+    """A `configs` entry from a measure() result."""
+    rf = r["roofline"]
+    out = {"value": r["value"], "unit": "env-steps/s (whole job)" if r["global_envs"] != r["envs_per_gpu"]
+           else "env-steps/s (one GPU's slice)", "ms_per_step": r["ms_per_step"],
+           "regions": r["regions"], "envs_per_gpu": r["envs_per_gpu"], "global_envs": r["global_envs"], "handle": handle,
+           "workload": r["desc"], "weights": r["weights"], "finite": r["finite"], "dominant_kernel": rf["kernel"],
+           "kernel_us": rf["kernel_us"], "bound": rf["bound"], "frac": rf["frac"],
+           "achieved": rf["achieved"], "roofline_unit": rf["unit"], "stream_shards": r["stream_shards"],
+           "episode_steps": r["episode_steps"], "envs_per_kernel_launch": rf.get("envs_per_launch", r["envs_per_gpu"]),
+           "all_gathered_returns": r["all_gather_len"], "all_gather_us": r["all_gather_us"]}
+    for k in ("valu", "mfma_cycles_per_tile", "algorithmic", "bf16_products_tflops"):
+        if k in rf:
+            out[k] = rf[k]
+    return out
 
 
 def main():
@@ -541,7 +647,7 @@ def main():
 
     res, env, (controller, flags, no_graph, bytes_per_step, n_global) = measure(
         args.workload, handle, args.integrator, args.launch, args.steps, args.warmup, args.chunk, args.no_graph,
-        args.envs, rank, world, dev, args.min_seconds, args.stream_shards)
+        args.envs, rank, world, dev, args.min_seconds, args.stream_shards, args.policy)
     ppo = controller.startswith("ppo")
     qualified = WORKLOADS[args.workload][5]
     out = {
@@ -558,8 +664,8 @@ def main():
                    "steps_per_graph_replay_or_launch": res["chunk"], "hip_graph": res["hip_graph"],
                    "parallelism": f"env-sharded x{world}", "stream_shards_per_gpu": res["stream_shards"],
                    "episode_steps": res["episode_steps"],
-                   "finite": res["finite"],
-                   "all_gathered_returns": res["all_gather_len"]},
+                   "finite": res["finite"], "weights": res["weights"],
+                   "all_gathered_returns": res["all_gather_len"], "all_gather_us": res["all_gather_us"]},
         "timing": {"regions": res["regions"], "statistic": "median of the K-step regions (each barrier+sync bracketed)",
                    "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
                    "timed_seconds": res["timed_seconds"]},
@@ -635,26 +741,37 @@ def main():
         out["roofline"]["measured_row_copy_GBps"] = round(2 * 13 * n_c * 4 * 10 / (a_.elapsed_time(b_) * 1e-3) / 1e9, 1)
         del src, dst
 
-    # short per-GPU slices of the other BASELINE configs (LQR full step, PPO actor in the loop, full PPO rollout + GAE):
-    # the driver's record then covers the 224-B step, the controller and the MLP, each on its qualified handle
-    if args.workload == "config2" and world == 1 and not args.no_subconfigs and args.envs == 0:
+    # short per-GPU slices of the other BASELINE configs (LQR full step, PPO actor in the loop, full PPO rollout + GAE), each
+    # on its qualified handle: the driver's record then covers the 224-B step, the controller and the MLP.  One GPU: config
+    # 3, config 4 (trained actor) and its random-policy variant, config 5 (trained and random policy), each with a ~1 s CPU
+    # baseline beside it.  N > 1: BASELINE defines configs 4 and 5 on the whole node -- they run at their per-GPU sizes on
+    # every rank (max-over-ranks timing, like `value`) and end with the RCCL all-gather of the episode returns, whose
+    # length and own time are in the slice.
+    if args.workload == "config2" and not args.no_subconfigs and args.envs == 0:
         subs = {}
-        for name, k_steps, w_steps in (("config3", 250, 250), ("config4", 250, 50), ("config5", 128, 128)):
-            r, e_, _ = measure(name, WORKLOADS[name][5], "rk45", "fused", k_steps, w_steps, 0, False, 0, 0, 1, dev, 0.2,
-                               args.stream_shards)
-            rf = r["roofline"]
-            subs[name] = {"value": r["value"], "unit": "env-steps/s (one GPU's slice)", "ms_per_step": r["ms_per_step"],
-                          "steps": k_steps, "regions": r["regions"], "envs": r["envs_per_gpu"], "handle": WORKLOADS[name][5],
-                          "workload": r["desc"], "finite": r["finite"], "dominant_kernel": rf["kernel"],
-                          "kernel_us": rf["kernel_us"], "bound": rf["bound"], "frac": rf["frac"],
-                          "achieved": rf["achieved"], "roofline_unit": rf["unit"], "stream_shards": r["stream_shards"],
-                          "episode_steps": r["episode_steps"],
-                          "envs_per_kernel_launch": rf.get("envs_per_launch", r["envs_per_gpu"])}
+        if world == 1:
+            plan = (("config3", "config3", 250, 250, None), ("config4", "config4", 250, 50, "trained"),
+                    ("config4_random_policy", "config4", 250, 50, "random"), ("config5", "config5", 128, 128, "trained"),
+                    ("config5_random_policy", "config5", 128, 128, "random"))
+        else:
+            plan = (("config4", "config4", 250, 50, "trained"), ("config5", "config5", 128, 128, "trained"))
+        for key, name, k_steps, w_steps, pol in plan:
+            r, e_, _ = measure(name, WORKLOADS[name][5], "rk45", "fused", k_steps, w_steps, 0, False, 0, rank, world, dev, 0.2,
+                               args.stream_shards, pol or "trained")
+            subs[key] = slice_of(r, name, WORKLOADS[name][5])
+            subs[key]["steps"] = k_steps
             del e_
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                c = cpu_baseline(name, "rk45", 1.5, pol or "trained", steps=100)
+                subs[key]["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample", "single_thread_rate",
+                                                               "fp32_build")}
         out["configs"] = subs
+    if world > 1:
+        out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+        out["dist_backend"] = dist.get_backend()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, args.integrator, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.integrator, args.cpu_seconds, args.policy)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

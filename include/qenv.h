@@ -183,6 +183,26 @@ int qenv_reset(qenv_t q, const void *init_states, const uint8_t *mask, void *out
 int qenv_step(qenv_t q, const void *actions, void *out_obs, void *out_reward, uint8_t *out_done,
               void *out_mask, int flags);
 
+/* quad.done_condition() followed by quad.reward_function() -- quadrotor_env.py:500-573 (MAIN),
+ * quadrotor_env_opt.py:410-480 (OPT) -- on attributes the CALLER sets, the way the reference's
+ * methods can be invoked on a hand-set object (its reward-branch table is built like that):
+ *   state [13][n], ang [3][n], action [4][n] (self.action), prev_shaping [n] (NaN = None) in the
+ *   handle's dtype; i int32 [n] (self.i); done_in uint8 [n] (self.done before the calls).
+ * The handle supplies the configuration the methods read (variant, training, n + T, the done
+ * box, zero_control); n is independent of the handle's n_envs.  Runs the device function the
+ * step kernels run.  Outputs: reward [n], done uint8 [n], solved int32 [n], shaping [n]
+ * (= self.prev_shaping afterwards). */
+int qenv_reward_function(qenv_t q, int64_t n, const void *state, const void *ang, const void *action,
+                         const void *prev_shaping, const int32_t *i, const uint8_t *done_in,
+                         void *out_reward, uint8_t *out_done, int32_t *out_solved, void *out_shaping);
+
+/* quad.f2F(action) on a direct_control handle (quadrotor_env.py:247-272) / quad.f2w(action[0],
+ * action[1:]) on an indirect one (:197-245; quadrotor_env_opt.py:144-176) for n actions [4][n],
+ * through the action pre-processing every step kernel starts with (clip to [-1, 1] / rotor
+ * saturation per the handle's `clipped`).  out_w [4][n]: rotor speeds; out_fm [4][n]: the
+ * [F, Mx, My, Mz] the dynamics integrate (f2w: FM_new); out_effort [4][n]: step_effort. */
+int qenv_mix(qenv_t q, int64_t n, const void *action, void *out_w, void *out_fm, void *out_effort);
+
 /* n_steps fused steps in ONE launch with the controller evaluated on device and the
  * state held in registers between steps -- the loop bodies of lqr_quad.py:123-168 and
  * pid_vel_control.py:141-164 (both ignore `done` and keep stepping), or a constant

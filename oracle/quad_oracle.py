@@ -21,10 +21,15 @@ INTEGRATORS = {"rk45": INT_RK45, "dp5": INT_DP5, "rk4": INT_RK4}
 _dp = C.POINTER(C.c_double)
 
 
+_SO_F32 = os.path.join(_HERE, "_build", "libquad_oracle_f32.so")
+
+
 def build(force=False):
     """Compile the oracle with gcc (seconds).  Safe to call repeatedly."""
     src = os.path.join(_HERE, "quad_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [src, os.path.join(_HERE, "quad_oracle_f32.c"), os.path.join(_HERE, "Makefile")]
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs)
+                    for so in (_SO, _SO_F32)):
         subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL,
                               stderr=subprocess.DEVNULL)
     return _SO
@@ -185,32 +190,50 @@ def random_init_states(seed_or_rng, n_envs=1):
     return out
 
 
+_lib32 = None
+
+
+def lib_f32():
+    """The fp32 build (quad_oracle_f32.c): batch drivers only, float arrays."""
+    global _lib32
+    if _lib32 is None:
+        build()
+        _lib32 = C.CDLL(_SO_F32)
+        _lib32.qo_batch_rollout.restype = C.c_long
+        _lib32.qo_batch_ppo.restype = C.c_long
+    return _lib32
+
+
 def batch_rollout(states, steps, t_step=0.01, direct=1, variant=VARIANT_MAIN, integrator="rk45",
-                  controller=0, act=None):
+                  controller=0, act=None, fp32=False):
     """N independent envs advanced `steps` steps (after reset's single warm-up step).
-    controller: 0 constant action, 1 LQR, 2 PID.  Returns (final states [N,13], reward sums [N])."""
-    s = np.array(states, dtype=np.float64, order="C").reshape(-1, 13)
-    rs = np.zeros(s.shape[0])
-    act = _a(np.zeros(4) if act is None else act, 4)
-    lib().qo_batch_rollout(s.shape[0], int(steps), C.c_double(t_step), int(direct), int(variant),
-                           INTEGRATORS[integrator], int(controller), _p(act), _p(s), _p(rs))
+    controller: 0 constant action, 1 LQR, 2 PID.  Returns (final states [N,13], reward sums [N]).
+    fp32: the float build of the same source (CPU-baseline timing only)."""
+    ft, ct, L = (np.float32, C.c_float, lib_f32()) if fp32 else (np.float64, C.c_double, lib())
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    s = np.array(states, dtype=ft, order="C").reshape(-1, 13)
+    rs = np.zeros(s.shape[0], dtype=ft)
+    act = np.ascontiguousarray(np.zeros(4) if act is None else act, dtype=ft)
+    assert act.size == 4
+    L.qo_batch_rollout(s.shape[0], int(steps), ct(t_step), int(direct), int(variant),
+                       INTEGRATORS[integrator], int(controller), vp(act), vp(s), vp(rs))
     return s, rs
 
 
-def batch_ppo(states, steps, actor, critic=None, T=5, t_step=0.01, integrator="rk45"):
+def batch_ppo(states, steps, actor, critic=None, T=5, t_step=0.01, integrator="rk45", fp32=False):
     """N envs with the actor (and optionally the critic) MLP in the loop; weights = lists
     [W1, b1, W2, b2, W3, b3] (torch layout).  Returns (final states [N,13], value sums [N])."""
-    s = np.array(states, dtype=np.float64, order="C").reshape(-1, 13)
-    vs = np.zeros(s.shape[0])
-    a = [_a(w) for w in actor]
-    c = [_a(w) for w in critic] if critic is not None else [None] * 6
-    pp = lambda x: None if x is None else _p(x)
-    lib().qo_batch_ppo(s.shape[0], int(steps), C.c_double(t_step), INTEGRATORS[integrator], int(T), int(a[0].shape[0]),
-                       *[pp(x) for x in a], *[pp(x) for x in c], _p(s), _p(vs))
+    ft, ct, L = (np.float32, C.c_float, lib_f32()) if fp32 else (np.float64, C.c_double, lib())
+    vp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    s = np.array(states, dtype=ft, order="C").reshape(-1, 13)
+    vs = np.zeros(s.shape[0], dtype=ft)
+    a = [np.ascontiguousarray(w, dtype=ft) for w in actor]
+    c = [np.ascontiguousarray(w, dtype=ft) for w in critic] if critic is not None else [None] * 6
+    L.qo_batch_ppo(s.shape[0], int(steps), ct(t_step), INTEGRATORS[integrator], int(T), int(a[0].shape[0]),
+                   *[vp(x) for x in a], *[vp(x) for x in c], vp(s), vp(vs))
     return s, vs
 
 
-# ---- quad-compatible class ------------------------------------------------------
 class OracleQuad:
     """Same call surface as reference ``quad`` (quadrotor_env.py:111-577).
 

@@ -13,6 +13,14 @@ import torch.multiprocessing as mp
 from .conftest import ROOT
 
 
+def _free_port():
+    """A rendezvous port the OS hands out (no fixed numbers: two test runs on one host must not collide)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _worker(rank, world, port, n_global, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -36,7 +44,7 @@ def _worker(rank, world, port, n_global, q):
 def test_all_gather_returns_world2(n_global):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + (n_global % 17)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -73,7 +81,8 @@ def test_gradient_bucket_all_reduce_world2():
     back as the mean over the ranks, in place, through the per-tensor views the Adam kernel reads."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, 29733, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

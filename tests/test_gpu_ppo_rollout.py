@@ -309,7 +309,12 @@ def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden, fused):
             assert torch.allclose(w.head(head)[kb], lin.bias, rtol=0, atol=2e-7)
 
 
-def test_full_size_ppo_rollout_properties_config5(aq):
+HANDLES = {"lean": dict(dtype=torch.float64, compute="lean"), "f32": dict(dtype=torch.float32)}
+
+
+@pytest.mark.parametrize("handle", ["lean", "f32"])
+@pytest.mark.parametrize("policy", ["random", "trained"])
+def test_full_size_ppo_rollout_properties_config5(aq, handle, policy):
     """BASELINE configs[4] at its per-GPU size (65 536 envs, T=5, N=128 actor + critic, Normal(mean, 0.1) Philox
     sampling, masked auto-reset, GAE): size-independent properties instead of an oracle that would need hours --
     (i) replay: the same seed gives the same bits; (ii) shard invariance: a 16 384-env shard with its env_offset
@@ -317,11 +322,15 @@ def test_full_size_ppo_rollout_properties_config5(aq):
     identity returns - raw advantage = V and the reverse-scan recurrence, checked on device tensors; (iv) masks =
     1 - done and the episode counter equals the number of zeros in the masks."""
     N, S = 65536, 24
-    w = aq.ActorCriticWeights.random(128, 75, 4, seed=1)
+    # bench.py's two policies: the reference's trained N=128 weights (reset-light) and random-init ones (reset-heavy), on
+    # the handle bench.py measures on (lean) and on fp32
+    w = _weights(aq)[0] if policy == "trained" else aq.ActorCriticWeights.random(128, 75, 4, seed=1)
     w.std = 0.1
 
     def run(n, lo):
-        env = aq.BatchedQuad(n, 0.01, 40, training=True, direct_control=1, T=5)
+        # random policy: 40-step episodes, the resets come from bounding-box exits; trained policy: 12-step episodes, so
+        # that every env also passes through a time-out reset inside the 24 steps
+        env = aq.BatchedQuad(n, 0.01, 40 if policy == "random" else 12, training=True, direct_control=1, T=5, **HANDLES[handle])
         ro = aq.PolicyRollout(env, w, S, auto_reset=True, seed=5, env_offset=lo)
         ro.start()
         for _ in range(S):
@@ -344,23 +353,25 @@ def test_full_size_ppo_rollout_properties_config5(aq):
     ret, adv = gae(vals, ro.masks, ro.rewards, ddof=0, normalize=False, group=False)
     assert torch.allclose(ret - adv, vals[:S], atol=1e-5)
     delta = ro.rewards + 0.99 * vals[1:] * ro.masks - vals[:S]
-    g_next = torch.cat([adv[1:], torch.zeros(1, N, device="cuda")])
+    g_next = torch.cat([adv[1:], torch.zeros(1, N, device="cuda", dtype=adv.dtype)])
     assert torch.allclose(adv, delta + 0.99 * 0.99 * ro.masks * g_next, atol=2e-3, rtol=1e-5)
     assert int((ro.masks == 0).sum()) == int(env.episodes.sum())
-    assert int(env.episodes.sum()) > 1000  # bounding-box exits of the random policy: thousands of masked resets at this size
+    # episodes end through the bounding box (random policy: thousands at this size), the 40-step limit, or the solved box
+    assert int(env.episodes.sum()) > 1000
 
 
-def test_full_size_actor_in_loop_is_batch_position_independent_config4(aq):
+@pytest.mark.parametrize("handle", ["lean", "f32"])
+def test_full_size_actor_in_loop_is_batch_position_independent_config4(aq, handle):
     """BASELINE configs[3] at its per-GPU size (131 072 envs, deterministic actor in the loop): the trajectory of an
     env does not depend on how many other envs share its launch (tiles, grid-stride order, workgroup) -- the first
     4 096 envs alone reproduce rows [0, 4096) of the full batch bit for bit over 20 steps."""
     from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
     N, n = 131072, 4096
-    w = aq.ActorCriticWeights.random(128, 75, 4, seed=1)
-    x0 = torch.from_numpy(np.ascontiguousarray(fast_random_init_states(4, N).T)).to("cuda", torch.float32)
+    w = _weights(aq)[0]  # config 4's actor: the reference's checked-in N=128 weights (SURVEY.md 8d)
+    x0 = torch.from_numpy(np.ascontiguousarray(fast_random_init_states(4, N).T)).to("cuda", HANDLES[handle]["dtype"])
 
     def run(cnt):
-        env = aq.BatchedQuad(cnt, 0.01, 1000, training=False, direct_control=1, T=5)
+        env = aq.BatchedQuad(cnt, 0.01, 1000, training=False, direct_control=1, T=5, **HANDLES[handle])
         ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None), 20)
         ro.start(x0[:, :cnt].contiguous())
         for _ in range(20):
@@ -644,6 +655,30 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["config"]["global_envs"] == 2 * 8192
     assert d["config"]["all_gathered_returns"] == 2 * 8192 and d["config"]["finite"]
     assert d["value"] > 0 and d["timing"]["regions"] >= 1
+    assert d["dist_backend"] == "gloo" and d["rccl_ranks"] == 0   # under nccl: rccl_ranks == n_gpus
+
+
+def test_bench_gpus2_default_line_carries_config4_and_config5_with_the_all_gather():
+    """The default workload under --gpus 2 (what a SCALE run launches, gloo here): besides config 2 the line carries
+    BASELINE's two node-level configs at their per-GPU sizes -- config 4 (trained actor in the loop) and config 5 (full PPO
+    rollout + GAE) -- each ending in the all-gather of the episode returns with the GLOBAL length, and the gather's time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["QENV_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--min-seconds", "0.05", "--no-sustained"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * 65536 and d["config"]["handle"] == "lean"
+    c4, c5 = d["configs"]["config4"], d["configs"]["config5"]
+    assert c4["global_envs"] == 2 * 131072 and c4["all_gathered_returns"] == 2 * 131072 and c4["finite"]
+    assert c5["global_envs"] == 2 * 65536 and c5["all_gathered_returns"] == 2 * 65536 and c5["finite"]
+    assert c4["weights"].startswith("trained") and c5["weights"].startswith("trained")
+    assert c4["all_gather_us"] > 0 and c5["all_gather_us"] > 0 and c4["value"] > 0 and c5["value"] > 0
 
 
 @pytest.mark.parametrize("overlap", ["0", "1"])
