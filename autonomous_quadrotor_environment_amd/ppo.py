@@ -123,7 +123,9 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministi
     n, N = rewards.shape
     assert values.shape == (n + 1, N) and masks.shape == (n, N)
     dt = L.F64 if values.dtype == torch.float64 else L.F32
-    values, masks, rewards = values.contiguous(), masks.to(values.dtype).contiguous(), rewards.contiguous()
+    if values.dtype not in (torch.float32, torch.float64):
+        raise ValueError("gae: values must be float32 or float64")
+    values, masks, rewards = values.contiguous(), masks.to(values.dtype).contiguous(), rewards.to(values.dtype).contiguous()
     ret = torch.empty_like(rewards)
     adv = torch.empty_like(rewards)
     stats = torch.zeros(3, dtype=torch.float64, device=values.device)
@@ -147,6 +149,8 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministi
 def adv_normalize(adv, stats, ddof=0):
     """(adv - mean) / (std + 1e-10) in place from the float64 moment sums `gae(..., normalize=False, return_stats=True)`
     returned (summed over shards / all-reduced over ranks by the caller): ppo.py:139, ppo_trainer.py:146."""
+    if adv.dtype not in (torch.float32, torch.float64) or not adv.is_contiguous() or stats.dtype != torch.float64 or stats.numel() < 3:
+        raise ValueError("adv_normalize: adv must be a contiguous float32 / float64 tensor, stats three float64 sums")
     dt = L.F64 if adv.dtype == torch.float64 else L.F32
     L.check(L.lib.qenv_adv_normalize(dt, adv.numel(), L.ptr(adv), L.ptr(stats), int(ddof), _stream(adv.device)),
             "qenv_adv_normalize")
@@ -162,6 +166,8 @@ def dense_tail(x, weights, final_tanh=True, out=None):
     assert W1.shape[1] == K and x.dtype == torch.float32
     x = x.contiguous()
     out = torch.empty(W3.shape[0], N, device=x.device, dtype=torch.float32) if out is None else out
+    if tuple(out.shape) != (W3.shape[0], N) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError(f"dense_tail: out must be a contiguous float32 [{W3.shape[0]}, {N}] tensor on {x.device}")
     stream = _stream(x.device)
     L.check(L.lib.qenv_dense_tail(N, K, W1.shape[0], W3.shape[0], int(bool(final_tanh)), L.ptr(x), L.ptr(W1), L.ptr(b1),
                                   L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), stream), "qenv_dense_tail")

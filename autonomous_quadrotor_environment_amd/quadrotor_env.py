@@ -216,6 +216,16 @@ class BatchedQuad:
             return x.t().contiguous()
         raise ValueError(f"{name}: expected shape [{rows}, {self.n_envs}] (or its transpose), got {tuple(x.shape)}")
 
+    def _mask(self, mask):
+        """uint8 [N] device copy of a reset / step mask (None passes through).  The kernels index it with the env number."""
+        if mask is None:
+            return None
+        if not isinstance(mask, torch.Tensor):
+            mask = torch.as_tensor(np.asarray(mask))
+        if mask.numel() != self.n_envs:
+            raise ValueError(f"mask: expected {self.n_envs} elements, got {tuple(mask.shape)}")
+        return mask.reshape(-1).to(device=self.device).to(torch.uint8).contiguous()
+
     # ---- attributes (device views into the workspace, [rows, N]) -----------------------------
     state = property(lambda s: s._field(L.FIELD_STATE))
     previous_state = state
@@ -262,7 +272,7 @@ class BatchedQuad:
             self._rng = rng
             det_state = random_init_states(rng, self.n_envs, self.variant).T.copy()
         init = self._as_rows(det_state, 13, "det_state")
-        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        m = self._mask(mask)
         states = torch.empty(self.T, 14, self.n_envs, device=self.device, dtype=self.dtype) if return_history else None
         actions = torch.empty(self.T, 4, self.n_envs, device=self.device, dtype=self.dtype) if return_history else None
         if return_history and mask is not None:
@@ -274,7 +284,7 @@ class BatchedQuad:
 
     def reset_sampled(self, seed, episode=0, env_offset=0, mask=None, push_window=False):
         """Masked auto-reset with device-drawn initial states (sample_init_states + reset(mask) in one launch)."""
-        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        m = self._mask(mask)
         self._bind()
         L.check(L.lib.qenv_reset_sampled(self._h, int(seed), int(episode), int(env_offset), L.ptr(m),
                                          int(bool(push_window))), "qenv_reset_sampled")
@@ -300,6 +310,10 @@ class BatchedQuad:
             done = torch.empty(self.n_envs, device=self.device, dtype=torch.uint8)
         else:
             obs, rew, done = out
+            self._check_buf(obs, 14, "out[0] (obs)")
+            self._check_buf(rew, 0, "out[1] (reward)")
+            self._check_buf(done, 0, "out[2] (done)", torch.uint8)
+        self._check_buf(out_mask, 0, "out_mask")
         L.check(L.lib.qenv_step(self._h, L.ptr(act), L.ptr(obs), L.ptr(rew), L.ptr(done), L.ptr(out_mask), flags),
                 "qenv_step")
         return obs, rew, (done.bool() if out is None else done)
@@ -371,6 +385,7 @@ class BatchedQuad:
 
     def lqr_action(self, out=None):
         out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
+        self._check_buf(out, 4, "out")
         self._bind()
         L.check(L.lib.qenv_lqr_action(self._h, L.ptr(out)), "qenv_lqr_action")
         return out
@@ -378,6 +393,7 @@ class BatchedQuad:
     def pid_action(self, targets=None, out=None):
         out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
         tg = None if targets is None else (C.c_double * 4)(*[float(a) for a in targets])
+        self._check_buf(out, 4, "out")
         self._bind()
         L.check(L.lib.qenv_pid_action(self._h, tg, L.ptr(out)), "qenv_pid_action")
         return out
@@ -386,12 +402,13 @@ class BatchedQuad:
         """PID_control.py position PD: targets = [xd, yd, zd, dxd, dyd, dzd, psi_d]."""
         out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
         tg = None if targets is None else (C.c_double * 7)(*[float(a) for a in targets])
+        self._check_buf(out, 4, "out")
         self._bind()
         L.check(L.lib.qenv_pidpos_action(self._h, tg, L.ptr(out)), "qenv_pidpos_action")
         return out
 
     def pid_reset(self, mask=None):
-        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        m = self._mask(mask)
         self._bind()
         L.check(L.lib.qenv_pid_reset(self._h, L.ptr(m)), "qenv_pid_reset")
 
@@ -473,6 +490,7 @@ class BatchedQuad:
         self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
         for t, nm in ((reward, "reward"), (mask, "mask")):
             self._check_buf(t, 0, nm)
+        self._check_buf(done, 0, "done", torch.uint8)
         nz = None if noise is None else self._as_rows(noise, 4, "noise")
         a = L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[t.data_ptr() for t in W], float(weights.std),
                           None if nz is None else nz.data_ptr(), int(seed), int(step), int(env_offset),
@@ -493,6 +511,8 @@ class BatchedQuad:
         (seed; global env index env_offset+e, step)."""
         out = torch.empty(4, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
         nz = None if noise is None else self._as_rows(noise, 4, "noise")
+        for t, nm in ((mean, "mean"), (out, "out"), (logprob, "logprob")):
+            self._check_buf(t, 4, nm)
         self._bind()
         L.check(L.lib.qenv_sample_action(self._h, L.ptr(mean), float(std), L.ptr(nz), int(seed), int(step),
                                          int(env_offset), L.ptr(out), L.ptr(logprob)), "qenv_sample_action")
@@ -524,7 +544,7 @@ class BatchedQuad:
         L.check(L.lib.qenv_outer_pospi(self._h, L.ptr(t), float(P), float(D), float(I)), "qenv_outer_pospi")
 
     def outer_reset(self, mask=None):
-        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        m = self._mask(mask)
         self._bind()
         L.check(L.lib.qenv_outer_reset(self._h, L.ptr(m)), "qenv_outer_reset")
 
@@ -542,7 +562,7 @@ class BatchedQuad:
         """robust_control.reset for the masked envs: params [12, N] (reference draw order: kf4, m, ir4, J3) or
         None = the same distributions from Philox keyed by (seed; global env, episode)."""
         p = self._as_rows(params, 12, "params")
-        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        m = self._mask(mask)
         self._bind()
         L.check(L.lib.qenv_robust_params(self._h, L.ptr(p), int(seed), int(env_offset), L.ptr(m)), "qenv_robust_params")
 
@@ -564,7 +584,8 @@ class BatchedQuad:
     def sample_init_states(self, seed, episode=0, env_offset=0, mask=None, out=None):
         """Device-side random branch of quad.reset (same distributions, Philox streams)."""
         out = torch.zeros(13, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
-        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        m = self._mask(mask)
+        self._check_buf(out, 13, "out")
         self._bind()
         L.check(L.lib.qenv_sample_init_states(self._h, int(seed), int(episode), int(env_offset), L.ptr(m), L.ptr(out)),
                 "qenv_sample_init_states")

@@ -63,6 +63,7 @@ class BatchedSensor:
         (FULL) flags.  z27: injected [27, N] standard normals in the reference's draw order."""
         b = self.env
         out = torch.empty(24, b.n_envs, device=b.device, dtype=b.dtype) if out is None else out
+        b._check_buf(out, 24, "out")
         z = None if z27 is None else b._as_rows(z27, 27, "z27")
         b._bind()
         L.check(L.lib.qenv_sensor_read(b._h, L.ptr(self._ws), L.ptr(z), self.seed, self.calls, self.env_offset,
@@ -94,6 +95,7 @@ class BatchedSensor:
         b = self.env
         if z27 is not None and (tuple(z27.shape) != (27, b.n_envs) or z27.dtype != b.dtype or not z27.is_contiguous()):
             raise ValueError(f"z27: a contiguous [27, {b.n_envs}] {b.dtype} tensor the caller refills in place")
+        b._check_buf(out, 24, "out")
         self._attached = (z27, out)
         zt, ot = self._attached
         b._sensor = self

@@ -57,7 +57,7 @@ def test_step_push_window_equals_separate_push(aq):
 
 def test_sample_action_injected_and_philox(aq):
     n = 100000
-    env = aq.BatchedQuad(n, 0.01, 1000, direct_control=1, T=1)
+    env = aq.BatchedQuad(n, 0.01, 1000, direct_control=1, T=1, dtype=torch.float32)  # fp32 buffers below
     mean = torch.randn(4, n, device="cuda")
     noise = torch.randn(4, n, device="cuda")
     lp = torch.empty(4, n, device="cuda")
@@ -73,14 +73,14 @@ def test_sample_action_injected_and_philox(aq):
     assert torch.equal(z.float(), env.sample_action(torch.zeros_like(mean), 1.0, seed=7, step=3))
     assert not torch.equal(z.float(), env.sample_action(torch.zeros_like(mean), 1.0, seed=7, step=4))
     assert not torch.equal(z.float(), env.sample_action(torch.zeros_like(mean), 1.0, seed=8, step=3))
-    half = aq.BatchedQuad(n // 2, 0.01, 1000, direct_control=1, T=1)
+    half = aq.BatchedQuad(n // 2, 0.01, 1000, direct_control=1, T=1, dtype=torch.float32)
     zh = half.sample_action(torch.zeros(4, n // 2, device="cuda"), 1.0, seed=7, step=3, env_offset=n // 2)
     assert torch.equal(zh, z.float()[:, n // 2:])
 
 
 def test_sample_init_states_distribution(aq):
     n = 200000
-    env = aq.BatchedQuad(n, 0.01, 1000, direct_control=1, T=1)
+    env = aq.BatchedQuad(n, 0.01, 1000, direct_control=1, T=1, dtype=torch.float32)  # fp32 buffers below
     x = _np(env.sample_init_states(11, episode=2))
     assert np.allclose(np.linalg.norm(x[6:10], axis=0), 1, atol=1e-6)
     assert np.all(np.abs(x[0:5:2]) <= 2.5) and np.all(np.abs(x[1:6:2]) <= 5)
@@ -98,7 +98,7 @@ def test_sample_init_states_distribution(aq):
     env.sample_init_states(11, episode=2, mask=m, out=out)
     o = _np(out)
     assert np.array_equal(o[:, ::3], x[:, ::3].astype(np.float32)) and np.all(o[:, 1::3] == 9)
-    half = aq.BatchedQuad(n // 2, 0.01, 1000, direct_control=1, T=1)
+    half = aq.BatchedQuad(n // 2, 0.01, 1000, direct_control=1, T=1, dtype=torch.float32)
     assert np.array_equal(_np(half.sample_init_states(11, 2, env_offset=n // 2)), x[:, n // 2:])
     assert not np.array_equal(_np(env.sample_init_states(11, episode=3)), x)
 
