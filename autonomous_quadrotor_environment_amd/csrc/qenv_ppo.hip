@@ -95,6 +95,22 @@ __device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const 
     }
 }
 
+// Diagnostic build only (-DQENV_MLP_STAMPS, tools/mlp_stamps.py): s_memtime stamps of k_mlp's phases per wave.  The product
+// build compiles none of it.
+#ifdef QENV_MLP_STAMPS
+__device__ unsigned long long g_mlp_stamps[4096 * 16];
+#define MLP_STAMP(slot)                                                                                             \
+    do {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        const unsigned long long t_ = (slot) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+        if ((threadIdx.x & 63) == 0 && (slot) < 16)                                                                 \
+            g_mlp_stamps[((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = t_;             \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#else
+#define MLP_STAMP(slot) do { } while (0)
+#endif
+
 // K1 = 15*T window elements; TW > 0: compile-time window length (the whole observation of a tile
 // is prefetched into registers with back-to-back global loads before the first MFMA, and every
 // loop is unrolled so hipcc hoists the LDS operand reads ahead of the MFMAs); TW == 0: run-time T.
@@ -119,6 +135,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     static_assert(!BF16L1 || TW > 0, "the split layer 1 is built for the compile-time window");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0;
+    MLP_STAMP(0); MLP_STAMP(14);
     const int K1 = TW ? 15 * TW : 15 * a.T;
     const int K1P = (K1 + 1) & ~1;
     constexpr int KS16 = (15 * (TW ? TW : 1) + 15) / 16;  // 16-wide k-steps of the split layer 1
@@ -190,13 +207,16 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     }
     if (threadIdx.x < 32) b3s[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
     __syncthreads();
+    MLP_STAMP(1);
 
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
     const int wave = threadIdx.x >> 6, waves_per_block = BLOCK / 64;
     const int64_t tiles_per_chunk = (a.N + 31) / 32;
     const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
+    [[maybe_unused]] int stamp_tile = 0;
     for (int64_t gtile = (int64_t)blockIdx.x * waves_per_block + wave; gtile < n_tiles;
          gtile += (int64_t)gridDim.x * waves_per_block) {
+        MLP_STAMP(2 + 6 * stamp_tile);
         // The weights in LDS and the ring offsets are invariant across tiles, so LICM would hoist hundreds of
         // LDS reads / offsets out of this loop and spill them; an opaque memory clobber per tile stops that.
         asm volatile("" ::: "memory");
@@ -240,6 +260,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                 }
                 split3x8(v8, xsp[sk][0], xsp[sk][1], xsp[sk][2]);
             }
+            MLP_STAMP(3 + 6 * stamp_tile);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -332,6 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
         // (n_out <= 4 rows, padded to one 32-row tile) consumes each finished layer-2 tile the same way: 16 more
         // MFMAs per tile instead of 64 dependent VALU fmas + 16 ds_read_b128 -- on this chip fp32 MFMAs and VALU
         // share the vector lanes, and the VALU form of this layer cost 26 us of a 99 us launch (ablation, A/B).
+        MLP_STAMP(4 + 6 * stamp_tile);
         f32x16 acc3;
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc3[j] = b3s[acc_row(j, half)];
@@ -348,6 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                     split3x8(v8, bsp[ti][jh][0], bsp[ti][jh][1], bsp[ti][jh][2]);
                 }
         }
+        MLP_STAMP(5 + 6 * stamp_tile);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x16 acc2;
@@ -394,6 +417,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
                 if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        MLP_STAMP(6 + 6 * stamp_tile);
         float outv[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -408,7 +432,10 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
         if constexpr (SAMPLE) {
             if (valid && half == 0) sample_store(a, e, outv);
         }
+        MLP_STAMP(7 + 6 * stamp_tile);
+        ++stamp_tile;
     }
+    MLP_STAMP(15);
 }
 
 // ---- the same MLP for SMALL batches (a handful of 32-env tiles: the N = 1 drop-in, the 256-env training demo) ----
@@ -1768,3 +1795,9 @@ int qenv_visual_reward(int dtype, int64_t n_envs, int total_steps, const void* m
 }
 
 }  // extern "C"
+
+#ifdef QENV_MLP_STAMPS
+extern "C" int qenv_debug_mlp_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qenv::g_mlp_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif

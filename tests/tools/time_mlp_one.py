@@ -9,7 +9,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 w = aq.ActorCriticWeights.random(128, 75, 4, device="cuda", seed=1)
 env = aq.BatchedQuad(N, 0.01, 500, training=True, direct_control=1, T=5)
 env.reset(env.sample_init_states(0, 0, 0), return_history=False, push_window=True)
-out = torch.empty(4, N, device="cuda")
+out = torch.empty(4, N, device="cuda", dtype=env.dtype)
 for _ in range(50):
     env.mlp_forward(w, "actor", out=out)
 torch.cuda.synchronize()
