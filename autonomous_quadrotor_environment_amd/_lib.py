@@ -73,6 +73,8 @@ SYMBOLS = {
     "qenv_pidpos_action": (_i, [_vp, _dptr, _vp]),
     "qenv_window_push": (_i, [_vp, _vp, _vp, _i]),
     "qenv_mlp_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_mlp_image_bytes": (C.c_size_t, [_i, _i]),
+    "qenv_mlp_prepare": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 7),
     "qenv_sensor_reset": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _dptr]),
     "qenv_sensor_read": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _dptr, _vp]),
     "qenv_sensor_ops": (_i, [_vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, _dptr, _vp]),

@@ -58,6 +58,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->side = nullptr; q->ev_main = nullptr; q->ev_side = nullptr;
     q->env_flags[0] = (uint8_t*)workspace + L.flag_off; q->env_flags[1] = q->env_flags[0] + L.flag_stride;
     q->ar_pending = 0; q->ar_parity = 0; q->zero_on_act = nullptr;
+    q->prep[0] = {nullptr, nullptr, 0}; q->prep[1] = {nullptr, nullptr, 0};
     q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);

@@ -116,6 +116,9 @@ struct qenv_s {
     int32_t ar_pending;        // a reset list (parity ar_parity) still waits for its warm-up
     int32_t ar_parity;
     int32_t* zero_on_act;      // a word the next policy forward clears in its first thread (see MlpArgs::zero_word)
+    // qenv_mlp_prepare: per head (0 actor, 1 critic) the caller-owned image of the weights in k_mlp_v3's LDS layout, used by
+    // the forward calls whose W1 pointer and n_out match
+    struct { const float* W1; const void* image; int32_t n_out; } prep[2];
 };
 
 namespace qenv {

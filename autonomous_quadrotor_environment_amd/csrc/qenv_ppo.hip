@@ -62,6 +62,8 @@ struct MlpArgs {
     // cleared by the first thread of the launch: the length counter of the reset list that the step kernel FOLLOWING this
     // policy forward on the stream appends to (qenv_ppo_step: saves a 4-byte memset launch, ~5 us, per rollout step)
     int32_t* zero_word;
+    // k_mlp_v3: null, or the weights already in the kernel's LDS layout (qenv_mlp_prepare): staging is then a plain copy
+    const uint4* image;
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1);
@@ -438,6 +440,279 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
     MLP_STAMP(15);
 }
 
+// ---- k_mlp_v3: the N = 128, T = 5 policy forward, round 3 ------------------------------------------------------------
+// What the in-kernel stamps of k_mlp<128,5,512,.,.,2> showed (tools/mlp_stamps.py, 131 072 envs, 104 k cycles per wave):
+// 14 k cycles of weight staging (global fp32 -> three-way split -> LDS), 2 x 9 k cycles in which every wave of the chip
+// waits for its window loads at the same time, and layer 3 -- 64 fp32 MFMAs of 64 cycles per tile for 4 real output rows
+// in a 32-row tile -- as 29 % of the matrix-pipe time; the bf16 layers themselves run near the pipe's pace for two waves.
+// And what tools/ubench/mfma_fill.hip measured: v_mfma_f32_32x32x2_f32 executes on the vector lanes (6 independent v_fma
+// after each one: 64 -> 109 cycles, nothing hides), whereas v_mfma_f32_32x32x16_bf16 hides ~5 VALU instructions per MFMA
+// in the SAME wave's stream (34 cycles with 4 fillers) -- but an MFMA-only wave next to a VALU-only wave on one SIMD is
+// destructive (81 cycles per MFMA, 18 per v_fma).  Hence:
+//  * layer 3 leaves the matrix pipe: each lane holds 64 of its env's 128 layer-2 activations in the accumulator layout, so
+//    out[o] = sum_h W3[o][h] h2[h] is 4 x 64 exact fp32 FMAs per lane (W3 as [h][4] float4 rows in LDS: one broadcast
+//    ds_read_b128 per activation), the two lane halves meet in one cross-half add.  -4 096 pipe cycles per tile, and the
+//    FMAs are VALU work of the kind that hides under the bf16 MFMAs of the other wave of the SIMD;
+//  * the weights arrive ALREADY in the LDS layout when the caller prepared them (qenv_mlp_prepare: once per weight
+//    update, not once per launch and workgroup): staging = a 159 KiB copy; without an image the kernel splits as before;
+//  * the first tile's window is requested before the staging, the next tile's right after the current one has been
+//    split into its bf16 terms -- the 39 MB of window per launch stream in behind the MFMAs instead of in front of them.
+// Layers 1 and 2 are k_mlp<.,.,.,.,.,2>'s arithmetic instruction for instruction (same products, same order).
+// k_mlp_small<.,.,.,3> mirrors layer 3 (mlp3_layer3): the two kernels stay bit-identical (shard invariance).
+namespace mlp3 {
+constexpr int H = 128, NT = 4, TW = 5, KW = 75, KS16 = 5;
+constexpr int W1F = 0;                               // uint4 offsets into the image
+constexpr int W2F = W1F + NT * KS16 * 3 * 64;        // 3840
+constexpr int W3T = W2F + NT * NT * 2 * 3 * 64;      // 9984: [128] float4 = W3[0..3][h], rows >= n_out zero
+constexpr int B1 = W3T + H;                          // 10112: 128 floats
+constexpr int B2 = B1 + H / 4;                       // 10144
+constexpr int B3 = B2 + H / 4;                       // 10176: 4 floats, zero beyond n_out
+constexpr int IMAGE_UINT4 = B3 + 1;                  // 10177 -> 162 832 B
+}  // namespace mlp3
+
+// the image from the fp32 torch-layout weights, written by `nthr` threads (a workgroup into LDS, or a small grid into
+// global memory: qenv_mlp_prepare).  Fragment layouts: see k_mlp.
+__device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, const float* b1, const float* W2, const float* b2,
+                                                 const float* W3, const float* b3, int n_out, int tid, int nthr) {
+    using namespace mlp3;
+    for (int c = tid; c < NT * KS16 * 64; c += nthr) {   // W1: lane (col, half) holds W1[32 t + col][16 s + 8 half + i]
+        const int ln = c & 63, sk = (c >> 6) % KS16, t = (c >> 6) / KS16;
+        const int k0 = 16 * sk + 8 * (ln >> 5);
+        const float* src = W1 + (size_t)(32 * t + (ln & 31)) * KW;
+        float w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w8[i] = (k0 + i) < KW ? src[k0 + i] : 0.f;
+        bf16x8 sp[3];
+        split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) img[W1F + ((t * KS16 + sk) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+    }
+    for (int c = tid; c < NT * NT * 2 * 64; c += nthr) { // W2: lane (col, half) holds W2[32 t + col][32 ti + acc_row(8 jh + i, half)]
+        const int ln = c & 63, jh = (c >> 6) & 1, ti = (c >> 7) % NT, t = (c >> 7) / NT;
+        const float* src = W2 + (size_t)(32 * t + (ln & 31)) * H + 32 * ti + 16 * jh + 4 * (ln >> 5);
+        const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
+        const float w8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        bf16x8 sp[3];
+        split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) img[W2F + (((t * NT + ti) * 2 + jh) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+    }
+    for (int h = tid; h < H; h += nthr) {
+        float4 w;
+        w.x = W3[h]; w.y = n_out > 1 ? W3[(size_t)H + h] : 0.f; w.z = n_out > 2 ? W3[(size_t)2 * H + h] : 0.f;
+        w.w = n_out > 3 ? W3[(size_t)3 * H + h] : 0.f;
+        img[W3T + h] = __builtin_bit_cast(uint4, w);
+    }
+    for (int q4 = tid; q4 < H / 4; q4 += nthr) {
+        img[B1 + q4] = *reinterpret_cast<const uint4*>(b1 + 4 * q4);
+        img[B2 + q4] = *reinterpret_cast<const uint4*>(b2 + 4 * q4);
+    }
+    if (tid == 0) {
+        float4 b;
+        b.x = b3[0]; b.y = n_out > 1 ? b3[1] : 0.f; b.z = n_out > 2 ? b3[2] : 0.f; b.w = n_out > 3 ? b3[3] : 0.f;
+        img[B3] = __builtin_bit_cast(uint4, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_prepare(uint4* image, const float* W1, const float* b1, const float* W2, const float* b2,
+                                                     const float* W3, const float* b3, int n_out) {
+    mlp3_build_image(image, W1, b1, W2, b2, W3, b3, n_out, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
+
+// layer 3 on the vector lanes: o[k] += W3[k][row] * h2[row] over the 16 rows register j of this lane half holds in output
+// tile t of layer 2, in register order.  One definition for k_mlp_v3 and k_mlp_small (bit-identical outputs).
+__device__ __forceinline__ void mlp3_layer3(const float4* W3t, int t, int half, const f32x16& h2, float o[4]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 w = W3t[32 * t + acc_row(j, half)];
+        o[0] = fmaf(w.x, h2[j], o[0]); o[1] = fmaf(w.y, h2[j], o[1]);
+        o[2] = fmaf(w.z, h2[j], o[2]); o[3] = fmaf(w.w, h2[j], o[3]);
+    }
+}
+// the two lane halves' partial sums meet: the result is valid in the lower half (which started from the bias)
+__device__ __forceinline__ void mlp3_layer3_finish(float o[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = o[k] + __shfl_xor(o[k], 32);
+}
+
+template <int BLOCK, bool SAMPLE>
+__global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
+    using namespace mlp3;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0;
+    MLP_STAMP(0); MLP_STAMP(14);
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const int wave = threadIdx.x >> 6, waves_per_block = BLOCK / 64;
+    const int64_t tiles_per_chunk = (a.N + 31) / 32;
+    const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
+    const int64_t tile_stride = (int64_t)gridDim.x * waves_per_block;
+    int64_t gtile = (int64_t)blockIdx.x * waves_per_block + wave;
+    uint32_t N32 = (uint32_t)a.N;
+
+    // window element (16 sk + 8 half + i) of env `e32` of chunk `chunk`: 40 loads per lane, no predicates (out-of-range envs
+    // read env N - 1 and are masked at the stores; the five padded elements are zeroed by a select)
+    float xw[KS16][8];
+    auto request_window = [&](int64_t g) {
+        const int64_t chunk = a.n_chunks > 1 ? g / tiles_per_chunk : 0;
+        const int64_t e = (g - chunk * tiles_per_chunk) * 32 + col;
+        const uint32_t e32 = (uint32_t)(e < a.N ? e : a.N - 1);
+        const float* __restrict__ winc = a.win + chunk * (int64_t)KW * a.N;
+        int hsel = half;
+        uint32_t n32 = N32;
+        int head = a.head;
+        asm volatile("" : "+s"(n32), "+s"(head), "+v"(hsel));  // the 75 row selects / offsets are recomputed per call: hoisted out of the
+                                                               // tile loop they are 150 SGPRs (spilled)
+#pragma unroll
+        for (int sk = 0; sk < KS16; ++sk)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k0 = 16 * sk + i, k1 = 16 * sk + 8 + i;  // this element for lane half 0 / 1
+                int sl0 = head + (k0 < KW ? k0 : 0) / 15, sl1 = head + (k1 < KW ? k1 : 0) / 15;  // wave-uniform
+                if (sl0 >= TW) sl0 -= TW;
+                if (sl1 >= TW) sl1 -= TW;
+                const uint32_t r0 = (uint32_t)(sl0 * 15 + (k0 < KW ? k0 : 0) % 15);
+                const uint32_t r1 = (uint32_t)(sl1 * 15 + (k1 < KW ? k1 : 0) % 15);
+                float x = winc[(hsel ? r1 : r0) * n32 + e32];
+                if (k1 >= KW) x = (hsel || k0 >= KW) ? 0.f : x;
+                xw[sk][i] = x;
+            }
+    };
+    if (gtile < n_tiles) request_window(gtile);   // in flight during the staging
+
+    if (a.image) {
+        for (int i = threadIdx.x; i < IMAGE_UINT4; i += BLOCK) lds4[i] = a.image[i];
+    } else {
+        mlp3_build_image(lds4, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.n_out, (int)threadIdx.x, BLOCK);
+    }
+    __syncthreads();
+    MLP_STAMP(1);
+    const uint4* W1f = lds4 + W1F;
+    const uint4* W2f = lds4 + W2F;
+    const float4* W3t = reinterpret_cast<const float4*>(lds4 + W3T);
+    const float* b1s = reinterpret_cast<const float*>(lds4 + B1);
+    const float* b2s = reinterpret_cast<const float*>(lds4 + B2);
+    const float* b3s = reinterpret_cast<const float*>(lds4 + B3);
+
+    [[maybe_unused]] int stamp_tile = 0;
+    for (; gtile < n_tiles; gtile += tile_stride) {
+        MLP_STAMP(2 + 6 * stamp_tile);
+        // the weights in LDS and the ring offsets are tile-invariant: without this LICM hoists hundreds of LDS reads and spills
+        asm volatile("" ::: "memory");
+        const int64_t chunk = a.n_chunks > 1 ? gtile / tiles_per_chunk : 0;  // wave-uniform
+        const int64_t tile = gtile - chunk * tiles_per_chunk;
+        const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
+        const int64_t e = tile * 32 + col;
+        const bool valid = e < a.N && !(a.env_skip && a.env_skip[e < a.N ? e : 0]);
+        const uint32_t e32 = (uint32_t)(e < a.N ? e : a.N - 1);
+        // ---- this tile's window -> bf16 terms; the observation copy
+        bf16x8 xsp[KS16][3];
+        {
+            uint32_t n32 = N32;
+            uint32_t kh = 8u * (uint32_t)half;
+            asm volatile("" : "+s"(n32), "+v"(kh));  // 32-bit offsets formed per use (hoisted: 75 address pairs, spilled)
+            float* __restrict__ obs_c = a.obs_store ? a.obs_store + chunk * (int64_t)KW * a.N : nullptr;
+#pragma unroll
+            for (int sk = 0; sk < KS16; ++sk) {
+                if (obs_c && valid) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t k = (uint32_t)(16 * sk + i) + kh;
+                        if (k < (uint32_t)KW) obs_c[k * n32 + e32] = xw[sk][i];
+                    }
+                }
+                split3x8(xw[sk], xsp[sk][0], xsp[sk][1], xsp[sk][2]);
+            }
+        }
+        MLP_STAMP(3 + 6 * stamp_tile);
+        // ---- layer 1 (k_mlp's split products, same order)
+        f32x16 acc1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+            const uint4* frag = W1f + (size_t)t * KS16 * 3 * 64 + lane;
+#pragma unroll
+            for (int sk = 0; sk < KS16; ++sk) {
+                const uint4* f = frag + sk * 3 * 64;
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                             al = __builtin_bit_cast(bf16x8, f[128]);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][1], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xsp[sk][0], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][2], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][0], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][1], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][0], acc1[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
+        }
+        MLP_STAMP(4 + 6 * stamp_tile);
+        // ---- the layer-1 activations of this lane as bf16 terms (the B operand of every layer-2 output tile)
+        bf16x8 bsp[NT][2][3];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = acc1[ti][8 * jh + i];
+                split3x8(v8, bsp[ti][jh][0], bsp[ti][jh][1], bsp[ti][jh][2]);
+            }
+        // the NEXT tile's window is requested here: its 40 registers are free again (the window lives on as xsp until layer 1
+        // ends, the activations as bsp from here), and layer 2 + 3 give the loads ~10 k cycles to land
+        if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);
+        MLP_STAMP(5 + 6 * stamp_tile);
+        // ---- layer 2 on the matrix cores, layer 3 on the vector lanes behind each finished output tile
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+            const uint4* frag = W2f + (size_t)t * NT * 2 * 3 * 64 + lane;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const uint4* f = frag + (ti * 2 + jh) * 3 * 64;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                                 al = __builtin_bit_cast(bf16x8, f[128]);
+                    const bf16x8 bh = bsp[ti][jh][0], bm = bsp[ti][jh][1], bl = bsp[ti][jh][2];
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc2, 0, 0, 0);   // smallest products first
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh(acc2[j]);
+            mlp3_layer3(W3t, t, half, acc2, o);
+        }
+        mlp3_layer3_finish(o);
+        MLP_STAMP(6 + 6 * stamp_tile);
+        float outv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = o[k];
+            if (a.final_tanh) v = tanhf(v);  // the 4 outputs keep the exact tanh
+            outv[k] = v;
+            if (valid && half == 0 && k < a.n_out && a.out) {
+                if (a.out_f64) ((double*)a.out)[out_off + (int64_t)k * a.N + e] = (double)v;
+                else ((float*)a.out)[out_off + (int64_t)k * a.N + e] = v;
+            }
+        }
+        if constexpr (SAMPLE) {
+            if (valid && half == 0) sample_store(a, e, outv);
+        }
+        MLP_STAMP(7 + 6 * stamp_tile);
+        ++stamp_tile;
+    }
+    MLP_STAMP(15);
+}
+
 // ---- the same MLP for SMALL batches (a handful of 32-env tiles: the N = 1 drop-in, the 256-env training demo) ----
 // k_mlp's cost at that size is not arithmetic: one workgroup stages 119 KB of weights (which every wave then uses
 // exactly once) and each wave walks the 472 dependent MFMAs of its tile alone: 39 us for 256 envs.  Here a tile
@@ -449,12 +724,23 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
 // results are bit-identical to k_mlp's.  Dependent MFMAs per tile: 38 + 16 NT + 16 NT instead of NT (38 + 16 NT + 16).
 template <int H, int TW, bool SAMPLE = false, int BF16 = 0>
 __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpArgs a) {
-    constexpr bool BF16L2 = BF16 >= 1, BF16L1 = BF16 >= 2;
+    constexpr bool BF16L2 = BF16 >= 1, BF16L1 = BF16 >= 2, L3V = BF16 >= 3;  // 3: k_mlp_v3's arithmetic (layer 3 on the vector lanes)
     constexpr int HP = H < 32 ? 32 : H;
     constexpr int NT = HP / 32;
     constexpr int K1 = 15 * TW, KS = (K1 + 1) / 2, KS16 = (K1 + 15) / 16;
     __shared__ float x1[NT * 16 * 64], x2[NT * 16 * 64];
+    __shared__ float4 w3t[L3V ? HP : 1];  // L3V: W3 as [h] float4 rows (outputs 0..3), read by wave 0 behind the tile's barriers
     if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0;
+    if constexpr (L3V) {
+        for (int hh = threadIdx.x; hh < HP; hh += HP * 2) {
+            float4 w;
+            w.x = hh < H ? a.W3[hh] : 0.f;
+            w.y = (hh < H && a.n_out > 1) ? a.W3[(size_t)H + hh] : 0.f;
+            w.z = (hh < H && a.n_out > 2) ? a.W3[(size_t)2 * H + hh] : 0.f;
+            w.w = (hh < H && a.n_out > 3) ? a.W3[(size_t)3 * H + hh] : 0.f;
+            w3t[hh] = w;
+        }
+    }
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, t = threadIdx.x >> 6;
     const int h = 32 * t + col;  // the hidden row this lane supplies as A operand
     const bool h_ok = h < H, o_ok = col < a.n_out;
@@ -493,7 +779,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         const float v = w2[k < H ? k : 0];
         a2[i] = (h_ok && k < H) ? v : 0.f;
     }
-    if (t == 0) {
+    if (t == 0 && !L3V) {
 #pragma unroll
         for (int i = 0; i < NT * 16; ++i) {
             const int k = 32 * (i >> 4) + acc_row(i & 15, half);
@@ -624,15 +910,31 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         for (int j = 0; j < 16; ++j) x2[(16 * t + j) * 64 + lane] = fast_tanh(acc[j]);
         __syncthreads();  // also: every wave is done with x1 before the next tile overwrites it
         if (t == 0) {     // layer 3 (n_out <= 4 rows in one zero-padded 32-row tile): one chain, k_mlp's order
+            float o3[4];
+            if constexpr (L3V) {  // k_mlp_v3's layer 3: the same FMAs in the same order on the same lanes
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o3[k] = (half || k >= a.n_out) ? 0.f : a.b3[k];
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    f32x16 h2;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) h2[j] = x2[(16 * ti + j) * 64 + lane];
+                    mlp3_layer3(w3t, ti, half, h2, o3);
+                }
+                mlp3_layer3_finish(o3);
+            } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = bias3[j];
 #pragma unroll
             for (int i = 0; i < NT * 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[i], x2[i * 64 + lane], acc, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o3[k] = acc[k];
+            }
             const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
             float outv[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                float v = acc[o];
+                float v = o3[o];
                 if (a.final_tanh) v = tanhf(v);
                 outv[o] = v;
                 if (valid && half == 0 && o < a.n_out && a.out) {
@@ -867,10 +1169,11 @@ template <int H, int TW, bool SAMPLE> static int launch_mlp_wide(const MlpArgs& 
 #define QENV_MLP_SMALL_TILES 512
 #endif
 
-// QENV_MLP_BF16: 2 (default) = layers 1 and 2 of the N = 128, T = 5 policy on the bf16 matrix cores with three-way split
-// operands, 1 = layer 2 only, 0 = every layer on the fp32 MFMA
+// QENV_MLP_BF16: 3 (default) = k_mlp_v3 for the N = 128, T = 5 policy: layers 1 and 2 on the bf16 matrix cores with three-way
+// split operands, layer 3 on the vector lanes, prepared weight image, prefetched windows; 2 = round 2's kernel (layers 1
+// and 2 split-bf16, layer 3 on the fp32 MFMA), 1 = layer 2 only, 0 = every layer on the fp32 MFMA (A/B runs)
 static inline int mlp_bf16_layer2() {
-    static const int on = getenv("QENV_MLP_BF16") ? atoi(getenv("QENV_MLP_BF16")) : 2;
+    static const int on = getenv("QENV_MLP_BF16") ? atoi(getenv("QENV_MLP_BF16")) : 3;
     return on;
 }
 
@@ -879,6 +1182,10 @@ template <int H, int TW, bool SAMPLE = false> static int launch_mlp_small(const 
     const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
     const dim3 g((unsigned)(n_tiles < 4096 ? n_tiles : 4096)), b(HP * 2);
     if constexpr (H == 128 && TW == 5) {
+        if (mlp_bf16_layer2() >= 3) {
+            hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE, 3>), g, b, 0, stream, a);
+            return check_launch("k_mlp_small(bf16 layers 1+2, vector layer 3)");
+        }
         if (mlp_bf16_layer2() >= 2) {
             hipLaunchKernelGGL((k_mlp_small<H, TW, SAMPLE, 2>), g, b, 0, stream, a);
             return check_launch("k_mlp_small(bf16 layers 1+2)");
@@ -911,6 +1218,13 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
         // layer 2 on the bf16 matrix cores with three-way split operands (see k_mlp): the default for the reference's
         // N = 128 policy at batch sizes beyond k_mlp_small's; QENV_MLP_BF16=0 keeps the all-fp32-MFMA kernel
         constexpr int NT = HP / 32, KS16 = (15 * TW + 15) / 16;
+        if (mlp_bf16_layer2() >= 3) {  // round 3's kernel (see k_mlp_v3)
+            const size_t lds = sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4;
+            hipError_t e = allow_dynamic_lds((const void*)k_mlp_v3<BLOCK, SAMPLE>, lds);
+            if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_v3)");
+            hipLaunchKernelGGL((k_mlp_v3<BLOCK, SAMPLE>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+            return check_launch("k_mlp_v3");
+        }
         if (mlp_bf16_layer2() >= 2) {
             const size_t lds = sizeof(float) * ((size_t)NT * KS16 * 3 * 64 * 4 + (size_t)NT * NT * 2 * 3 * 64 * 4 + 4 * HP + 2 * HP + 32);
             if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS");
@@ -1515,6 +1829,37 @@ int qenv_window_push(qenv_t q, const void* obs, const void* actions, int reset_f
     return check_launch("k_window_push");
 }
 
+size_t qenv_mlp_image_bytes(int k_in, int hidden) {
+    return (k_in == 15 * mlp3::TW && hidden == mlp3::H) ? sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4 : 0;
+}
+
+int qenv_mlp_prepare(qenv_t q, int head, int k_in, int hidden, int n_out, const float* W1, const float* b1, const float* W2,
+                     const float* b2, const float* W3, const float* b3, void* image) {
+    if (!q || head < 0 || head > 1) return fail(QENV_ERR_ARG, "qenv_mlp_prepare: null handle or head not 0 (actor) / 1 (critic)");
+    if (!image) { q->prep[head] = {nullptr, nullptr, 0}; return QENV_OK; }   // unregister
+    if (!W1 || !b1 || !W2 || !b2 || !W3 || !b3) return fail(QENV_ERR_ARG, "qenv_mlp_prepare: null weight pointer");
+    if (qenv_mlp_image_bytes(k_in, hidden) == 0 || k_in != 15 * q->cfg.T)
+        return fail(QENV_ERR_ARG, "qenv_mlp_prepare: only the 75-128-128-n policy on a T = 5 handle has a prepared form (see qenv_mlp_image_bytes)");
+    if (n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_mlp_prepare: n_out must be 1..4");
+    if (((uintptr_t)image & 15) != 0) return fail(QENV_ERR_ARG, "qenv_mlp_prepare: the image must be 16-byte aligned");
+    hipLaunchKernelGGL(k_mlp_prepare, dim3(16), dim3(256), 0, q->stream, (uint4*)image, W1, b1, W2, b2, W3, b3, n_out);
+    const int rc = check_launch("k_mlp_prepare");
+    if (rc == QENV_OK) q->prep[head] = {W1, image, n_out};
+    return rc;
+}
+
+}  // extern "C"
+
+// the prepared image of these weights, if the caller registered one for them on this handle
+static const uint4* prepared_image(const qenv_s* q, const float* W1, int hidden, int n_out) {
+    if (hidden != mlp3::H || q->cfg.T != mlp3::TW) return nullptr;
+    for (int h = 0; h < 2; ++h)
+        if (q->prep[h].image && q->prep[h].W1 == W1 && q->prep[h].n_out == n_out) return (const uint4*)q->prep[h].image;
+    return nullptr;
+}
+
+extern "C" {
+
 int qenv_mlp_forward(qenv_t q, int k_in, int hidden, int n_out, int final_tanh, const float* W1, const float* b1, const float* W2,
                      const float* b2, const float* W3, const float* b3, void* out, float* obs_store) {
     if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_mlp_forward: null argument");
@@ -1527,6 +1872,7 @@ int qenv_mlp_forward(qenv_t q, int k_in, int hidden, int n_out, int final_tanh, 
     a.out_f64 = q->cfg.dtype == QENV_F64;
     a.obs_store = obs_store;
     a.n_chunks = 1;
+    a.image = prepared_image(q, W1, hidden, n_out);
     const bool t5 = q->cfg.T == 5;  // the reference's window (ppo.py:60, T = 5): fully unrolled variant
     switch (hidden) {
         case 16: return t5 ? launch_mlp<16, 5, 512, true>(a, 5, q->stream) : launch_mlp<16, 0, 512, true>(a, q->cfg.T, q->stream);
@@ -1566,6 +1912,7 @@ int qenv::policy_act_subset(qenv_s* q, int k_in, int hidden, const float* W1, co
     a.out_action = out_action; a.out_logprob = out_logprob;
     a.env_skip = env_skip; a.list_idx = list_idx; a.list_count = list_count;
     a.zero_word = q->zero_on_act; q->zero_on_act = nullptr;  // consumed by this launch (qenv_ppo_step)
+    a.image = prepared_image(q, W1, hidden, 4);
     const bool t5 = q->cfg.T == 5;
     switch (hidden) {
         case 16: return t5 ? launch_mlp<16, 5, 512, true, true>(a, 5, q->stream) : launch_mlp<16, 0, 512, true, true>(a, q->cfg.T, q->stream);

@@ -40,6 +40,13 @@ class ActorCriticWeights:
         self.std = float(std)
         self.hidden = self.actor[0].shape[0]
         self.state_dim = self.actor[0].shape[1]
+        # bumped whenever the weight VALUES change in place (PpoLearner does; call touch() after writing into the tensors
+        # yourself): an env re-builds its prepared image of the weights (qenv_mlp_prepare) when it sees a new version
+        self.version = 0
+
+    def touch(self):
+        """Tell the envs that the weight values changed in place (their prepared images are rebuilt at the next forward)."""
+        self.version += 1
 
     @classmethod
     def from_state_dict(cls, sd, device="cuda"):
@@ -348,6 +355,7 @@ class PpoLearner:
         L.check(L.lib.qenv_adam_step(p.numel(), L.ptr(p), L.ptr(self.bucket.flat), L.ptr(self.flat_m), L.ptr(self.flat_v),
                                      self.lr, self.betas[0], self.betas[1], self.eps, self.step, _stream(p.device)),
                 "qenv_adam_step")
+        self.w.touch()
         if self.learn_std:  # the kernels take std by value: one small device-to-host read per Adam step
             self.w.std = float(self.std_param.item())
 
@@ -388,6 +396,7 @@ class PpoLearner:
             v = self._graph_loss.clone()
             out.append({"loss": v[0], "actor": v[1], "critic": v[2], "entropy": v[3]})
         self.step += self.K_epochs
+        self.w.touch()
         return out
 
     def update(self, rollout, returns, adv, minibatch=None, generator=None, graph=False):
@@ -654,6 +663,7 @@ class StreamShardedRollout:
             if self._fast:
                 C = self._C
                 for (h, per_t, std), ro in zip(self._fast, self.ros):
+                    ro.env._ensure_prepared(ro.w, "actor")
                     a = per_t[ro.t]
                     a.step = ro.global_step + 1
                     a.std = float(ro.w.std)  # always: a learner / schedule may move the std (and move it back) between steps

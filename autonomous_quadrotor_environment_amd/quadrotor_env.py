@@ -444,6 +444,27 @@ class BatchedQuad:
             raise ValueError(f"{name}: expected a contiguous {dtype} tensor of shape {shp} on {self.device}, got "
                              f"{tuple(t.shape)} {t.dtype} on {t.device}")
 
+    def _ensure_prepared(self, weights, head):
+        """Build / refresh this handle's prepared image of `weights.head(head)` (qenv_mlp_prepare: the weights in the
+        forward kernel's LDS layout) when the weight object or its version changed.  Only the 75-128-128-n policy on a
+        T = 5 handle has one; everything else stages the weights inside every launch."""
+        W = weights.head(head)
+        nbytes = L.lib.qenv_mlp_image_bytes(int(W[0].shape[1]), int(W[0].shape[0]))
+        if nbytes == 0 or self.T != 5:
+            return
+        slot = 0 if head == "actor" else 1
+        prep = self.__dict__.setdefault("_prep", {})
+        key = (id(weights), getattr(weights, "version", 0), W[0].data_ptr())
+        cur = prep.get(slot)
+        if cur is not None and cur[0] == key:
+            return
+        self._check_head(W, head)
+        img = cur[1] if cur is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._bind()
+        L.check(L.lib.qenv_mlp_prepare(self._h, slot, int(W[0].shape[1]), int(W[0].shape[0]), int(W[4].shape[0]),
+                                       *[L.ptr(t) for t in W], L.ptr(img)), "qenv_mlp_prepare")
+        prep[slot] = (key, img, weights)   # the image (and the weights it was built from) stay alive with the handle
+
     def mlp_forward(self, weights, head="actor", out=None, obs_store=None):
         """ActorCritic.actor / .critic forward on the observation ring (model.py:27-42).
         obs_store: optional float32 [15*T, N] receiving the window in time order."""
@@ -453,6 +474,7 @@ class BatchedQuad:
         out = torch.empty(n_out, self.n_envs, device=self.device, dtype=self.dtype) if out is None else out
         self._check_buf(out, n_out, "out")
         self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
+        self._ensure_prepared(weights, head)
         self._bind()
         L.check(L.lib.qenv_mlp_forward(self._h, W1.shape[1], W1.shape[0], n_out, int(head == "actor"), L.ptr(W1), L.ptr(b1),
                                        L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), L.ptr(obs_store)),
@@ -470,6 +492,7 @@ class BatchedQuad:
         for t, nm in ((out, "out"), (logprob, "logprob"), (mean, "mean")):
             self._check_buf(t, 4, nm)
         self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
+        self._ensure_prepared(weights, "actor")
         self._bind()
         L.check(L.lib.qenv_policy_act(self._h, W1.shape[1], W1.shape[0], L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3),
                                       float(weights.std), L.ptr(nz), int(seed), int(step), int(env_offset), L.ptr(mean),
@@ -492,6 +515,7 @@ class BatchedQuad:
             self._check_buf(t, 0, nm)
         self._check_buf(done, 0, "done", torch.uint8)
         nz = None if noise is None else self._as_rows(noise, 4, "noise")
+        self._ensure_prepared(weights, "actor")
         a = L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[t.data_ptr() for t in W], float(weights.std),
                           None if nz is None else nz.data_ptr(), int(seed), int(step), int(env_offset),
                           None if mean is None else mean.data_ptr(), actions.data_ptr(),

@@ -241,6 +241,20 @@ int qenv_pidpos_action(qenv_t q, const double *targets, void *out_actions);
  * (dl_in_gen.reset). */
 int qenv_window_push(qenv_t q, const void *obs, const void *actions, int reset_first);
 
+/* The 75-128-128-n policy (model.py:27-42 with N = 128, T = 5: the reference's checked-in weights) has a PREPARED form:
+ * the weights in the LDS layout of the forward kernel (bf16 three-way split fragments of W1 / W2, W3 as [h][4] rows,
+ * biases), built once per weight update instead of once per launch and workgroup.
+ *   qenv_mlp_image_bytes  size of the image for this shape, 0 if the shape has none.
+ *   qenv_mlp_prepare      builds the image (caller-owned device buffer, 16-byte aligned) on the handle's stream and
+ *                         registers it for `head` (0 actor, 1 critic) of this handle: qenv_mlp_forward /
+ *                         qenv_policy_act / qenv_ppo_step calls whose W1 pointer and n_out equal the registered ones
+ *                         then read the image instead of the fp32 weights.  Call it again after changing the weights
+ *                         in place (an optimiser step); image = NULL unregisters.  Without it every call stages the
+ *                         weights itself, with the same results bit for bit. */
+size_t qenv_mlp_image_bytes(int k_in, int hidden);
+int qenv_mlp_prepare(qenv_t q, int head, int k_in, int hidden, int n_out, const float *W1, const float *b1,
+                     const float *W2, const float *b2, const float *W3, const float *b3, void *image);
+
 /* Replaces ActorCritic.actor / .critic forward (environment/controller/model.py:27-42):
  * y = [tanh](W3 tanh(W2 tanh(W1 x + b1) + b2) + b3) on the observation ring, fp32
  * MFMA.  Weights: float32 device, row-major [out][in] exactly as torch's nn.Linear

@@ -545,6 +545,43 @@ def test_batched_critic_equals_per_step_critic(aq, dt, hidden):
     assert not aq.PolicyRollout(env, w, 4).batched_critic
 
 
+@pytest.mark.parametrize("N", [100, 40000])
+def test_prepared_weight_image_equals_in_kernel_staging(aq, N):
+    """qenv_mlp_prepare (the weights in the forward kernel's LDS layout, built once per weight update) against the same
+    kernels staging the fp32 weights themselves: bit-identical actor and critic outputs, for the tile-per-workgroup kernel
+    (100 envs) and the staged one (40 000); after an in-place weight change + touch() the image follows."""
+    from autonomous_quadrotor_environment_amd import _lib as L
+    w, _ = _weights(aq, 128)
+    env = aq.BatchedQuad(N, 0.01, 500, training=True, direct_control=1, T=5)
+    env.reset(env.sample_init_states(3, 0, 0), return_history=False, push_window=True)
+
+    def both():
+        return env.mlp_forward(w, "actor").clone(), env.mlp_forward(w, "critic").clone()
+
+    def unregistered():
+        for slot in (0, 1):
+            L.check(L.lib.qenv_mlp_prepare(env._h, slot, 75, 128, 4, None, None, None, None, None, None, None), "unregister")
+        keep, env._prep = env._prep, {}
+        ensure, env._ensure_prepared = env._ensure_prepared, (lambda *a, **k: None)
+        try:
+            return both()
+        finally:
+            env._prep, env._ensure_prepared = keep, ensure
+            for slot, head in ((0, "actor"), (1, "critic")):   # re-register the images that were built
+                W = w.head(head)
+                L.check(L.lib.qenv_mlp_prepare(env._h, slot, 75, 128, int(W[4].shape[0]), *[L.ptr(t) for t in W],
+                                               L.ptr(env._prep[slot][1])), "re-register")
+    a1, c1 = both()
+    assert set(env._prep) == {0, 1}
+    a0, c0 = unregistered()
+    assert torch.equal(a1, a0) and torch.equal(c1, c0)
+    w.actor[0].mul_(1.01); w.critic[4].add_(0.25); w.touch()
+    a2, c2 = both()
+    assert not torch.equal(a2, a1) and not torch.equal(c2, c1)
+    a3, c3 = unregistered()
+    assert torch.equal(a2, a3) and torch.equal(c2, c3)
+
+
 @pytest.mark.parametrize("hidden", [64, 128])
 @pytest.mark.parametrize("n_out,final_tanh", [(4, True), (1, False)])
 def test_small_batch_mlp_kernel_is_bit_identical_to_the_staged_kernel(aq, hidden, n_out, final_tanh):
