@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 4
+QENV_ABI_VERSION = 5
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -47,7 +47,8 @@ class QenvError(RuntimeError):
 class PpoStepArgs(C.Structure):  # qenv_ppo_step_args (include/qenv.h)
     _fields_ = [("k_in", C.c_int32), ("hidden", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3")] + \
                [("std", C.c_double), ("noise", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_uint64), ("env_offset", C.c_int64)] + \
-               [(n, C.c_void_p) for n in ("out_mean", "out_action", "out_logprob", "obs_store", "out_reward", "out_done", "out_mask")]
+               [(n, C.c_void_p) for n in ("out_mean", "out_action", "out_logprob", "obs_store", "out_reward", "out_done", "out_mask",
+                                          "out_valid")] + [("inband", C.c_int32), ("key_by_episode", C.c_int32)]
 
 
 # every symbol include/qenv.h declares: (name, restype, argtypes)
@@ -96,10 +97,13 @@ SYMBOLS = {
     "qenv_robust_gusts": (_i, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, _i64]),
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_adv_normalize": (_i, [_i, _i64, _vp, _vp, _i, _vp]),
+    "qenv_gae_masked": (_i, [_i, _i64, _i] + [_vp] * 9),
+    "qenv_adv_normalize_masked": (_i, [_i, _i64, _vp, _vp, _vp, _i, _vp]),
     "qenv_visual_reward": (_i, [_i, _i64, _i] + [_vp] * 13),
     "qenv_ppo_loss": (_i, [_i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "qenv_mlp_backward": (_i, [_i64, _i, _i, _i, _i, _i] + [_vp] * 14),
     "qenv_mlp_backward_ppo": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 5 + [C.c_double] * 3 + [_i64] + [_vp] * 13),
+    "qenv_mlp_backward_ppo_masked": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 6 + [C.c_double] * 3 + [_i64] + [_vp] * 13),
     "qenv_weight_grad": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "qenv_weight_grad_workspace_bytes": (C.c_size_t, [_i, _i]),
     "qenv_weight_grad_deterministic": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -252,12 +252,27 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     // they share their SIMDs with the policy forward, the gathered forward of the reset envs costs 65 us and the two
     // streams meet twice per step; with few resets per step (episodes that run their 500 steps) the side chain is shorter
     // than the main one and it pays (tests/tools/ab_ppo_overlap.py measures both and checks bit-identity)
+    if (p->inband) {
+        // in-band warm-up: policy + step, the restart in the step kernel's epilogue, the warm-up steps ride the next T steps
+        if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+        StepExtra exi{};
+        exi.ar_on = 2; exi.ar_seed = p->seed; exi.ar_episode = p->step; exi.ar_env_offset = p->env_offset;
+        exi.ar_key_episode = p->key_by_episode; exi.out_valid = p->out_valid;
+        int rci = policy_act_subset(q, p->k_in, p->hidden, p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->std, p->noise, p->seed, p->step,
+                                    p->env_offset, p->out_mean, p->out_action, p->out_logprob, p->obs_store, nullptr, nullptr, nullptr);
+        if (rci == QENV_OK)
+            rci = QENV_DISPATCH(q, do_step, q, p->out_action, nullptr, nullptr, p->out_reward, p->out_done, p->out_mask, QENV_STEP_NO_AUX,
+                                q->win_head, &exi);
+        if (rci == QENV_OK) q->win_head = (q->win_head + 1) % q->cfg.T;
+        return rci;
+    }
     static const int want_overlap = getenv("QENV_PPO_OVERLAP") ? atoi(getenv("QENV_PPO_OVERLAP")) : 0;
     const bool overlap = want_overlap && (p->hidden == 64 || p->hidden == 128) && q->cfg.T == 5;
     const int64_t N = q->N;
     const int cur = q->ar_parity, next = cur ^ 1;
     StepExtra ex{};
     ex.ar_on = 1; ex.ar_seed = p->seed; ex.ar_episode = p->step; ex.ar_env_offset = p->env_offset;
+    ex.ar_key_episode = p->key_by_episode; ex.out_valid = p->out_valid;
     ex.ar_idx = q->wsi + (next ? IROW_IDX2 : IROW_IDX) * N;
     ex.ar_count = q->counters + next;
     ex.ar_flags_next = q->env_flags[next];

@@ -52,12 +52,19 @@ template <typename T, typename S = T> struct StepArgs {
     // ... and the auto-reset of the worker loop (ppo.py:232-262) happens in this kernel's epilogue: an env that ends its
     // episode here banks its return, draws its next initial state (the streams of qenv_reset_sampled) and appends
     // itself to the list the warm-up rollout will walk; its byte in ar_flags_next marks it for the next step
+    // ar_on = 2: IN-BAND warm-up (round 3).  The env that ends its episode here is reset in the epilogue as above, but no
+    // list is kept and no warm-up launch follows: reset() 's T warm-up steps (quadrotor_env.py:448-453) are the env's next T
+    // REGULAR steps -- recognised by its own step counter (i < T), they apply zero_control whatever the policy asked for,
+    // push their slices into the common ring slot like everybody else, and mark their slot of the rollout invalid
+    // (out_valid = 0: excluded from GAE's moments and from the loss).  A rollout step is then two launches, policy + step.
     int32_t ar_on;
+    int32_t ar_key_episode;   // 1: the next initial state is keyed by the env's own episode count instead of ar_episode
     uint64_t ar_seed, ar_episode;
     int64_t ar_env_offset;
     int32_t* ar_idx;
     int32_t* ar_count;
     uint8_t* ar_flags_next;
+    S* out_valid;             // [N] or null: 0 for an env whose step was one of its reset's warm-up steps (ar_on = 2), else 1
 };
 
 template <typename T, typename S = T> struct RolloutArgs {
@@ -96,11 +103,13 @@ template <typename S, typename V> __device__ __forceinline__ void st(S* base, in
 // the auto-reset epilogue of k_step.  S = storage type; the Euler angles of the new state use S's IEEE functions in both.
 template <typename S>
 __device__ __forceinline__ void reset_env_sampled(S* ws, int32_t* wsi, int64_t N, int64_t e, uint64_t seed, uint64_t episode,
-                                                  int64_t env_offset, bool bank) {
+                                                  int64_t env_offset, bool bank, bool key_episode = false) {
     using m = Mth<S>;
     if (bank) {  // an episode ends here: bank its return before the counters are cleared
         st(ws, ROW_LAST_RETURN, N, e, ld(ws, ROW_EP_RETURN, N, e));
-        wsi[IROW_EPISODES * N + e] += 1;
+        const int32_t n_ep = wsi[IROW_EPISODES * N + e] + 1;
+        wsi[IROW_EPISODES * N + e] = n_ep;
+        if (key_episode) episode = (uint64_t)n_ep;  // the stream of the env's n-th restart, whenever it happens
     }
     float xf[13];
     sample_init_state(seed, episode, (uint64_t)(env_offset + e), xf);
@@ -233,6 +242,14 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
     // SQ counters show as waits are that one phase's round trip, ~2 us with every SIMD loading at once.)
     Book<T> bk;
     if (a.mode != QENV_STEP_DYNAMICS_ONLY) load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
+    bool warming = false;
+    if (a.ar_on == 2 && a.mode != QENV_STEP_DYNAMICS_ONLY) {  // in-band warm-up: steps 1..T after a reset apply zero_control (:448-451)
+        warming = bk.i < cfg.warmup;
+        if (warming) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) raw[k] = (cfg.direct || k == 0) ? cfg.zero_control0 : T(0);
+        }
+    }
     prepare_action(raw, cfg, pl, w, effort, cl, act, u);
     integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy);
     if constexpr (ROBUST) store_gust(a.ws, a.wsi, N, e, pl);
@@ -269,6 +286,7 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
     if (a.out_reward) a.out_reward[e] = (S)bk.reward;
     if (a.out_done) a.out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
     if (a.out_mask) a.out_mask[e] = (bk.flags & FLAG_DONE) ? S(0) : S(1);
+    if (a.out_valid) a.out_valid[e] = warming ? S(0) : S(1);
     if (a.win) {  // dl_in_gen.dl_input: [raw action(4), vel(3), q(4), q_dot(4)] (dl_auxiliary.py:27-31)
         float* wv = a.win + (int64_t)a.win_slot * 15 * N + e;
 #pragma unroll
@@ -353,7 +371,12 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
         for (int k = 0; k < 4; ++k) { wv[(int64_t)(7 + k) * N] = (float)y[6 + k]; wv[(int64_t)(11 + k) * N] = (float)kq[6 + k]; }
         }
     }
-    if (a.ar_on) {  // wave-uniform; the lanes still here are the envs this launch stepped
+    if (a.ar_on == 2) {
+        // in-band: an episode that ends in a POLICY step restarts here (a done raised by a warm-up step stays sticky, like
+        // the done reset() ignores: the first policy step then reports it and the episode has length one)
+        if ((bk.flags & FLAG_DONE) != 0 && !warming)
+            reset_env_sampled<S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, true, a.ar_key_episode != 0);
+    } else if (a.ar_on) {  // wave-uniform; the lanes still here are the envs this launch stepped
         const bool fin = (bk.flags & FLAG_DONE) != 0;
         const unsigned long long b = __ballot(fin);
         const int lane = threadIdx.x & 63;
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
             base = __shfl(base, leader);
             if (fin) {
                 a.ar_idx[base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)e;
-                reset_env_sampled<S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, true);
+                reset_env_sampled<S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, true, a.ar_key_episode != 0);
             }
         }
     }
@@ -989,6 +1012,7 @@ struct StepExtra {
     const int32_t* list_idx; const int32_t* list_count;  // step only the envs of this compacted list
     int32_t ar_on; uint64_t ar_seed, ar_episode; int64_t ar_env_offset;
     int32_t* ar_idx; int32_t* ar_count; uint8_t* ar_flags_next;
+    int32_t ar_key_episode; void* out_valid;
 };
 
 template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
@@ -1025,8 +1049,9 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
         q->sens.calls += 1;
     }
     a.env_skip = nullptr; a.ar_on = 0; a.ar_seed = a.ar_episode = 0; a.ar_env_offset = 0;
-    a.ar_idx = nullptr; a.ar_count = nullptr; a.ar_flags_next = nullptr;
+    a.ar_idx = nullptr; a.ar_count = nullptr; a.ar_flags_next = nullptr; a.ar_key_episode = 0; a.out_valid = nullptr;
     if (ex) {
+        a.ar_key_episode = ex->ar_key_episode; a.out_valid = (S*)ex->out_valid;
         a.env_skip = ex->env_skip; a.ar_on = ex->ar_on; a.ar_seed = ex->ar_seed;
         if (ex->list_idx) { a.idx = ex->list_idx; a.count = ex->list_count; }
         a.ar_episode = ex->ar_episode; a.ar_env_offset = ex->ar_env_offset; a.ar_idx = ex->ar_idx; a.ar_count = ex->ar_count;

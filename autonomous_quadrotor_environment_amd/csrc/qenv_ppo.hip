@@ -1616,9 +1616,12 @@ __global__ __launch_bounds__(256) void k_sensor_ops(int64_t N, T* ws, const int3
 // with wavefront shuffles and one double atomicAdd pair per wave.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* values, const T* masks, const T* rewards,
-                                             T* returns, T* adv, double* stats, double* partials) {
+                                             T* returns, T* adv, double* stats, double* partials, const T* valid = nullptr) {
+    // valid (in-band warm-up rollouts, qenv_ppo_step): rows with valid == 0 are the warm-up steps of a restarted env.  They
+    // follow a terminal row (mask 0) or open the horizon, so no valid row's recurrence reads them; their advantage is set
+    // to 0 and they are left out of the moments (count included).
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
     if (e < N) {
         const T gmma = T(0.99), lmbda = T(0.99);
         T gae = T(0);
@@ -1627,12 +1630,13 @@ __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* va
         // before the first one is consumed (a plain loop exposes one HBM round trip per step: 107 us for 128 steps)
         constexpr int U = 8;
         for (int i0 = n_steps - 1; i0 >= 0; i0 -= U) {
-            T v[U], mk[U], rw[U];
+            T v[U], mk[U], rw[U], vl[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = i0 - u;
                 const int64_t o = (int64_t)(i >= 0 ? i : 0) * N + e;
                 v[u] = values[o]; mk[u] = masks[o]; rw[u] = rewards[o];
+                vl[u] = valid ? valid[o] : T(1);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1643,10 +1647,13 @@ __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* va
                     gae = delta + gmma * lmbda * mk[u] * gae;
                     const T ret = gae + v[u];
                     returns[o] = ret;
-                    const T ad = ret - v[u];
+                    const T ad = vl[u] != T(0) ? ret - v[u] : T(0);
                     adv[o] = ad;
-                    s1 += (double)ad;
-                    s2 += (double)ad * (double)ad;
+                    if (vl[u] != T(0)) {
+                        s1 += (double)ad;
+                        s2 += (double)ad * (double)ad;
+                        cnt += 1.0;
+                    }
                     v_next = v[u];
                 }
             }
@@ -1657,6 +1664,7 @@ __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* va
         for (int off = 32; off > 0; off >>= 1) {
             s1 += __shfl_xor(s1, off);
             s2 += __shfl_xor(s2, off);
+            if (valid) cnt += __shfl_xor(cnt, off);
         }
         if ((threadIdx.x & 63) == 0) {
             if (partials) {  // deterministic mode: this wave's moments to their own slot, summed in a fixed order afterwards
@@ -1666,8 +1674,9 @@ __global__ __launch_bounds__(256) void k_gae(int64_t N, int n_steps, const T* va
                 atomicAdd(&stats[1], s1);
                 atomicAdd(&stats[2], s2);
             }
+            if (valid && cnt != 0.0) atomicAdd(&stats[0], cnt);  // a sum of integers: exact in any order
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (double)N * (double)n_steps);
+        if (!valid && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (double)N * (double)n_steps);
     }
 }
 
@@ -1691,13 +1700,13 @@ __global__ __launch_bounds__(1024) void k_sum_slots(const A* partials, int64_t n
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_adv_normalize(int64_t n, T* adv, const double* stats, int ddof) {
+__global__ __launch_bounds__(256) void k_adv_normalize(int64_t n, T* adv, const double* stats, int ddof, const T* valid = nullptr) {
     const double cnt = stats[0], mean = stats[1] / cnt;
     double var = (stats[2] - cnt * mean * mean) / (cnt - ddof);
     if (var < 0) var = 0;
     const double inv = 1.0 / (sqrt(var) + 1e-10);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        adv[i] = (T)(((double)adv[i] - mean) * inv);
+        adv[i] = (valid && valid[i] == T(0)) ? T(0) : (T)(((double)adv[i] - mean) * inv);  // warm-up rows stay at 0
 }
 
 // ---- PPO clipped-surrogate loss (ppo.py:185-203) ------------------------------------------------
@@ -2050,16 +2059,18 @@ int qenv_sensor_ops(qenv_t q, void* sens, const int32_t* ops, int n_ops, const v
 }
 
 static int gae_impl(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,
-                    void* returns, void* adv, double* stats, double* partials, void* stream) {
+                    void* returns, void* adv, double* stats, double* partials, void* stream, const void* valid = nullptr) {
     if (!values || !masks || !rewards || !returns || !adv) return fail(QENV_ERR_ARG, "qenv_gae: null argument");
     if (n_envs <= 0 || n_steps <= 0) return fail(QENV_ERR_ARG, "qenv_gae: n_envs and n_steps must be positive");
     const dim3 g((unsigned)((n_envs + 255) / 256)), b(256);
     if (dtype == QENV_F64)
         hipLaunchKernelGGL((k_gae<double>), g, b, 0, (hipStream_t)stream, n_envs, n_steps, (const double*)values,
-                           (const double*)masks, (const double*)rewards, (double*)returns, (double*)adv, stats, partials);
+                           (const double*)masks, (const double*)rewards, (double*)returns, (double*)adv, stats, partials,
+                           (const double*)valid);
     else if (dtype == QENV_F32)
         hipLaunchKernelGGL((k_gae<float>), g, b, 0, (hipStream_t)stream, n_envs, n_steps, (const float*)values,
-                           (const float*)masks, (const float*)rewards, (float*)returns, (float*)adv, stats, partials);
+                           (const float*)masks, (const float*)rewards, (float*)returns, (float*)adv, stats, partials,
+                           (const float*)valid);
     else return fail(QENV_ERR_ARG, "qenv_gae: bad dtype");
     int rc = check_launch("k_gae");
     if (rc == 0 && partials && stats) {
@@ -2082,16 +2093,32 @@ int qenv_gae_deterministic(int dtype, int64_t n_envs, int n_steps, const void* v
     return gae_impl(dtype, n_envs, n_steps, values, masks, rewards, returns, adv, stats, (double*)workspace, stream);
 }
 
+int qenv_gae_masked(int dtype, int64_t n_envs, int n_steps, const void* values, const void* masks, const void* rewards,
+                    const void* valid, void* returns, void* adv, double* stats, void* workspace, void* stream) {
+    if (!stats) return fail(QENV_ERR_ARG, "qenv_gae_masked: stats is required (the count of valid rows is returned there)");
+    return gae_impl(dtype, n_envs, n_steps, values, masks, rewards, returns, adv, stats, (double*)workspace, stream, valid);
+}
+
+static int adv_normalize_impl(int dtype, int64_t n, void* adv, const void* valid, const double* stats, int ddof, void* stream);
+
+int qenv_adv_normalize_masked(int dtype, int64_t n, void* adv, const void* valid, const double* stats, int ddof, void* stream) {
+    return adv_normalize_impl(dtype, n, adv, valid, stats, ddof, stream);
+}
+
 int qenv_adv_normalize(int dtype, int64_t n, void* adv, const double* stats, int ddof, void* stream) {
+    return adv_normalize_impl(dtype, n, adv, nullptr, stats, ddof, stream);
+}
+
+static int adv_normalize_impl(int dtype, int64_t n, void* adv, const void* valid, const double* stats, int ddof, void* stream) {
     if (!adv || !stats) return fail(QENV_ERR_ARG, "qenv_adv_normalize: null argument");
     if (n <= 0) return fail(QENV_ERR_ARG, "qenv_adv_normalize: n must be positive");
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     const dim3 g((unsigned)blocks), b(256);
     if (dtype == QENV_F64)
-        hipLaunchKernelGGL((k_adv_normalize<double>), g, b, 0, (hipStream_t)stream, n, (double*)adv, stats, ddof);
+        hipLaunchKernelGGL((k_adv_normalize<double>), g, b, 0, (hipStream_t)stream, n, (double*)adv, stats, ddof, (const double*)valid);
     else if (dtype == QENV_F32)
-        hipLaunchKernelGGL((k_adv_normalize<float>), g, b, 0, (hipStream_t)stream, n, (float*)adv, stats, ddof);
+        hipLaunchKernelGGL((k_adv_normalize<float>), g, b, 0, (hipStream_t)stream, n, (float*)adv, stats, ddof, (const float*)valid);
     else return fail(QENV_ERR_ARG, "qenv_adv_normalize: bad dtype");
     return check_launch("k_adv_normalize");
 }

@@ -26,6 +26,8 @@ struct BwdArgs {
     float inv_var, inv_std, log_norm, eps_clip, c_value, inv_B;
     double* sums;                // qenv_ppo_loss's {B, sum actor, sum (V - ret)^2, entropy * B}: [1] (mode 1) or [2] (mode 2) accumulated;
                                  // mode 1 also adds sum_s d actor_s / d std to [4] (learned action std, model.py:45-48)
+    const float* weight;         // null, or [c][N] sample weights of the fused loss (1 / 0: the `valid` rows of an in-band warm-up
+                                 // rollout, qenv_ppo_step); inv_B is then 1 / (number of valid samples)
 };
 
 // Stores of a tile go through raw buffer instructions: a lane beyond the chunk (e >= N in the last tile of a chunk) or a
@@ -184,10 +186,11 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
             const float clipped = fminf(fmaxf(ratio, 1.f - a.eps_clip), 1.f + a.eps_clip);
             const float s1 = ratio * A, s2 = clipped * A;
             const bool use1 = s1 <= s2;  // torch.min picks surr1 on ties
-            const bool live = use1 || (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip);
+            const float wgt = a.weight ? (a.weight + (size_t)c * a.N)[ec] : 1.f;
+            const bool live = (use1 || (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip)) && wgt != 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) sd[k] = live ? -A * ratio * d[k] * a.inv_var * a.inv_B : 0.f;
-            if (valid && half == 0) {
+            if (valid && half == 0 && wgt != 0.f) {
                 loss_acc += -(double)(use1 ? s1 : s2);
                 // d log N(a; mean, std) / d std summed over the four action dimensions = sum_k (d_k^2 / std^2 - 1) / std
                 float dls = 0.f;
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
                 if (live) std_acc += (double)(-A * ratio) * (double)(dls * a.inv_std);
             }
         } else {  // critic: c_value * (V - ret)^2
-            const float err = outv[0] - (a.returns + (size_t)c * a.N)[ec];
+            const float wgt = a.weight ? (a.weight + (size_t)c * a.N)[ec] : 1.f;
+            const float err = wgt != 0.f ? outv[0] - (a.returns + (size_t)c * a.N)[ec] : 0.f;
             sd[0] = 2.f * a.c_value * err * a.inv_B;
             if (valid && half == 0) loss_acc += (double)err * (double)err;
         }
@@ -497,7 +501,7 @@ int qenv_mlp_backward(int64_t n_envs, int n_chunks, int k_in, int hidden, int n_
     a.obs = obs; a.seed = seed; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
     a.h1 = h1; a.h2 = h2; a.dz2 = dz2; a.dz1 = dz1; a.dz3 = dz3;
     a.loss_mode = 0; a.actions = a.old_logprob = a.adv = a.returns = nullptr; a.sums = nullptr;
-    a.inv_var = a.inv_std = a.log_norm = a.eps_clip = a.c_value = a.inv_B = 0.f;
+    a.inv_var = a.inv_std = a.log_norm = a.eps_clip = a.c_value = a.inv_B = 0.f; a.weight = nullptr;
     return launch_bwd(a, hidden, stream);
 }
 
@@ -506,6 +510,15 @@ int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, in
                           double std, double eps_clip, double c_value, int64_t batch, double* sums, const float* W1,
                           const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* h1,
                           float* h2, float* dz2, float* dz1, float* dz3, void* stream) {
+    return qenv_mlp_backward_ppo_masked(n_envs, n_chunks, k_in, hidden, head, obs, actions, old_logprob, adv, returns, nullptr, std,
+                                        eps_clip, c_value, batch, sums, W1, b1, W2, b2, W3, b3, h1, h2, dz2, dz1, dz3, stream);
+}
+
+int qenv_mlp_backward_ppo_masked(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float* obs,
+                                 const float* actions, const float* old_logprob, const float* adv, const float* returns,
+                                 const float* weight, double std, double eps_clip, double c_value, int64_t batch, double* sums,
+                                 const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                 const float* b3, float* h1, float* h2, float* dz2, float* dz1, float* dz3, void* stream) {
     if (!obs || !sums || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !h1 || !h2 || !dz2 || !dz1 || !dz3)
         return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: null argument");
     if (head != 0 && head != 1) return fail(QENV_ERR_ARG, "qenv_mlp_backward_ppo: head must be 0 (actor) or 1 (critic)");
@@ -520,7 +533,7 @@ int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, in
     a.loss_mode = head == 0 ? 1 : 2; a.actions = actions; a.old_logprob = old_logprob; a.adv = adv; a.returns = returns;
     a.inv_var = (float)(1.0 / (std * std)); a.inv_std = (float)(1.0 / std); a.log_norm = (float)(-std::log(std) - 0.9189385332046727);
     a.eps_clip = (float)eps_clip; a.c_value = (float)c_value; a.inv_B = 1.f / (float)batch;
-    a.sums = sums;
+    a.sums = sums; a.weight = weight;
     return launch_bwd(a, hidden, stream);
 }
 

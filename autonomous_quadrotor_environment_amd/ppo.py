@@ -118,7 +118,7 @@ class dl_in_gen:
         return self.deep_learning_input
 
 
-def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministic=False, return_stats=False):
+def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministic=False, return_stats=False, valid=None):
     """PPO.get_advantages (ppo.py:125-141 ddof=0; ppo_trainer.py:133-148 ddof=1) on a
     time-major rollout: values [n+1, N], masks [n, N], rewards [n, N] device tensors.
     Returns (returns [n, N], normalised advantages [n, N]).  With `group`
@@ -126,7 +126,8 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministi
     global mean/std, exactly like a single learner.  deterministic: the moments are summed in a fixed order instead
     of with double-precision atomics.  return_stats (with normalize=False): also return the three float64 moment
     sums [count, sum, sum of squares] of the raw advantages, for a caller that combines several shards before
-    `adv_normalize`."""
+    `adv_normalize`.  valid [n, N] (in-band warm-up rollouts): rows with 0 are a restarted env's warm-up steps -- their
+    advantage is 0, before and after the normalisation, and the moments (count included) leave them out."""
     n, N = rewards.shape
     assert values.shape == (n + 1, N) and masks.shape == (n, N)
     dt = L.F64 if values.dtype == torch.float64 else L.F32
@@ -137,8 +138,14 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministi
     adv = torch.empty_like(rewards)
     stats = torch.zeros(3, dtype=torch.float64, device=values.device)
     stream = _stream(values.device)
-    if deterministic:  # moments summed in a fixed order (run-to-run identical normalised advantages)
-        ws = torch.empty(int(L.lib.qenv_gae_workspace_bytes(N)), dtype=torch.uint8, device=values.device)
+    if valid is not None:
+        assert valid.shape == (n, N)
+        valid = valid.to(values.dtype).contiguous()
+    ws = torch.empty(int(L.lib.qenv_gae_workspace_bytes(N)), dtype=torch.uint8, device=values.device) if deterministic else None
+    if valid is not None:
+        L.check(L.lib.qenv_gae_masked(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(valid), L.ptr(ret), L.ptr(adv),
+                                      L.ptr(stats), L.ptr(ws), stream), "qenv_gae_masked")
+    elif deterministic:  # moments summed in a fixed order (run-to-run identical normalised advantages)
         L.check(L.lib.qenv_gae_deterministic(dt, N, n, L.ptr(values), L.ptr(masks), L.ptr(rewards), L.ptr(ret), L.ptr(adv),
                                              L.ptr(stats), L.ptr(ws), stream), "qenv_gae_deterministic")
     else:
@@ -149,17 +156,21 @@ def gae(values, masks, rewards, ddof=0, group=None, normalize=True, deterministi
     if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size(group) > 1:
         torch.distributed.all_reduce(stats, group=group)
-    L.check(L.lib.qenv_adv_normalize(dt, n * N, L.ptr(adv), L.ptr(stats), int(ddof), stream), "qenv_adv_normalize")
-    return ret, adv
+    adv_normalize(adv, stats, ddof, valid=valid)
+    return (ret, adv, stats) if return_stats else (ret, adv)
 
 
-def adv_normalize(adv, stats, ddof=0):
+def adv_normalize(adv, stats, ddof=0, valid=None):
     """(adv - mean) / (std + 1e-10) in place from the float64 moment sums `gae(..., normalize=False, return_stats=True)`
     returned (summed over shards / all-reduced over ranks by the caller): ppo.py:139, ppo_trainer.py:146."""
     if adv.dtype not in (torch.float32, torch.float64) or not adv.is_contiguous() or stats.dtype != torch.float64 or stats.numel() < 3:
         raise ValueError("adv_normalize: adv must be a contiguous float32 / float64 tensor, stats three float64 sums")
     dt = L.F64 if adv.dtype == torch.float64 else L.F32
-    L.check(L.lib.qenv_adv_normalize(dt, adv.numel(), L.ptr(adv), L.ptr(stats), int(ddof), _stream(adv.device)),
+    if valid is not None:
+        if valid.shape != adv.shape:
+            raise ValueError("adv_normalize: valid must have adv's shape")
+        valid = valid.to(adv.dtype).contiguous()
+    L.check(L.lib.qenv_adv_normalize_masked(dt, adv.numel(), L.ptr(adv), L.ptr(valid), L.ptr(stats), int(ddof), _stream(adv.device)),
             "qenv_adv_normalize")
     return adv
 
@@ -267,9 +278,11 @@ class PpoLearner:
             self._buf = (key, dict(h1=mk(H), h2=mk(H), dz2=mk(H), dz1=mk(H), dz3=mk(4), mean=mk(4), value=mk(1)))
         return self._buf[1]
 
-    def gradients(self, obs, actions, old_logprob, adv, returns):
+    def gradients(self, obs, actions, old_logprob, adv, returns, valid=None, n_valid=None):
         """One forward + loss + backward over the batch; fills the .grad buffers.  obs [n, 75, N] float32,
-        actions / old_logprob [n, 4, N], adv / returns [n, N].  Returns the loss dict of `ppo_loss`."""
+        actions / old_logprob [n, 4, N], adv / returns [n, N].  Returns the loss dict of `ppo_loss`.
+        valid [n, N] (in-band warm-up rollouts): rows of weight 0 take no part in the loss; n_valid = their count on THIS
+        learner (computed here with one device-to-host read if not given)."""
         n, K, N = obs.shape
         dev, w = obs.device, self.w
         H = w.hidden
@@ -278,8 +291,14 @@ class PpoLearner:
         f32 = lambda t: t.to(torch.float32).contiguous()
         obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
         self.bucket.zero_()
+        if valid is not None:
+            if not self.fused_loss:
+                raise ValueError("valid rows need the fused-loss backward (hidden 16, 32, 64 or 128)")
+            valid = f32(valid)
+            if n_valid is None:
+                n_valid = int(valid.sum().item())
         if self.fused_loss:
-            return self._gradients_fused(obs, actions, old_logprob, adv, returns, b)
+            return self._gradients_fused(obs, actions, old_logprob, adv, returns, b, valid, n_valid)
         # forward of both heads on the stored observations (the dense kernel takes feature-major chunks)
         for head, out, ft in (("actor", b["mean"], True), ("critic", b["value"], False)):
             W = w.head(head)  # all n stored steps in one launch
@@ -318,7 +337,7 @@ class PpoLearner:
         L.check(L.lib.qenv_weight_grad_deterministic(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb),
                                                      L.ptr(self._wg_ws[key]), stream), "qenv_weight_grad_deterministic")
 
-    def _gradients_fused(self, obs, actions, old_logprob, adv, returns, b):
+    def _gradients_fused(self, obs, actions, old_logprob, adv, returns, b, valid=None, n_valid=None):
         """The same update with the loss inside the backward kernel: per head one backward launch (which recomputes
         the forward anyway and derives d loss / d output from it) + three weight-gradient launches; no forward launch,
         no loss launch, no [n, r, N] <-> [r, n N] copies."""
@@ -329,17 +348,18 @@ class PpoLearner:
         for hid, head in enumerate(("actor", "critic")):
             W = w.head(head)
             n_out = W[4].shape[0]
-            L.check(L.lib.qenv_mlp_backward_ppo(N, n, K, H, hid, L.ptr(obs), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
-                                                L.ptr(returns), std, float(self.eps_clip), float(self.c_value), n * N,
-                                                L.ptr(sums), *[L.ptr(x) for x in W], L.ptr(b["h1"]), L.ptr(b["h2"]),
-                                                L.ptr(b["dz2"]), L.ptr(b["dz1"]), L.ptr(b["dz3"]), stream),
+            L.check(L.lib.qenv_mlp_backward_ppo_masked(N, n, K, H, hid, L.ptr(obs), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
+                                                       L.ptr(returns), L.ptr(valid), std, float(self.eps_clip), float(self.c_value),
+                                                       n * N if valid is None else max(1, int(n_valid)),
+                                                       L.ptr(sums), *[L.ptr(x) for x in W], L.ptr(b["h1"]), L.ptr(b["h2"]),
+                                                       L.ptr(b["dz2"]), L.ptr(b["dz1"]), L.ptr(b["dz3"]), stream),
                     "qenv_mlp_backward_ppo")
             g = [self._state[(head, k)][0] for k in range(6)]
             dz3 = b["dz3"] if n_out == 4 else b["dz3"][:, :n_out].contiguous()
             for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
                 self._weight_grad(N, n, rows_a, rows_b, A, Bm, gw, gb, stream)
-        B = float(n * N)
+        B = float(n * N) if valid is None else float(max(1, int(n_valid)))
         if self.learn_std:  # before the all-reduce: the std's gradient travels in the same bucket
             self.bucket.flat[-1] = (sums[4] / B - self.c_entropy * 4.0 / std).to(torch.float32)
         self.bucket.all_reduce_mean_(self.group)
@@ -409,6 +429,17 @@ class PpoLearner:
         of a step stay together, so nothing is gathered sample by sample)."""
         n = rollout.t
         out = []
+        valid = getattr(rollout, "valid", None)
+        if valid is not None:   # in-band warm-up rollout: the warm-up rows carry weight 0 (full-batch epochs only)
+            if minibatch is not None:
+                raise ValueError("minibatch epochs over an in-band rollout are not implemented (full-batch epochs are)")
+            v32 = valid[:n].to(torch.float32).contiguous()
+            n_valid = int(v32.sum().item())
+            for _ in range(self.K_epochs):
+                out.append(self.gradients(rollout.obs[:n], rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n],
+                                          valid=v32, n_valid=n_valid))
+                self.adam_step()
+            return out
         if graph and minibatch is None and not self.learn_std and self.fused_loss and not (
                 self.group is not False and torch.distributed.is_available() and torch.distributed.is_initialized()
                 and torch.distributed.get_world_size(self.group if self.group is not None else None) > 1):
@@ -465,10 +496,19 @@ class PolicyRollout:
     streams shard-invariant)."""
 
     def __init__(self, env: BatchedQuad, weights: ActorCriticWeights, horizon, store_obs=False, auto_reset=False,
-                 seed=0, env_offset=0):
+                 seed=0, env_offset=0, inband=False, key_by_episode=False):
+        """inband (with auto_reset): IN-BAND warm-up (qenv_ppo_step, include/qenv.h) -- an env whose episode ends is reset in
+        the step kernel's epilogue and the T warm-up steps of that reset are its next T regular steps (zero_control forced,
+        window refilled in place); those rows of the rollout get `valid` = 0 and are left out of GAE's moments and of the
+        loss (finish() and PpoLearner.update take care of it).  No warm-up launch: a step is policy + env step.  The valid
+        rows of an env are the samples the default schedule collects for the same episodes, T rows later per restart.
+        key_by_episode: an env's n-th restart draws its state from the stream of n, not of the step it happens in."""
         assert env.direct_control_flag, "the PPO controller commands the four rotors (direct_control=1)"
         self.env, self.w, self.horizon = env, weights, int(horizon)
         self.auto_reset, self.seed, self.env_offset = bool(auto_reset), int(seed), int(env_offset)
+        self.inband, self.key_by_episode = bool(inband), bool(key_by_episode)
+        if self.inband and not self.auto_reset:
+            raise ValueError("inband=True is a schedule of the auto-reset rollout (auto_reset=True)")
         self.keep_init = False  # True: auto-resets also leave the drawn initial states in `self.init`
         # With the observations stored, V(s_t) of every step is evaluated in ONE launch over the whole horizon at
         # finish() instead of one launch per step: same kernel, same arithmetic (bit-identical values), but each
@@ -486,6 +526,7 @@ class PolicyRollout:
         self.logprobs = torch.zeros(H, 4, N, device=dev, dtype=dt)
         self.rewards = torch.zeros(H, N, device=dev, dtype=dt)
         self.masks = torch.ones(H, N, device=dev, dtype=dt)
+        self.valid = torch.ones(H, N, device=dev, dtype=dt) if self.inband else None   # 0: a restarted env's warm-up row
         self.values = torch.zeros(H + 1, N, device=dev, dtype=dt)
         self.obs = torch.zeros(H, 15 * env.T, N, device=dev, dtype=torch.float32) if store_obs else None
         self.mean = torch.zeros(4, N, device=dev, dtype=dt)
@@ -514,10 +555,16 @@ class PolicyRollout:
         """One env step for all envs.  noise: injected [4, N] standard normal."""
         env, t, w = self.env, self.t, self.w
         store = None if self.obs is None else self.obs[t]
-        if (self.auto_reset and self.overlap and self.fused_act and not deterministic and not self.keep_init
-                and not env.robust_control and (w.critic is None or self.batched_critic)):
+        fused = (self.auto_reset and self.overlap and self.fused_act and not deterministic and not self.keep_init
+                 and not env.robust_control and (w.critic is None or self.batched_critic))
+        if self.inband and not fused:
+            raise ValueError("inband=True needs the fused step (stochastic policy, stored observations or no critic, no "
+                             "robust_control, keep_init off)")
+        if fused:
             env.ppo_step(w, self.seed, self.global_step + 1, self.env_offset, self.actions[t], self.logprobs[t], self.mean,
-                         store, self.rewards[t], self.done, self.masks[t], noise=noise)
+                         store, self.rewards[t], self.done, self.masks[t], noise=noise,
+                         valid=None if self.valid is None else self.valid[t], inband=self.inband,
+                         key_by_episode=self.key_by_episode)
             self.t += 1
             self.global_step += 1
             return
@@ -573,7 +620,7 @@ class PolicyRollout:
         else:
             self.values[n].zero_()
         return gae(self.values[:n + 1], self.masks[:n], self.rewards[:n], ddof=ddof, group=group, deterministic=deterministic,
-                   normalize=normalize, return_stats=return_stats)
+                   normalize=normalize, return_stats=return_stats, valid=None if self.valid is None else self.valid[:n])
 
 
 class StreamShardedRollout:
@@ -639,7 +686,9 @@ class StreamShardedRollout:
                 per_t.append(L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[x.data_ptr() for x in W], float(w.std), None,
                                            int(ro.seed), 0, int(ro.env_offset), ro.mean.data_ptr(), ro.actions[t].data_ptr(),
                                            ro.logprobs[t].data_ptr(), None if ro.obs is None else ro.obs[t].data_ptr(),
-                                           ro.rewards[t].data_ptr(), ro.done.data_ptr(), ro.masks[t].data_ptr()))
+                                           ro.rewards[t].data_ptr(), ro.done.data_ptr(), ro.masks[t].data_ptr(),
+                                           None if ro.valid is None else ro.valid[t].data_ptr(), int(ro.inband),
+                                           int(ro.key_by_episode)))
             out.append((env._h, per_t, float(w.std)))
         self._C = C
         return out
@@ -691,8 +740,8 @@ class StreamShardedRollout:
         if group is not False and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size(group) > 1:
             torch.distributed.all_reduce(self._stats, group=group)
-        for o in outs:
-            adv_normalize(o[1], self._stats, ddof)
+        for o, ro in zip(outs, self.ros):
+            adv_normalize(o[1], self._stats, ddof, valid=None if ro.valid is None else ro.valid[:ro.t])
         return [(o[0], o[1]) for o in outs]
 
     def synchronize(self):

@@ -499,7 +499,8 @@ class BatchedQuad:
                                       L.ptr(out), L.ptr(logprob), L.ptr(obs_store)), "qenv_policy_act")
         return out
 
-    def ppo_step(self, weights, seed, step, env_offset, actions, logprob, mean, obs_store, reward, done, mask, noise=None):
+    def ppo_step(self, weights, seed, step, env_offset, actions, logprob, mean, obs_store, reward, done, mask, noise=None,
+                 valid=None, inband=False, key_by_episode=False):
         """One step of the rollout worker loop with auto-reset (qenv_ppo_step): policy_act + step(NO_AUX, push_window) +
         reset_sampled(mask=done), bit-identical buffers, with the reset envs' warm-up overlapped with the next step (it
         stays PENDING after the call: ppo_flush(), or any other call that touches the env, completes it)."""
@@ -511,7 +512,7 @@ class BatchedQuad:
         for t, nm in ((actions, "actions"), (logprob, "logprob"), (mean, "mean")):
             self._check_buf(t, 4, nm)
         self._check_buf(obs_store, 15 * self.T, "obs_store", torch.float32)
-        for t, nm in ((reward, "reward"), (mask, "mask")):
+        for t, nm in ((reward, "reward"), (mask, "mask"), (valid, "valid")):
             self._check_buf(t, 0, nm)
         self._check_buf(done, 0, "done", torch.uint8)
         nz = None if noise is None else self._as_rows(noise, 4, "noise")
@@ -520,7 +521,8 @@ class BatchedQuad:
                           None if nz is None else nz.data_ptr(), int(seed), int(step), int(env_offset),
                           None if mean is None else mean.data_ptr(), actions.data_ptr(),
                           None if logprob is None else logprob.data_ptr(), None if obs_store is None else obs_store.data_ptr(),
-                          reward.data_ptr(), done.data_ptr(), None if mask is None else mask.data_ptr())
+                          reward.data_ptr(), done.data_ptr(), None if mask is None else mask.data_ptr(),
+                          None if valid is None else valid.data_ptr(), int(bool(inband)), int(bool(key_by_episode)))
         self._bind()
         L.check(L.lib.qenv_ppo_step(self._h, C.byref(a)), "qenv_ppo_step")
 

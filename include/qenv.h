@@ -33,10 +33,13 @@
 extern "C" {
 #endif
 
-/* 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
+/* 5: qenv_ppo_step_args gains out_valid / inband / key_by_episode (in-band warm-up); qenv_gae_masked,
+ *    qenv_adv_normalize_masked, qenv_mlp_backward_ppo_masked (the `valid` rows of such a rollout); qenv_mlp_prepare /
+ *    qenv_mlp_image_bytes; qenv_reward_function, qenv_mix.
+ * 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
  * 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
-#define QENV_ABI_VERSION 4
+#define QENV_ABI_VERSION 5
 
 typedef struct qenv_s *qenv_t;
 
@@ -374,6 +377,19 @@ typedef struct {
     void *out_reward;                           /* [N] */
     uint8_t *out_done;                          /* [N] */
     void *out_mask;                             /* [N]: 1 - done */
+    /* ABI 5.  inband != 0: IN-BAND warm-up -- the schedule above without its third part.  An env that finishes in a
+     * POLICY step still restarts in that step kernel's epilogue, but the T warm-up steps of its reset (quadrotor_env.py
+     * :448-453) are its next T REGULAR steps: recognised by the env's own step counter (i < T) they apply zero_control
+     * whatever the policy sampled, push their window slice into the common ring slot, and report out_valid = 0; the
+     * caller excludes those rows from GAE's normalisation moments and from the loss (qenv_gae / qenv_adv_normalize /
+     * qenv_mlp_backward_ppo take the same array).  No list, no warm-up launch, nothing pending after the call: a
+     * rollout step is policy + step.  The valid rows of an env are exactly the samples the schedule above collects for
+     * the same episodes (same dynamics, same reward, same windows); they sit T rows later per finished episode.
+     * key_by_episode != 0 (either schedule): the next initial state of an env is drawn from the Philox stream of ITS
+     * OWN restart count instead of the stream of `step`, so that the n-th episode of an env starts from the same state
+     * whenever it starts. */
+    void *out_valid;                            /* [N] in the handle's dtype, nullable: 0 for a warm-up row, else 1 */
+    int32_t inband, key_by_episode;
 } qenv_ppo_step_args;
 int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args *args);
 int qenv_ppo_flush(qenv_t q);
@@ -439,6 +455,16 @@ int qenv_gae_deterministic(int dtype, int64_t n_envs, int n_steps, const void *v
                            void *stream);
 int qenv_adv_normalize(int dtype, int64_t n_elems, void *adv, const double *stats, int ddof,
                        void *stream);
+/* The same two for an in-band warm-up rollout (qenv_ppo_step with inband): valid [n_steps][N] in `dtype`, 0 for the rows
+ * that were a restarted env's warm-up steps.  Such rows follow a terminal row (mask 0) or open the horizon, so no valid
+ * row's recurrence reads them; their advantage is set to 0 (and stays 0 through the normalisation) and they are left out
+ * of the moments: stats[0] receives the number of VALID rows.  workspace: null, or qenv_gae_workspace_bytes(n_envs)
+ * bytes for the fixed-order sums of qenv_gae_deterministic.  valid = null is qenv_gae / qenv_adv_normalize. */
+int qenv_gae_masked(int dtype, int64_t n_envs, int n_steps, const void *values, const void *masks,
+                    const void *rewards, const void *valid, void *returns, void *adv, double *stats,
+                    void *workspace, void *stream);
+int qenv_adv_normalize_masked(int dtype, int64_t n_elems, void *adv, const void *valid, const double *stats,
+                              int ddof, void *stream);
 
 /* Replaces the loss of PPO.update (environment/controller/ppo.py:185-203): per sample
  *   logp_k = Normal(mean_k, std).log_prob(action_k); ratio = exp(sum_k logp_k - sum_k old_logprob_k)
@@ -482,6 +508,15 @@ int qenv_mlp_backward_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, in
                           double std, double eps_clip, double c_value, int64_t batch, double *sums, const float *W1,
                           const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
                           float *h1, float *h2, float *dz2, float *dz1, float *dz3, void *stream);
+/* qenv_mlp_backward_ppo with per-sample weights [c][N] (float, nullable = all ones): a sample of weight 0 contributes
+ * neither to the loss sums nor to any gradient (its seed is zero) -- the warm-up rows of an in-band rollout; `batch` is
+ * then the number of samples of non-zero weight (stats[0] of qenv_gae_masked). */
+int qenv_mlp_backward_ppo_masked(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float *obs,
+                                 const float *actions, const float *old_logprob, const float *adv,
+                                 const float *returns, const float *weight, double std, double eps_clip,
+                                 double c_value, int64_t batch, double *sums, const float *W1, const float *b1,
+                                 const float *W2, const float *b2, const float *W3, const float *b3, float *h1,
+                                 float *h2, float *dz2, float *dz1, float *dz3, void *stream);
 int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float *A, const float *B,
                      float *C, float *rowsum, void *stream);
 /* qenv_weight_grad with a fixed summation order (bit-reproducible gradients, hence training runs): every workgroup

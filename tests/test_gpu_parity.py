@@ -330,12 +330,13 @@ def test_ppo_actor_in_loop_teacher_forced_golden(aq, oracle, dt):
     (i) policy: the reference's RECORDED windows (the fixture holds the first 8 of each seed) written into the ring -> the
         actor forward is within 2e-6 of the action the reference's torch forward produced from that window;
     (ii) env: the reference's RECORDED action of every step goes into qenv_step for all 500 steps of all four seeds.  The
-        device stays within 1e-9 of the fp64 ORACLE fed the same actions.  Against the fixture itself the first 100 steps are
+        device stays within 1e-9 of the fp64 ORACLE fed the same actions.  Against the fixture itself the first 10 steps are
         within the 1e-5 spec and no better than ~1e-7 from the first step on, for a reason on the reference's side: its
         eval loop hands quad.step a float32 action (torch), so numpy evaluates f2F -- (a + 1) T2WR M G / 8, the rotor speeds,
         their sum -- in float32 (quadrotor_env.py:247-272): a 6e-8 relative rounding of the thrust in every step that the
         open loop (no feedback under teacher forcing) then amplifies; the oracle measures exactly the same drift
-        (7e-8 at step 1, 5e-6 at step 100) and neither it nor the kernels copy that numpy-version-dependent promotion;
+        (worst seed: 3e-7 at step 1, 2e-6 at step 10, 2e-4 at step 100) and neither it nor the kernels copy that
+        numpy-version-dependent promotion;
     (iii) the window the device builds after each of the first recorded steps is the reference's dl_input window."""
     gs = [golden(f"g6_ppo128_seed{s}") for s in (1, 2, 3, 4)]
     wg = golden("g9_mlp_N128")
@@ -361,7 +362,7 @@ def test_ppo_actor_in_loop_teacher_forced_golden(aq, oracle, dt):
         refs.append(r)
     env.reset(torch.from_numpy(x0), return_history=False, push_window=True)
     obs = torch.empty(75, 4, device="cuda", dtype=torch.float32)
-    worst_oracle = worst_fixture_100 = worst_win = 0.0
+    worst_oracle = worst_fixture_10 = worst_win = 0.0
     for k in range(500):
         if k < 8:  # (iii) the device's own window before step k against the reference's
             env.mlp_forward(w, "actor", out=mean, obs_store=obs)
@@ -373,10 +374,10 @@ def test_ppo_actor_in_loop_teacher_forced_golden(aq, oracle, dt):
             r.step(gs[e]["actions"][k])
         st = _np(env.state).T
         worst_oracle = max(worst_oracle, scaled_err(st, np.array([r.state for r in refs])))
-        if k < 100:
-            worst_fixture_100 = max(worst_fixture_100, scaled_err(st, np.stack([g["traj"][k, :13] for g in gs], 0)))
+        if k < 10:
+            worst_fixture_10 = max(worst_fixture_10, scaled_err(st, np.stack([g["traj"][k, :13] for g in gs], 0)))
     assert worst_oracle < 1e-9, worst_oracle
-    assert worst_fixture_100 < SPEC, worst_fixture_100
+    assert worst_fixture_10 < SPEC, worst_fixture_10
     assert worst_win < 2e-6, worst_win   # fp32 of numbers that agree to ~1e-7 (see (ii))
     for e, r in enumerate(refs):
         assert bool(env.solved[e]) == bool(r.solved) and bool(env.done[e]) == bool(r.done)
