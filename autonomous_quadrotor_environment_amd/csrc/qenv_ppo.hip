@@ -535,7 +535,17 @@ __device__ __forceinline__ void mlp3_layer3_finish(float o[4]) {
     for (int k = 0; k < 4; ++k) o[k] = o[k] + __shfl_xor(o[k], 32);
 }
 
-template <int BLOCK, bool SAMPLE>
+// N_MFMA times { one MFMA, then N_VALU VALU instructions }: the interleave a scheduling region is asked for (the region's
+// other instructions -- LDS reads, waits -- go where the scheduler likes)
+template <int N_MFMA, int N_VALU> __device__ __forceinline__ void sgb_interleave() {
+#pragma unroll
+    for (int m = 0; m < N_MFMA; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, N_VALU, 0);
+    }
+}
+
+template <int BLOCK, bool SAMPLE, bool PIPE = true>
 __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
     using namespace mlp3;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
@@ -624,10 +634,15 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
             }
         }
         MLP_STAMP(3 + 6 * stamp_tile);
-        // ---- layer 1 (k_mlp's split products, same order)
+        // ---- layers 1-3 as a software pipeline: every matrix-core chain (30 MFMAs of a layer-1 output tile, 48 of a layer-2
+        // one) shares its scheduling region with the vector work of the PREVIOUS output tile (tanh + the bf16 split that
+        // turns it into the next layer's B operand, or tanh + layer 3), and sched_group_barrier asks for one MFMA followed
+        // by a handful of VALU instructions throughout: ~5 VALU issue slots hide under a v_mfma_f32_32x32x16_bf16 in the
+        // same wave's stream (tools/ubench/mfma_fill.hip), while an MFMA-only phase of one wave next to a VALU-only phase
+        // of the other wave of the SIMD -- what the un-pipelined loop produced -- costs both (81 cycles per MFMA).
         f32x16 acc1[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        bf16x8 bsp[NT][2][3];
+        auto l1_chain = [&](int t) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
             const uint4* frag = W1f + (size_t)t * KS16 * 3 * 64 + lane;
@@ -643,32 +658,19 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
                 acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][1], acc1[t], 0, 0, 0);
                 acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][0], acc1[t], 0, 0, 0);
             }
+        };
+        auto l1_finish = [&](int t) {   // tanh, then the activations as bf16 terms (layer 2's B operand)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
-        }
-        MLP_STAMP(4 + 6 * stamp_tile);
-        // ---- the layer-1 activations of this lane as bf16 terms (the B operand of every layer-2 output tile)
-        bf16x8 bsp[NT][2][3];
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
                 float v8[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v8[i] = acc1[ti][8 * jh + i];
-                split3x8(v8, bsp[ti][jh][0], bsp[ti][jh][1], bsp[ti][jh][2]);
+                for (int i = 0; i < 8; ++i) v8[i] = acc1[t][8 * jh + i];
+                split3x8(v8, bsp[t][jh][0], bsp[t][jh][1], bsp[t][jh][2]);
             }
-        // the NEXT tile's window is requested here: its 40 registers are free again (the window lives on as xsp until layer 1
-        // ends, the activations as bsp from here), and layer 2 + 3 give the loads ~10 k cycles to land
-        if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);
-        MLP_STAMP(5 + 6 * stamp_tile);
-        // ---- layer 2 on the matrix cores, layer 3 on the vector lanes behind each finished output tile
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x16 acc2;
+        };
+        auto l2_chain = [&](int t, f32x16& acc2) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
             const uint4* frag = W2f + (size_t)t * NT * 2 * 3 * 64 + lane;
@@ -687,9 +689,57 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc2, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
                 }
+        };
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
+        if constexpr (PIPE) {
+            __builtin_amdgcn_sched_barrier(0);
+            l1_chain(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 1; t < NT; ++t) {   // chain t beside tanh + split of t - 1
+                l1_chain(t);
+                l1_finish(t - 1);
+                sgb_interleave<30, 6>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x16 acc2[2];
+            l2_chain(0, acc2[0]);            // its first 36 MFMAs read bsp[0..2] only: beside tanh + split of layer-1 tile 3
+            l1_finish(NT - 1);
+            sgb_interleave<48, 4>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);   // see below
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 1; t < NT; ++t) {   // chain t beside tanh + layer 3 of t - 1
+                l2_chain(t, acc2[t & 1]);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc2[(t - 1) & 1][j] = fast_tanh(acc2[(t - 1) & 1][j]);
+                mlp3_layer3(W3t, t - 1, half, acc2[(t - 1) & 1], o);
+                sgb_interleave<48, 3>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[(NT - 1) & 1][j] = fast_tanh(acc2[(NT - 1) & 1][j]);
+            mlp3_layer3(W3t, NT - 1, half, acc2[(NT - 1) & 1], o);
+        } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { l1_chain(t); l1_finish(t); }
+        MLP_STAMP(4 + 6 * stamp_tile);
+        // the NEXT tile's window is requested here: its 40 registers are free again (the window lives on as xsp until layer 1
+        // ends, the activations as bsp from here), and layer 2 + 3 give the loads ~10 k cycles to land
+        if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);
+        MLP_STAMP(5 + 6 * stamp_tile);
+        // ---- layer 2 on the matrix cores, layer 3 on the vector lanes behind each finished output tile
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc2;
+            l2_chain(t, acc2);
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh(acc2[j]);
             mlp3_layer3(W3t, t, half, acc2, o);
+        }
         }
         mlp3_layer3_finish(o);
         MLP_STAMP(6 + 6 * stamp_tile);

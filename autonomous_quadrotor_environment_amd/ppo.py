@@ -711,8 +711,10 @@ class StreamShardedRollout:
                 self._fast = self._fast_args() or False
             if self._fast:
                 C = self._C
-                for (h, per_t, std), ro in zip(self._fast, self.ros):
-                    ro.env._ensure_prepared(ro.w, "actor")
+                for (h, per_t, std), ro, st in zip(self._fast, self.ros, self.streams):
+                    if not ro.env._prepared_is_current(ro.w, "actor"):   # rebuilt on the SHARD's stream (the handle stays bound to it)
+                        with torch.cuda.stream(st):
+                            ro.env._ensure_prepared(ro.w, "actor")
                     a = per_t[ro.t]
                     a.step = ro.global_step + 1
                     a.std = float(ro.w.std)  # always: a learner / schedule may move the std (and move it back) between steps

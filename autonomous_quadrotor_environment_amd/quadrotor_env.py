@@ -444,6 +444,14 @@ class BatchedQuad:
             raise ValueError(f"{name}: expected a contiguous {dtype} tensor of shape {shp} on {self.device}, got "
                              f"{tuple(t.shape)} {t.dtype} on {t.device}")
 
+    def _prepared_is_current(self, weights, head):
+        """True if nothing would be launched by _ensure_prepared (no prepared form for this shape, or the image is current)."""
+        W = weights.head(head)
+        if self.T != 5 or L.lib.qenv_mlp_image_bytes(int(W[0].shape[1]), int(W[0].shape[0])) == 0:
+            return True
+        cur = self.__dict__.get("_prep", {}).get(0 if head == "actor" else 1)
+        return cur is not None and cur[0] == (id(weights), getattr(weights, "version", 0), W[0].data_ptr())
+
     def _ensure_prepared(self, weights, head):
         """Build / refresh this handle's prepared image of `weights.head(head)` (qenv_mlp_prepare: the weights in the
         forward kernel's LDS layout) when the weight object or its version changed.  Only the 75-128-128-n policy on a

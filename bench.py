@@ -73,9 +73,8 @@ MLP_FLOPS = 2 * (75 * 128 + 128 * 128 + 128 * 4)  # per env and forward (SURVEY.
 MFMA_F32_PEAK_TFLOPS = 157.3
 MAX_CLOCK_GHZ = 2.4
 # matrix-core instructions k_mlp<128,5,BF16=2> executes per 32-env tile: name -> (count, pipe cycles each, flops each)
-# layer 1: 4 output tiles x 5 k-steps x 6 split products; layer 2: 4 x 4 x 2 x 6; layer 3: see csrc/qenv_ppo.hip
-MLP_MFMA = {"v_mfma_f32_32x32x16_bf16": (120 + 192, 32, 2 * 32 * 32 * 16),
-            "v_mfma_f32_32x32x2_f32": (64, 64, 2 * 32 * 32 * 2)}
+# layer 1: 4 output tiles x 5 k-steps x 6 split products; layer 2: 4 x 4 x 2 x 6 (k_mlp_v3, csrc/qenv_ppo.hip)
+MLP_MFMA = {"v_mfma_f32_32x32x16_bf16": (120 + 192, 32, 2 * 32 * 32 * 16)}   # round 3: layer 3 runs on the vector lanes
 HANDLES = {  # --dtype -> (torch dtype of the rows, compute mode, arithmetic type reported as `dtype`)
     "f32": (torch.float32, None, "f32"),
     "mix": (torch.float64, "f32", "f32"),
@@ -106,6 +105,10 @@ def parse(argv=None):
                    help="config5: the rank's env range as this many shards on their own HIP streams (1 = one batch)")
     p.add_argument("--policy", default="trained", choices=["trained", "random"],
                    help="configs 4 / 5: the reference's checked-in N=128 weights (default, SURVEY.md 8d) or random-init weights")
+    p.add_argument("--schedule", default="inband", choices=["inband", "list"],
+                   help="config5: inband = a finished env restarts in the step kernel and its T warm-up steps ride the next T "
+                        "regular steps (rows flagged invalid; a step is policy + env step); list = round 2's schedule (a "
+                        "warm-up launch over the list of finished envs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--extras", action="store_true", help="also time the other integrators / launch modes")
@@ -236,7 +239,7 @@ def load_policy(policy, dev):
 
 
 def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_global, shards=1, make_env=None, n_local=0,
-                    dev=None, policy="trained"):
+                    dev=None, policy="trained", inband=True):
     """config 4 / 5: the rollout collector of ppo.py:223-269 on the device."""
     from autonomous_quadrotor_environment_amd import PolicyRollout
     from autonomous_quadrotor_environment_amd import ActorCriticWeights
@@ -266,7 +269,7 @@ def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_globa
     if shards > 1:  # the rank's range as independent shards on their own streams (StreamShardedRollout's docstring)
         from autonomous_quadrotor_environment_amd import StreamShardedRollout
         sro = StreamShardedRollout(make_env, n_local, w, chunk, shards=shards, seed=seed, env_offset=env_offset, device=dev,
-                                   store_obs=True, auto_reset=True)
+                                   store_obs=True, auto_reset=True, inband=inband)
 
         def sharded_body():
             sro.t = 0
@@ -275,7 +278,7 @@ def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_globa
             sro.finish(ddof=0, group=None)
             all_gather_returns(sro.last_returns(), n_global)
         return sharded_body, chunk, sro
-    ro = PolicyRollout(env, w, chunk, store_obs=True, auto_reset=True, seed=seed, env_offset=env_offset)
+    ro = PolicyRollout(env, w, chunk, store_obs=True, auto_reset=True, seed=seed, env_offset=env_offset, inband=inband)
 
     def body():  # one horizon: rollout, GAE (global normalisation), episode returns all-gathered over RCCL
         ro.t = 0
@@ -400,7 +403,7 @@ def pick(total, cap, mult=1):
 
 
 def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_graph, envs, rank, world, dev,
-            min_seconds, stream_shards=1, policy="trained"):
+            min_seconds, stream_shards=1, policy="trained", schedule="inband"):
     """One workload on this rank's shard: W untimed warm-up steps, the K-step region repeated (median), the dominant
     kernel's per-launch time by HIP events, and its roofline block.  Returns (result dict, env, runner info)."""
     from autonomous_quadrotor_environment_amd.distributed import all_gather_returns, shard_range
@@ -435,7 +438,7 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
         if ppo:
             return make_ppo_runner(env, controller, c, graph_ok and (not no_graph) and controller == "ppo_actor",
                                    seed=4, env_offset=lo, n_global=n_global, shards=shards, make_env=make_env,
-                                   n_local=hi - lo, dev=dev, policy=policy)
+                                   n_local=hi - lo, dev=dev, policy=policy, inband=(schedule == "inband"))
         return make_runner(env, controller, flags, launch, c, not no_graph) + (None,)
     # Episodes: the closed-loop workloads without an auto-reset (LQR / PID rollouts, actor in the loop) run EPISODES of 500
     # steps like the reference's scripts (lqr_quad.py / ppo_quad_eval.py run one episode per reset); without this the
@@ -537,7 +540,7 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
         executed = tiles * flop_tile / t_s / 1e12
         tfl = MLP_FLOPS * n_l / t_s / 1e12
         roofline = {"bound": "mfma", "achieved": executed, "peak": executed / busy, "unit": "TFLOP/s", "frac": busy,
-                    "traffic": None, "kernel": "k_mlp<128,5> (actor forward)", "kernel_us": mlp_us,
+                    "traffic": None, "kernel": "k_mlp_v3 (actor forward 75-128-128-4)", "kernel_us": mlp_us,
                     "envs_per_launch": n_l, "mlp_forwards_per_env_step": heads,
                     "achieved_is": "EXECUTED matrix-core flops per launch (the instruction mix below, padded tiles included) / "
                                    "launch time; `peak` = that same mix with the matrix pipe of all 1024 SIMDs busy every cycle "
@@ -560,7 +563,11 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
            "envs_per_gpu": hi - lo, "global_envs": n_global, "controller": controller, "desc": desc, "roofline": roofline,
            "all_gather_len": None if gathered is None else int(gathered.numel()), "all_gather_us": gather_us,
            "stream_shards": shards, "episode_steps": EPISODE_STEPS if episodic else None,
-           "weights": (policy_label(policy) if ppo else None)}
+           "weights": (policy_label(policy) if ppo else None),
+           "schedule": (schedule if controller == "ppo_rollout" else None)}
+    if controller == "ppo_rollout" and schedule == "inband":   # share of the rollout rows that are policy steps (the others are
+        ros = [ro] if shards == 1 else ro.ros                   # the restarted envs' warm-up steps: env steps, but no samples)
+        res["valid_row_fraction"] = float(sum(float(r.valid[:r.t].sum()) for r in ros) / max(1, sum(r.valid[:r.t].numel() for r in ros)))
     return res, env, (controller, flags, no_graph, bytes_per_step, n_global)
 
 
@@ -624,6 +631,9 @@ def slice_of(r, name, handle):
            "achieved": rf["achieved"], "roofline_unit": rf["unit"], "stream_shards": r["stream_shards"],
            "episode_steps": r["episode_steps"], "envs_per_kernel_launch": rf.get("envs_per_launch", r["envs_per_gpu"]),
            "all_gathered_returns": r["all_gather_len"], "all_gather_us": r["all_gather_us"]}
+    for k in ("schedule", "valid_row_fraction"):
+        if r.get(k) is not None:
+            out[k] = r[k]
     for k in ("valu", "mfma_cycles_per_tile", "algorithmic", "bf16_products_tflops"):
         if k in rf:
             out[k] = rf[k]
@@ -647,7 +657,7 @@ def main():
 
     res, env, (controller, flags, no_graph, bytes_per_step, n_global) = measure(
         args.workload, handle, args.integrator, args.launch, args.steps, args.warmup, args.chunk, args.no_graph,
-        args.envs, rank, world, dev, args.min_seconds, args.stream_shards, args.policy)
+        args.envs, rank, world, dev, args.min_seconds, args.stream_shards, args.policy, args.schedule)
     ppo = controller.startswith("ppo")
     qualified = WORKLOADS[args.workload][5]
     out = {
@@ -664,7 +674,8 @@ def main():
                    "steps_per_graph_replay_or_launch": res["chunk"], "hip_graph": res["hip_graph"],
                    "parallelism": f"env-sharded x{world}", "stream_shards_per_gpu": res["stream_shards"],
                    "episode_steps": res["episode_steps"],
-                   "finite": res["finite"], "weights": res["weights"],
+                   "finite": res["finite"], "weights": res["weights"], "schedule": res.get("schedule"),
+                   "valid_row_fraction": res.get("valid_row_fraction"),
                    "all_gathered_returns": res["all_gather_len"], "all_gather_us": res["all_gather_us"]},
         "timing": {"regions": res["regions"], "statistic": "median of the K-step regions (each barrier+sync bracketed)",
                    "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
@@ -757,7 +768,7 @@ def main():
             plan = (("config4", "config4", 250, 50, "trained"), ("config5", "config5", 128, 128, "trained"))
         for key, name, k_steps, w_steps, pol in plan:
             r, e_, _ = measure(name, WORKLOADS[name][5], "rk45", "fused", k_steps, w_steps, 0, False, 0, rank, world, dev, 0.2,
-                               args.stream_shards, pol or "trained")
+                               args.stream_shards, pol or "trained", args.schedule)
             subs[key] = slice_of(r, name, WORKLOADS[name][5])
             subs[key]["steps"] = k_steps
             del e_
