@@ -559,38 +559,54 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
     int64_t gtile = (int64_t)blockIdx.x * waves_per_block + wave;
     uint32_t N32 = (uint32_t)a.N;
 
-    // window element (16 sk + 8 half + i) of env `e32` of chunk `chunk`: 40 loads per lane, no predicates (out-of-range envs
-    // read env N - 1 and are masked at the stores; the five padded elements are zeroed by a select)
+    // ---- the window: 40 loads per lane (element 16 sk + 8 half + i of the lane's env), as raw buffer loads whose byte offset
+    // is (ring row of that element) * N * 4 + env * 4.  The 80 row offsets depend on the ring head only: a table in LDS,
+    // [half][40], read back ten ds_read_b128 per request -- the per-load address arithmetic is ONE v_add (the 64-bit
+    // multiply-adds and selects it replaces were ~6 VALU per load, 2 k cycles per request).  The five padded elements
+    // (k >= 75) carry an offset beyond the buffer: the hardware range check returns 0 for them, as for the lanes of a
+    // ragged last tile.
+    uint32_t* rowtab = reinterpret_cast<uint32_t*>(lds4 + IMAGE_UINT4);   // 80 words behind the image
+    if (threadIdx.x < 80) {
+        const int hf = threadIdx.x / 40, slot = threadIdx.x % 40;        // slot = 8 sk + i
+        const int k = 16 * (slot >> 3) + 8 * hf + (slot & 7);
+        int sl = a.head + (k < KW ? k : 0) / 15;
+        if (sl >= TW) sl -= TW;
+        rowtab[threadIdx.x] = k < KW ? (uint32_t)(sl * 15 + k % 15) * N32 * 4u : 0x80000000u;
+    }
+    __syncthreads();
     float xw[KS16][8];
+    const uint4* rowq = reinterpret_cast<const uint4*>(rowtab) + 10 * half;
     auto request_window = [&](int64_t g) {
         const int64_t chunk = a.n_chunks > 1 ? g / tiles_per_chunk : 0;
         const int64_t e = (g - chunk * tiles_per_chunk) * 32 + col;
-        const uint32_t e32 = (uint32_t)(e < a.N ? e : a.N - 1);
-        const float* __restrict__ winc = a.win + chunk * (int64_t)KW * a.N;
-        int hsel = half;
-        uint32_t n32 = N32;
-        int head = a.head;
-        asm volatile("" : "+s"(n32), "+s"(head), "+v"(hsel));  // the 75 row selects / offsets are recomputed per call: hoisted out of the
-                                                               // tile loop they are 150 SGPRs (spilled)
+        const uint32_t e4 = e < a.N ? (uint32_t)e * 4u : 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.win + chunk * (int64_t)KW * a.N), 0,
+                                                                            (int)((uint32_t)KW * N32 * 4u), 0x00020000);
 #pragma unroll
-        for (int sk = 0; sk < KS16; ++sk)
+        for (int q = 0; q < 10; ++q) {
+            const uint4 r = rowq[q];
+            const uint32_t off[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k0 = 16 * sk + i, k1 = 16 * sk + 8 + i;  // this element for lane half 0 / 1
-                int sl0 = head + (k0 < KW ? k0 : 0) / 15, sl1 = head + (k1 < KW ? k1 : 0) / 15;  // wave-uniform
-                if (sl0 >= TW) sl0 -= TW;
-                if (sl1 >= TW) sl1 -= TW;
-                const uint32_t r0 = (uint32_t)(sl0 * 15 + (k0 < KW ? k0 : 0) % 15);
-                const uint32_t r1 = (uint32_t)(sl1 * 15 + (k1 < KW ? k1 : 0) % 15);
-                float x = winc[(hsel ? r1 : r0) * n32 + e32];
-                if (k1 >= KW) x = (hsel || k0 >= KW) ? 0.f : x;
-                xw[sk][i] = x;
-            }
+            for (int c = 0; c < 4; ++c)
+                xw[(4 * q + c) >> 3][(4 * q + c) & 7] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off[c] + e4, 0, 0));
+        }
     };
     if (gtile < n_tiles) request_window(gtile);   // in flight during the staging
 
+    // ---- the weights.  With a prepared image: W1 / W3 / biases by every wave, barrier; W2 (96 of the 159 KiB) by the UPPER
+    // half of the waves while the lower half already runs layer 1 of its first tile -- a second barrier in front of layer 2
+    // joins them, after which the two waves of every SIMD are one layer-1 phase apart (the stagger that lets one wave's
+    // vector-heavy phase meet the other's matrix-heavy one).  Without an image every wave splits its share of the fp32
+    // weights as before.
+    bool w2_pending = false;
+    const bool upper = wave >= waves_per_block / 2;
+    auto copy_image = [&](int first, int count, int tid, int nthr) {
+        for (int i = tid; i < count; i += nthr) lds4[first + i] = a.image[first + i];
+    };
     if (a.image) {
-        for (int i = threadIdx.x; i < IMAGE_UINT4; i += BLOCK) lds4[i] = a.image[i];
+        copy_image(W1F, W2F - W1F, (int)threadIdx.x, BLOCK);
+        copy_image(W3T, IMAGE_UINT4 - W3T, (int)threadIdx.x, BLOCK);
+        w2_pending = true;
     } else {
         mlp3_build_image(lds4, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.n_out, (int)threadIdx.x, BLOCK);
     }
@@ -670,12 +686,14 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
                 split3x8(v8, bsp[t][jh][0], bsp[t][jh][1], bsp[t][jh][2]);
             }
         };
-        auto l2_chain = [&](int t, f32x16& acc2) {
+        auto l2_chain = [&](int t, f32x16& acc2, int ti0 = 0, int ti1 = NT) {   // input tiles [ti0, ti1) of output tile t
+            if (ti0 == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+                for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+            }
             const uint4* frag = W2f + (size_t)t * NT * 2 * 3 * 64 + lane;
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
+            for (int ti = ti0; ti < ti1; ++ti)
 #pragma unroll
                 for (int jh = 0; jh < 2; ++jh) {
                     const uint4* f = frag + (ti * 2 + jh) * 3 * 64;
@@ -693,6 +711,11 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
+        if (w2_pending && upper) {   // (wave-uniform) the upper half stages W2, then joins the lower half in front of ITS layer 2
+            copy_image(W2F, W3T - W2F, (int)threadIdx.x - BLOCK / 2, BLOCK / 2);
+            __syncthreads();
+            w2_pending = false;
+        }
         if constexpr (PIPE) {
             __builtin_amdgcn_sched_barrier(0);
             l1_chain(0);
@@ -704,11 +727,13 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
                 sgb_interleave<30, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (w2_pending) { __syncthreads(); w2_pending = false; }   // the lower half: W2 has been staged meanwhile
             f32x16 acc2[2];
-            l2_chain(0, acc2[0]);            // its first 36 MFMAs read bsp[0..2] only: beside tanh + split of layer-1 tile 3
+            l2_chain(0, acc2[0], 0, NT - 1); // its first 36 MFMAs read bsp[0..2] only: beside tanh + split of layer-1 tile 3
             l1_finish(NT - 1);
-            sgb_interleave<48, 4>();
+            sgb_interleave<36, 5>();
             __builtin_amdgcn_sched_barrier(0);
+            l2_chain(0, acc2[0], NT - 1, NT);
             if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);   // see below
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -726,6 +751,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) { l1_chain(t); l1_finish(t); }
+        if (w2_pending) { __syncthreads(); w2_pending = false; }
         MLP_STAMP(4 + 6 * stamp_tile);
         // the NEXT tile's window is requested here: its 40 registers are free again (the window lives on as xsp until layer 1
         // ends, the activations as bsp from here), and layer 2 + 3 give the loads ~10 k cycles to land
@@ -759,6 +785,10 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         }
         MLP_STAMP(7 + 6 * stamp_tile);
         ++stamp_tile;
+    }
+    if (w2_pending) {   // a wave without a tile still takes part in the staging and its barrier
+        if (upper) copy_image(W2F, W3T - W2F, (int)threadIdx.x - BLOCK / 2, BLOCK / 2);
+        __syncthreads();
     }
     MLP_STAMP(15);
 }
@@ -1268,8 +1298,9 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
         // layer 2 on the bf16 matrix cores with three-way split operands (see k_mlp): the default for the reference's
         // N = 128 policy at batch sizes beyond k_mlp_small's; QENV_MLP_BF16=0 keeps the all-fp32-MFMA kernel
         constexpr int NT = HP / 32, KS16 = (15 * TW + 15) / 16;
-        if (mlp_bf16_layer2() >= 3) {  // round 3's kernel (see k_mlp_v3)
-            const size_t lds = sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4;
+        if (mlp_bf16_layer2() >= 3 && (int64_t)15 * TW * a.N * 4 < ((int64_t)1 << 31)) {  // round 3's kernel (see k_mlp_v3; its window
+            // loads are raw buffer loads: one chunk of the window must stay below 2 GiB)
+            const size_t lds = sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4 + 80 * sizeof(uint32_t);
             hipError_t e = allow_dynamic_lds((const void*)k_mlp_v3<BLOCK, SAMPLE>, lds);
             if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_v3)");
             hipLaunchKernelGGL((k_mlp_v3<BLOCK, SAMPLE>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
