@@ -600,8 +600,22 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
     // weights as before.
     bool w2_pending = false;
     const bool upper = wave >= waves_per_block / 2;
+    // image[first .. first + count) -> LDS by nthr threads, eight 16-byte loads in flight per thread: one load per round trip
+    // (what a plain loop compiles to) made the 96 KiB of W2 a 20 k-cycle latency chain
     auto copy_image = [&](int first, int count, int tid, int nthr) {
-        for (int i = tid; i < count; i += nthr) lds4[first + i] = a.image[first + i];
+        for (int base = tid; base < count; base += 8 * nthr) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * nthr;
+                v[u] = a.image[first + (i < count ? i : count - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * nthr;
+                if (i < count) lds4[first + i] = v[u];
+            }
+        }
     };
     if (a.image) {
         copy_image(W1F, W2F - W1F, (int)threadIdx.x, BLOCK);
