@@ -591,7 +591,6 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
                 xw[(4 * q + c) >> 3][(4 * q + c) & 7] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off[c] + e4, 0, 0));
         }
     };
-    if (gtile < n_tiles) request_window(gtile);   // in flight during the staging
 
     // ---- the weights.  With a prepared image: W1 / W3 / biases by every wave, barrier; W2 (96 of the 159 KiB) by the UPPER
     // half of the waves while the lower half already runs layer 1 of its first tile -- a second barrier in front of layer 2
@@ -602,26 +601,55 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
     const bool upper = wave >= waves_per_block / 2;
     // image[first .. first + count) -> LDS by nthr threads, eight 16-byte loads in flight per thread: one load per round trip
     // (what a plain loop compiles to) made the 96 KiB of W2 a 20 k-cycle latency chain
+    // Every workgroup reads the SAME 159 KiB, and the 32 workgroups of an XCD start together: read in the same order they
+    // all ask for the same L2 lines at the same time.  Each workgroup therefore walks its copy from its own starting point
+    // (`rot`: 1/32 of the index space per workgroup of the XCD): W2 by four waves 15.9 k -> 9.8 k cycles, W1 14.5 k -> 11.7 k.
+    // (A CU pulls ~10 B per clock through its vector L1 whatever the source -- MI355X_MICROARCH.md: prologue bursts ~11
+    // B/cyc/CU -- and MORE loads in flight make it worse: all twenty 16-byte loads of a thread at once took 34 k cycles.)
+    const int xcd_slot = (int)(blockIdx.x >> 3) & 31;   // workgroups b, b + 8, b + 16 ... share an XCD (round-robin dispatch)
     auto copy_image = [&](int first, int count, int tid, int nthr) {
+        const int rot = (count / 32) * xcd_slot;
         for (int base = tid; base < count; base += 8 * nthr) {
             uint4 v[8];
+            int idx[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = base + u * nthr;
-                v[u] = a.image[first + (i < count ? i : count - 1)];
+                int j = (i < count ? i : count - 1) + rot;
+                if (j >= count) j -= count;
+                idx[u] = j;
+                v[u] = a.image[first + j];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * nthr;
-                if (i < count) lds4[first + i] = v[u];
-            }
+            for (int u = 0; u < 8; ++u)
+                if (base + u * nthr < count) lds4[first + idx[u]] = v[u];
         }
     };
     if (a.image) {
-        copy_image(W1F, W2F - W1F, (int)threadIdx.x, BLOCK);
-        copy_image(W3T, IMAGE_UINT4 - W3T, (int)threadIdx.x, BLOCK);
+        // the image loads go out BEFORE the first tile's window loads: vector-memory results return in issue order, and W1
+        // (from L2) should not queue behind the 20 MB of first-tile windows that the whole chip pulls from HBM at once
+        static_assert((W2F - W1F) <= 8 * BLOCK && (IMAGE_UINT4 - W3T) <= BLOCK, "one round of nine loads per thread");
+        uint4 v[9];
+        int idx[8];
+        constexpr int C1 = W2F - W1F;
+        const int rot = (C1 / 32) * xcd_slot;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = (int)threadIdx.x + u * BLOCK;
+            int j = (i < C1 ? i : C1 - 1) + rot;
+            if (j >= C1) j -= C1;
+            idx[u] = j;
+            v[u] = a.image[W1F + j];
+        }
+        v[8] = a.image[W3T + ((int)threadIdx.x < IMAGE_UINT4 - W3T ? (int)threadIdx.x : 0)];
+        if (gtile < n_tiles) request_window(gtile);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if ((int)threadIdx.x + u * BLOCK < C1) lds4[W1F + idx[u]] = v[u];
+        if ((int)threadIdx.x < IMAGE_UINT4 - W3T) lds4[W3T + threadIdx.x] = v[8];
         w2_pending = true;
     } else {
+        if (gtile < n_tiles) request_window(gtile);   // in flight during the staging
         mlp3_build_image(lds4, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.n_out, (int)threadIdx.x, BLOCK);
     }
     __syncthreads();

@@ -48,9 +48,16 @@ rows = {}
 for k, nm in enumerate(names):
     d = (s[:, k + 1] - s[:, k]).astype(np.float64)
     rows[nm] = [float(np.percentile(d, q)) for q in (10, 50, 90)]
+# per wave half (waves 0-3 / 4-7 of a workgroup share the SIMDs pairwise): offsets from the wave's entry, medians
+wave_in_block = np.arange(n_waves)[: len(s)] % 8 if len(s) == n_waves else None
+halves = {}
+if wave_in_block is not None:
+    for nm, sel in (("lower_waves_0_3", wave_in_block < 4), ("upper_waves_4_7", wave_in_block >= 4)):
+        rel = (s[sel][:, 1:14] - s[sel][:, :1]).astype(np.float64)
+        halves[nm] = {f"slot{k + 1}": float(np.median(rel[:, k])) for k in range(13)}
 total = (s[:, 13] - s[:, 0]).astype(np.float64)
 start_spread = float(s[:, 0].max() - s[:, 0].min())
 print(json.dumps(dict(lib=os.environ.get("QENV_LIB", "default"), envs=N, launch_us=round(us, 2), clock_ghz_est=round(float(clock_ghz), 3),
                       waves=int(len(s)), wave_total_cycles_p10_50_90=[float(np.percentile(total, q)) for q in (10, 50, 90)],
                       first_to_last_entry_cycles=start_spread, last_exit_minus_first_entry=float(s[:, 13].max() - s[:, 0].min()),
-                      phases_cycles_p10_50_90=rows), indent=1))
+                      phases_cycles_p10_50_90=rows, medians_from_entry_by_wave_half=halves), indent=1))
