@@ -580,8 +580,13 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         const int64_t chunk = a.n_chunks > 1 ? g / tiles_per_chunk : 0;
         const int64_t e = (g - chunk * tiles_per_chunk) * 32 + col;
         const uint32_t e4 = e < a.N ? (uint32_t)e * 4u : 0x80000000u;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.win + chunk * (int64_t)KW * a.N), 0,
-                                                                            (int)((uint32_t)KW * N32 * 4u), 0x00020000);
+        // the descriptor must be PROVABLY wave-uniform (the tile index comes from threadIdx.x >> 6): otherwise hipcc wraps every
+        // one of the 40 buffer loads in a waterfall loop (readfirstlane x 4, compare, saveexec, branch)
+        const uint64_t base = (uint64_t)(a.win + chunk * (int64_t)KW * a.N);
+        const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);          // (the builtin returns int:
+        const uint32_t base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));  //  no sign extension into bit 32+)
+        const uint64_t base_u = ((uint64_t)base_hi << 32) | (uint64_t)base_lo;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base_u, 0, (int)((uint32_t)KW * N32 * 4u), 0x00020000);
 #pragma unroll
         for (int q = 0; q < 10; ++q) {
             const uint4 r = rowq[q];
@@ -642,17 +647,20 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
             v[u] = a.image[W1F + j];
         }
         v[8] = a.image[W3T + ((int)threadIdx.x < IMAGE_UINT4 - W3T ? (int)threadIdx.x : 0)];
-        if (gtile < n_tiles) request_window(gtile);
+        if (gtile < n_tiles && !upper) request_window(gtile);   // the lower half's first windows: behind W1, ahead of W2
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if ((int)threadIdx.x + u * BLOCK < C1) lds4[W1F + idx[u]] = v[u];
         if ((int)threadIdx.x < IMAGE_UINT4 - W3T) lds4[W3T + threadIdx.x] = v[8];
-        w2_pending = true;
+        copy_image(W2F, W3T - W2F, (int)threadIdx.x, BLOCK);   // W2 by every wave, eight loads in flight per thread and round
     } else {
         if (gtile < n_tiles) request_window(gtile);   // in flight during the staging
         mlp3_build_image(lds4, a.W1, a.b1, a.W2, a.b2, a.W3, a.b3, a.n_out, (int)threadIdx.x, BLOCK);
     }
     __syncthreads();
+    // the upper half asks for its first window only now: two bursts instead of one, and the two waves of every SIMD start
+    // their first tile a few thousand cycles apart -- a stagger without an unpaired phase at either end
+    if (a.image && upper && gtile < n_tiles) request_window(gtile);
     MLP_STAMP(1);
     const uint4* W1f = lds4 + W1F;
     const uint4* W2f = lds4 + W2F;
