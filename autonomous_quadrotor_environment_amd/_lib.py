@@ -89,6 +89,7 @@ SYMBOLS = {
     "qenv_reset_sampled": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i]),
     "qenv_ppo_step": (_i, [_vp, _vp]),
     "qenv_ppo_flush": (_i, [_vp]),
+    "qenv_ppo_rollout": (_i, [_vp, _vp, _i]),
     "qenv_outer_velpid": (_i, [_vp, _vp, C.c_int32]),
     "qenv_outer_pospi": (_i, [_vp, _vp, C.c_double, C.c_double, C.c_double]),
     "qenv_outer_reset": (_i, [_vp, _vp]),

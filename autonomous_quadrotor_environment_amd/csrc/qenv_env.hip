@@ -351,6 +351,30 @@ int qenv_mix(qenv_t q, int64_t n, const void* action, void* out_w, void* out_fm,
     return QENV_DISPATCH(q, do_method, q, 1, n, in, out);
 }
 
+int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args* first, int n_steps) {
+    if (!q || !first) return fail(QENV_ERR_ARG, "qenv_ppo_rollout: null argument");
+    if (n_steps < 0) return fail(QENV_ERR_ARG, "qenv_ppo_rollout: negative n_steps");
+    const size_t esz = q->cfg.dtype == QENV_F64 ? 8 : 4;
+    const size_t N = (size_t)q->N;
+    auto adv = [&](const void* p, size_t bytes_per_step, int t) -> void* {
+        return p ? (void*)((char*)const_cast<void*>(p) + bytes_per_step * (size_t)t) : nullptr;
+    };
+    for (int t = 0; t < n_steps; ++t) {
+        qenv_ppo_step_args a = *first;
+        a.step = first->step + (uint64_t)t;
+        a.noise = adv(first->noise, 4 * N * esz, t);
+        a.out_action = adv(first->out_action, 4 * N * esz, t);
+        a.out_logprob = adv(first->out_logprob, 4 * N * esz, t);
+        a.obs_store = (float*)adv(first->obs_store, (size_t)15 * q->cfg.T * N * sizeof(float), t);
+        a.out_reward = adv(first->out_reward, N * esz, t);
+        a.out_mask = adv(first->out_mask, N * esz, t);
+        a.out_valid = adv(first->out_valid, N * esz, t);
+        const int rc = qenv_ppo_step(q, &a);
+        if (rc != QENV_OK) return rc;
+    }
+    return QENV_OK;
+}
+
 int qenv_rollout(qenv_t q, int controller, int n_steps, const double* const_action, int pid_first_action, int flags) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_rollout: null handle");
     if (controller < QENV_CTRL_CONST || controller > QENV_CTRL_PIDPOS) return fail(QENV_ERR_ARG, "qenv_rollout: bad controller");

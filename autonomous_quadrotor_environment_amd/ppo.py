@@ -592,6 +592,44 @@ class PolicyRollout:
         self.t += 1
         self.global_step += 1
 
+    def run(self, n_steps, noise=None):
+        """n_steps rollout steps from slot self.t on in ONE library call (qenv_ppo_rollout: the worker loop's `for t` in C):
+        the same buffers as n_steps step() calls, bit for bit, without a Python round trip between the launches.  The
+        sampling auto-reset rollout only (what step() runs as the fused call); noise: injected [n_steps, 4, N]."""
+        env, w, t0 = self.env, self.w, self.t
+        n_steps = int(n_steps)
+        if n_steps <= 0:
+            return
+        if t0 + n_steps > self.horizon:
+            raise ValueError(f"run({n_steps}) from slot {t0} exceeds the horizon {self.horizon}")
+        fused = (self.auto_reset and self.overlap and self.fused_act and not self.keep_init and not env.robust_control
+                 and (w.critic is None or self.batched_critic))
+        if not fused:
+            for k in range(n_steps):
+                self.step(noise=None if noise is None else noise[k])
+            return
+        nz = None
+        if noise is not None:
+            nz = noise.to(device=env.device, dtype=env.dtype).contiguous()
+            if tuple(nz.shape) != (n_steps, 4, env.n_envs):
+                raise ValueError(f"noise: expected [{n_steps}, 4, {env.n_envs}]")
+        key = (id(w), w.actor[0].data_ptr())
+        if getattr(env, "_ppo_checked", None) != key:
+            env._check_head(w.head("actor"), "actor", n_out=4)
+            env._ppo_checked = key
+        env._ensure_prepared(w, "actor")
+        W = w.head("actor")
+        a = L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[x.data_ptr() for x in W], float(w.std),
+                          None if nz is None else nz.data_ptr(), int(self.seed), int(self.global_step + 1), int(self.env_offset),
+                          self.mean.data_ptr(), self.actions[t0].data_ptr(), self.logprobs[t0].data_ptr(),
+                          None if self.obs is None else self.obs[t0].data_ptr(), self.rewards[t0].data_ptr(), self.done.data_ptr(),
+                          self.masks[t0].data_ptr(), None if self.valid is None else self.valid[t0].data_ptr(), int(self.inband),
+                          int(self.key_by_episode))
+        env._bind()
+        L.check(L.lib.qenv_ppo_rollout(env._h, C.byref(a), n_steps), "qenv_ppo_rollout")
+        self.t += n_steps
+        self.global_step += n_steps
+
     def critic_values(self, n=None):
         """values[:n] = critic(obs[:n]) in one launch over the stored observations (batched_critic)."""
         n = self.t if n is None else n
@@ -725,6 +763,15 @@ class StreamShardedRollout:
         for st, ro in zip(self.streams, self.ros):
             with torch.cuda.stream(st):
                 ro.step(deterministic=deterministic)
+
+    def run(self, n_steps):
+        """n_steps steps of every shard, one library call per shard (PolicyRollout.run) on the shard's stream: the host
+        enqueues a shard's whole horizon at once and the streams interleave on the device."""
+        if self.ros[0].t == 0:
+            self._join_consumer()
+        for st, ro in zip(self.streams, self.ros):
+            with torch.cuda.stream(st):
+                ro.run(n_steps)
 
     def finish(self, ddof=0, group=None, bootstrap=False, deterministic=False):
         """Per shard: pending warm-ups, critic over the horizon, GAE; then ONE normalisation over all shards (and ranks).

@@ -273,8 +273,7 @@ def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_globa
 
         def sharded_body():
             sro.t = 0
-            for _ in range(chunk):
-                sro.step()
+            sro.run(chunk)          # the whole horizon of every shard: one library call per shard (qenv_ppo_rollout)
             sro.finish(ddof=0, group=None)
             all_gather_returns(sro.last_returns(), n_global)
         return sharded_body, chunk, sro
@@ -282,8 +281,7 @@ def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_globa
 
     def body():  # one horizon: rollout, GAE (global normalisation), episode returns all-gathered over RCCL
         ro.t = 0
-        for _ in range(chunk):
-            ro.step()
+        ro.run(chunk)               # the whole horizon in one library call (qenv_ppo_rollout)
         ro.finish(ddof=0, group=None)
         all_gather_returns(env.last_return, n_global)
     return body, chunk, ro

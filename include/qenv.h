@@ -393,6 +393,14 @@ typedef struct {
 } qenv_ppo_step_args;
 int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args *args);
 int qenv_ppo_flush(qenv_t q);
+/* n_steps consecutive qenv_ppo_step calls issued from C: the `for t in range(max_timesteps)` of the worker loop
+ * (ppo.py:239-262) for a whole horizon in one call.  `first` describes step 0; step t uses the same struct with
+ * step + t, and with every per-step array advanced by t rows of the time-major rollout buffers: out_action /
+ * out_logprob [n_steps][4][N], obs_store [n_steps][15*T][N], out_reward / out_mask / out_valid [n_steps][N] (and noise
+ * [n_steps][4][N] when injected); out_mean and out_done are scratch and not advanced.  Identical to the n_steps separate
+ * calls bit for bit; what it removes is the host's per-step work between the launches (a step is two ~25 us kernels at
+ * 65 536 envs: a Python round trip per step leaves the GPU idle for about as long). */
+int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args *first, int n_steps);
 
 /* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------
  * The reference hard-codes `self.robust_control = False` (:183) and a user flips the attribute; this is that

@@ -189,3 +189,34 @@ def test_inband_learner_ignores_the_warm_up_rows(aq):
     assert float((g3 - g4).abs().max()) < 2e-6 * max(1.0, float(g4.abs().max()))
     assert abs(l3["actor"] - float(l4["actor"])) < 1e-6 and abs(l3["critic"] - float(l4["critic"])) < 1e-6
     assert nv < H * n
+
+
+@pytest.mark.parametrize("inband", [True, False])
+def test_ppo_rollout_call_equals_the_step_calls(aq, inband):
+    """qenv_ppo_rollout (the worker loop's `for t` issued from C, PolicyRollout.run) against the same number of
+    qenv_ppo_step calls (PolicyRollout.step): every rollout buffer, the env state, the banked returns and the episode
+    counters bit for bit, over two horizons (Philox policy noise), for both schedules."""
+    w, _ = _weights(aq)
+    n, H = 2000, 40
+    outs = []
+    for use_run in (False, True):
+        env = aq.BatchedQuad(n, 0.01, 13, training=True, direct_control=1, T=5, **LEAN)
+        ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=21, env_offset=500, inband=inband)
+        ro.start()
+        snap = []
+        for rep in range(2):
+            ro.t = 0
+            if use_run:
+                ro.run(17); ro.run(H - 17)
+            else:
+                for _ in range(H):
+                    ro.step()
+            ret, adv = ro.finish(ddof=0, group=False, deterministic=True)
+            snap.append([x.clone() for x in (ro.actions, ro.logprobs, ro.rewards, ro.masks, ro.obs, ro.values, ret, adv, env.state,
+                                             env.last_return, env.episodes, env.window, env.i)] +
+                        ([ro.valid.clone()] if inband else []))
+        outs.append(snap)
+    for rep in range(2):
+        for k, (x, y) in enumerate(zip(outs[0][rep], outs[1][rep])):
+            assert torch.equal(x, y), (rep, k)
+    assert int(outs[0][1][10].sum()) > n   # episodes did end and restart
