@@ -14,7 +14,7 @@ def child():
     for T in (5, 3, 8):
         w = aq.ActorCriticWeights.random(256, 15 * T, 4, device="cuda", seed=3)
         for N in (1, 100, 4096, 131072):
-            env = aq.BatchedQuad(N, 0.01, 500, training=True, direct_control=1, T=T)
+            env = aq.BatchedQuad(N, 0.01, 500, training=True, direct_control=1, T=T, dtype=torch.float32)
             env.reset(env.sample_init_states(0, 0, 0), return_history=False, push_window=True)
             for k in range(T + 1):
                 env.step(torch.rand(4, N, device="cuda") * 2 - 1, push_window=True)

@@ -15,7 +15,7 @@ N, H, U = 4096, 16, 3
 
 def run(lo, hi, group):
     w = aq.ActorCriticWeights.random(64, 75, 4, seed=5)
-    env = aq.BatchedQuad(hi - lo, 0.01, 60, training=True, direct_control=1, T=5)
+    env = aq.BatchedQuad(hi - lo, 0.01, 60, training=True, direct_control=1, T=5, dtype=torch.float32)
     ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=3, env_offset=lo)
     ln = aq.PpoLearner(w, K_epochs=2, group=group, deterministic=True)
     ro.start()

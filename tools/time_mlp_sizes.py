@@ -9,7 +9,7 @@ hidden = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 w = aq.ActorCriticWeights.random(hidden, 75, 4, device="cuda", seed=1)
 res = {}
 for N in (1, 32, 256, 1024, 4096, 8192, 16384, 32768, 65536, 131072):
-    env = aq.BatchedQuad(N, 0.01, 500, training=True, direct_control=1, T=5)
+    env = aq.BatchedQuad(N, 0.01, 500, training=True, direct_control=1, T=5, dtype=torch.float32)
     env.reset(env.sample_init_states(0, 0, 0), return_history=False, push_window=True)
     out = torch.empty(4, N, device="cuda")
     for _ in range(20):
