@@ -481,7 +481,7 @@ __device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, co
         const float* src = W1 + (size_t)(32 * t + (ln & 31)) * KW;
         float w8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w8[i] = (k0 + i) < KW ? src[k0 + i] : 0.f;
+        for (int i = 0; i < 8; ++i) w8[i] = (k0 + i) < KW ? src[k0 + i] * TANH_PRESCALE : 0.f;   // (see fast_tanh_prescaled)
         bf16x8 sp[3];
         split3x8(w8, sp[0], sp[1], sp[2]);
 #pragma unroll
@@ -491,7 +491,8 @@ __device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, co
         const int ln = c & 63, jh = (c >> 6) & 1, ti = (c >> 7) % NT, t = (c >> 7) / NT;
         const float* src = W2 + (size_t)(32 * t + (ln & 31)) * H + 32 * ti + 16 * jh + 4 * (ln >> 5);
         const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
-        const float w8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        const float w8[8] = {lo4.x * TANH_PRESCALE, lo4.y * TANH_PRESCALE, lo4.z * TANH_PRESCALE, lo4.w * TANH_PRESCALE,
+                             hi4.x * TANH_PRESCALE, hi4.y * TANH_PRESCALE, hi4.z * TANH_PRESCALE, hi4.w * TANH_PRESCALE};
         bf16x8 sp[3];
         split3x8(w8, sp[0], sp[1], sp[2]);
 #pragma unroll
@@ -504,8 +505,11 @@ __device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, co
         img[W3T + h] = __builtin_bit_cast(uint4, w);
     }
     for (int q4 = tid; q4 < H / 4; q4 += nthr) {
-        img[B1 + q4] = *reinterpret_cast<const uint4*>(b1 + 4 * q4);
-        img[B2 + q4] = *reinterpret_cast<const uint4*>(b2 + 4 * q4);
+        const float4 x1 = *reinterpret_cast<const float4*>(b1 + 4 * q4), x2 = *reinterpret_cast<const float4*>(b2 + 4 * q4);
+        const float4 s1 = {x1.x * TANH_PRESCALE, x1.y * TANH_PRESCALE, x1.z * TANH_PRESCALE, x1.w * TANH_PRESCALE};
+        const float4 s2 = {x2.x * TANH_PRESCALE, x2.y * TANH_PRESCALE, x2.z * TANH_PRESCALE, x2.w * TANH_PRESCALE};
+        img[B1 + q4] = __builtin_bit_cast(uint4, s1);
+        img[B2 + q4] = __builtin_bit_cast(uint4, s2);
     }
     if (tid == 0) {
         float4 b;
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         };
         auto l1_finish = [&](int t) {   // tanh, then the activations as bf16 terms (layer 2's B operand)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh(acc1[t][j]);
+            for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh_prescaled(acc1[t][j]);
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
                 float v8[8];
@@ -790,13 +794,13 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
             for (int t = 1; t < NT; ++t) {   // chain t beside tanh + layer 3 of t - 1
                 l2_chain(t, acc2[t & 1]);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc2[(t - 1) & 1][j] = fast_tanh(acc2[(t - 1) & 1][j]);
+                for (int j = 0; j < 16; ++j) acc2[(t - 1) & 1][j] = fast_tanh_prescaled(acc2[(t - 1) & 1][j]);
                 mlp3_layer3(W3t, t - 1, half, acc2[(t - 1) & 1], o);
                 sgb_interleave<48, 3>();
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc2[(NT - 1) & 1][j] = fast_tanh(acc2[(NT - 1) & 1][j]);
+            for (int j = 0; j < 16; ++j) acc2[(NT - 1) & 1][j] = fast_tanh_prescaled(acc2[(NT - 1) & 1][j]);
             mlp3_layer3(W3t, NT - 1, half, acc2[(NT - 1) & 1], o);
         } else {
 #pragma unroll
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
             f32x16 acc2;
             l2_chain(t, acc2);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh(acc2[j]);
+            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh_prescaled(acc2[j]);
             mlp3_layer3(W3t, t, half, acc2, o);
         }
         }
@@ -891,7 +895,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
             for (int i = 0; i < 8; ++i) {
                 const int k = 16 * sk + 8 * half + i;
                 const float v = w1[k < K1 ? k : K1 - 1];
-                w8[i] = (h_ok && k < K1) ? v : 0.f;
+                w8[i] = (h_ok && k < K1) ? (L3V ? v * TANH_PRESCALE : v) : 0.f;   // L3V: k_mlp_v3's pre-scaled hidden layers
             }
             split3x8(w8, a1sp[sk][0], a1sp[sk][1], a1sp[sk][2]);
         }
@@ -907,7 +911,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
     for (int i = 0; i < NT * 16; ++i) {
         const int k = 32 * (i >> 4) + acc_row(i & 15, half);
         const float v = w2[k < H ? k : 0];
-        a2[i] = (h_ok && k < H) ? v : 0.f;
+        a2[i] = (h_ok && k < H) ? (L3V ? v * TANH_PRESCALE : v) : 0.f;
     }
     if (t == 0 && !L3V) {
 #pragma unroll
@@ -935,8 +939,8 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int r = 32 * t + acc_row(j, half), r3 = acc_row(j, half);
-        bias1[j] = r < H ? a.b1[r] : 0.f;
-        bias2[j] = r < H ? a.b2[r] : 0.f;
+        bias1[j] = r < H ? (L3V ? a.b1[r] * TANH_PRESCALE : a.b1[r]) : 0.f;
+        bias2[j] = r < H ? (L3V ? a.b2[r] * TANH_PRESCALE : a.b2[r]) : 0.f;
         bias3[j] = r3 < a.n_out ? a.b3[r3] : 0.f;
     }
     const int64_t n_list = a.list_idx ? (int64_t)*a.list_count : 0;  // list mode: dense tiles gathered from a compacted list
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], xs[s], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) x1[(16 * t + j) * 64 + lane] = fast_tanh(acc[j]);
+        for (int j = 0; j < 16; ++j) x1[(16 * t + j) * 64 + lane] = L3V ? fast_tanh_prescaled(acc[j]) : fast_tanh(acc[j]);
         __syncthreads();
         // layer 2, output tile t, over all NT input tiles
 #pragma unroll
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
             for (int i = 0; i < NT * 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], x1[i * 64 + lane], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) x2[(16 * t + j) * 64 + lane] = fast_tanh(acc[j]);
+        for (int j = 0; j < 16; ++j) x2[(16 * t + j) * 64 + lane] = L3V ? fast_tanh_prescaled(acc[j]) : fast_tanh(acc[j]);
         __syncthreads();  // also: every wave is done with x1 before the next tile overwrites it
         if (t == 0) {     // layer 3 (n_out <= 4 rows in one zero-padded 32-row tile): one chain, k_mlp's order
             float o3[4];

@@ -618,6 +618,47 @@ def cpu_baseline(workload, integrator, seconds, policy="trained", steps=1000):
                                             "(BASELINE.md section 3); it cannot travel to the GPU box"}
 
 
+def next_rows(dev, policy):
+    """Dense tail of the landing policy at config 4's batch, and one learner epoch at config 5's horizon (a few hundred ms)."""
+    import autonomous_quadrotor_environment_amd as aq
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    K, H, n_out, N = 800, 64, 3, 131072
+    W = [r(H, K) / K ** 0.5, r(H) * 0.1, r(H, H) / H ** 0.5, r(H) * 0.1, r(n_out, H) / H ** 0.5, r(n_out) * 0.1]
+    x = torch.rand(K, N, device=dev, generator=g) * 2 - 1
+    y = torch.empty(n_out, N, device=dev)
+    us = kernel_launch_us(lambda: aq.dense_tail(x, W, final_tanh=True, out=y), 1, "fused", reps=4)
+    flops = 2.0 * N * (K * H + H * H + H * n_out)
+    out["dense_tail_800_64_64_3"] = {"samples": N, "kernel": "k_dense_tail<64>", "kernel_us": us, "samples_per_s": N / us * 1e6,
+                                     "bound": "mfma (fp32 32x32x2)", "algorithmic_TFLOPs": flops / us / 1e6,
+                                     "frac_of_fp32_mfma_peak": flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                                     "hbm_GBps": (K + n_out) * 4 * N / us / 1e3, "data": "synthetic U(-1,1) features"}
+    del x, y
+    n, S = 65536, 128
+    w = load_policy(policy, dev)
+    env = aq.BatchedQuad(n, 0.01, 500, training=True, direct_control=1, T=5, device=dev)
+    ro = aq.PolicyRollout(env, w, S, store_obs=True, auto_reset=True, seed=3, inband=True)
+    ro.start()
+    ro.run(S)
+    ret, adv = ro.finish(ddof=0, group=False)
+    learner = aq.PpoLearner(w, K_epochs=1, group=False)
+    learner.update(ro, ret, adv)      # buffers
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        learner.update(ro, ret, adv)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    samples = n * S
+    fl = samples * 2 * (75 * 128 + 128 * 128 + 128 * 4 + 75 * 128 + 128 * 128 + 128) * 3   # forward + 2x backward, both heads
+    out["ppo_update_epoch"] = {"samples": samples, "valid_samples": int(float(ro.valid[:S].sum())), "seconds": dt,
+                               "samples_per_s": samples / dt, "kernels": "k_mlp_bwd (fused loss), k_wgrad, k_adam; fp32 MFMA",
+                               "algorithmic_TFLOPs": fl / dt / 1e12, "frac_of_fp32_mfma_peak": fl / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "weights": policy_label(policy), "schedule": "inband"}
+    return out
+
+
 def slice_of(r, name, handle):
     """A `configs` entry from a measure() result."""
     rf = r["roofline"]
@@ -775,6 +816,11 @@ def main():
                 subs[key]["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample", "single_thread_rate",
                                                                "fp32_build")}
         out["configs"] = subs
+    # the two GEMM-shaped rows that are not a BASELINE config of their own: config 4's dense-tail shape
+    # (rl_nn_model.py 800 -> 64 -> 64 -> 3 on synthetic U(-1,1) features, 131 072 samples) and one PPO update epoch over a
+    # config-5 horizon (65 536 envs x 128 steps = 8.4 M samples: fused-loss backward, weight gradients, Adam, both heads)
+    if args.workload == "config2" and world == 1 and not args.no_subconfigs and args.envs == 0:
+        out["next_rows"] = next_rows(dev, args.policy)
     if world > 1:
         out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
         out["dist_backend"] = dist.get_backend()
