@@ -205,11 +205,26 @@ __device__ __forceinline__ void store_gust(S* ws, int32_t* wsi, int64_t N, int64
 #define QENV_MIN_WAVES 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
 #endif
 
-// quad.step for N envs: one launch, one lane per env.
-template <typename T, typename S, int INTEG, bool ROBUST, bool LEAN = false>
-__global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
-    using M = typename MathSel<T, LEAN>::type;
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- quad.step for N envs: one lane per env ---------------------------------------------------------------------------
+// The inputs of one env step (13 state rows, 4 action rows, the bookkeeping rows): what a lane requests from memory BEFORE
+// it integrates.  One wave per SIMD is resident (register footprint of the scipy-exact integrator), so this one round trip
+// -- ~2 us with every SIMD loading at once -- has nothing to hide behind: 28 % of a k_step wave's life (SQ counters, round
+// 2).  k_step<..., TILES = true> caps the grid at the resident waves and has a wave request tile t + 1's inputs before it
+// integrates tile t; the loop costs the allocator far more than the ~50 registers of the rows (334 -> 512 + AGPR spills),
+// which eats the hidden round trip until a wave owns eight tiles (do_step's launch rule has the measurements).
+template <typename T, typename S> struct StepIn {
+    S ys[13];
+    T raw[4];
+    Book<T> bk;
+    int64_t e;
+    bool active;
+};
+
+template <typename T, typename S>
+__device__ __forceinline__ void step_load(const StepArgs<T, S>& a, int64_t g, StepIn<T, S>& in) {
+    in.active = false;
+    in.e = 0;
+    int64_t e = g;
     if (e >= a.N) return;
     if (a.idx) {  // masked steps (reset warm-ups) run on the compacted list: only ceil(count/64) waves do any work
         if (e >= *a.count) return;
@@ -218,15 +233,30 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
     if (a.env_skip && a.env_skip[e]) return;
     const int64_t N = a.N;
     const Cfg<T>& cfg = a.cfg;
+    in.e = e;
+    in.active = true;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) in.ys[k] = ld(a.ws, ROW_STATE + k, N, e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        in.raw[k] = a.actions ? (T)a.actions[(int64_t)k * N + e] : ((cfg.direct || k == 0) ? cfg.zero_control0 : T(0));
+    if (a.mode != QENV_STEP_DYNAMICS_ONLY) load_book(a.ws, a.wsi, N, e, cfg.variant != 0, in.bk);
+}
+
+template <typename T, typename S, int INTEG, bool ROBUST, bool LEAN>
+__device__ __forceinline__ void step_one(const StepArgs<T, S>& a, const StepIn<T, S>& in) {
+    using M = typename MathSel<T, LEAN>::type;
+    const int64_t e = in.e;
+    const int64_t N = a.N;
+    const Cfg<T>& cfg = a.cfg;
     constexpr bool MIXED = !std::is_same<T, S>::value;
     T y[13];
     S ys[13];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) { ys[k] = ld(a.ws, ROW_STATE + k, N, e); y[k] = (T)ys[k]; }
+    for (int k = 0; k < 13; ++k) { ys[k] = in.ys[k]; y[k] = (T)ys[k]; }
     T raw[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        raw[k] = a.actions ? (T)a.actions[(int64_t)k * N + e] : ((cfg.direct || k == 0) ? cfg.zero_control0 : T(0));
+    for (int k = 0; k < 4; ++k) raw[k] = in.raw[k];
     T w[4], effort[4], cl[4], act[4], kq[13], dy[13];
     const T q_old[4] = {y[6], y[7], y[8], y[9]};
     Act<T> u;
@@ -236,12 +266,7 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
         load_plant<T>(a.ws, a.wsi, N, e, a.gust, pl);
         begin_step_wind(pl, a.wsi[IROW_I * N + e] + 1);  // self.i += 1 comes first in step (:467)
     }
-    // the bookkeeping rows are requested BEFORE the integration: one wave per SIMD is resident (register footprint), so a
-    // load issued after the RK45 is a full memory round trip with nothing to hide behind.  (Measured A/B on config 4: neutral,
-    // 32.2 vs 31.5 us per launch -- the compiler had them in the first phase already; the 28 % of a wave's cycles that the
-    // SQ counters show as waits are that one phase's round trip, ~2 us with every SIMD loading at once.)
-    Book<T> bk;
-    if (a.mode != QENV_STEP_DYNAMICS_ONLY) load_book(a.ws, a.wsi, N, e, cfg.variant != 0, bk);
+    Book<T> bk = in.bk;   // (requested with the state rows, ahead of the integration)
     bool warming = false;
     if (a.ar_on == 2 && a.mode != QENV_STEP_DYNAMICS_ONLY) {  // in-band warm-up: steps 1..T after a reset apply zero_control (:448-451)
         warming = bk.i < cfg.warmup;
@@ -390,6 +415,32 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
                 a.ar_idx[base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)e;
                 reset_env_sampled<S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, true, a.ar_key_episode != 0);
             }
+        }
+    }
+}
+
+// TILES = false: one 64-env tile per wave, the grid covers the batch (every integrator below the chip's resident-wave count,
+// and the fixed-step integrators always: they keep 2+ waves per SIMD and the tile loop's registers would cost one).
+template <typename T, typename S, int INTEG, bool ROBUST, bool LEAN = false, bool TILES = false>
+__global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArgs<T, S> a) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    StepIn<T, S> cur;
+    step_load(a, g, cur);
+    if constexpr (!TILES) {
+        if (cur.active) step_one<T, S, INTEG, ROBUST, LEAN>(a, cur);
+    } else {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+        for (;;) {
+            const int64_t gn = g + stride;
+            const bool more = gn - (int64_t)(threadIdx.x & 63) < a.N;   // wave-uniform: the wave's next tile starts inside the batch
+            StepIn<T, S> nxt;
+            nxt.active = false;
+            if (more) step_load(a, gn, nxt);   // in flight during this tile's integration
+            if (cur.active) step_one<T, S, INTEG, ROBUST, LEAN>(a, cur);
+            if (!more) break;
+            cur = nxt;
+            g = gn;
         }
     }
 }
@@ -1005,6 +1056,32 @@ static inline int env_block() {
     return b;
 }
 static inline dim3 env_grid(int64_t N) { return dim3((unsigned)((N + env_block() - 1) / env_block())); }
+// k_step's grid: no more workgroups than the chip holds at once (for the scipy-exact integrator one wave per SIMD: 1 024
+// waves = 65 536 lanes); beyond that a wave walks several tiles and requests the next one's rows while it integrates the
+// current one (step_load / step_one).  QENV_STEP_GRID_LANES overrides the resident-lane count (A/B runs).
+template <typename F> static inline dim3 step_grid(F fn, int64_t N) {
+    struct Slot { const void* fn; int dev; int64_t lanes; };
+    static thread_local Slot cache[32] = {};
+    static thread_local int n = 0;
+    const int block = env_block();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    int64_t cap = 0;
+    for (int i = 0; i < n && !cap; ++i)
+        if (cache[i].fn == (const void*)fn && cache[i].dev == dev) cap = cache[i].lanes;
+    if (!cap) {
+        if (const char* s = getenv("QENV_STEP_GRID_LANES")) cap = atoll(s);
+        if (cap <= 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (dev < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            cap = (int64_t)per_cu * block * cus;
+        }
+        if (dev >= 0 && n < 32) cache[n++] = Slot{(const void*)fn, dev, cap};
+    }
+    const int64_t lanes = N < cap ? N : cap;
+    return dim3((unsigned)((lanes + block - 1) / block));
+}
 
 // extras of the overlapped PPO step (see StepArgs)
 struct StepExtra {
@@ -1078,7 +1155,23 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
         }
     }
     switch (q->cfg.integrator) {
-        case QENV_RK45: hipLaunchKernelGGL((k_step<T, S, INT_RK45, false, LEAN>), g, b, 0, q->stream, a); break;
+        case QENV_RK45: {
+            // the tile loop (a wave requests tile t + 1's rows before it integrates tile t) costs ~180 more registers than the
+            // ~50 the rows need (A/B, tests/tools/time_step_one.py: 131 072 envs 39.8 vs 38.7 us without, 262 144 65.7 vs 65.5,
+            // 524 288 121.7..125.7 vs 128.5; fp32 rows 33.1 vs 26.8: the smaller kernel keeps 2 waves per SIMD): from eight
+            // tiles per wave on fp64 rows (+2..5 %), never on fp32 rows.  QENV_STEP_TILES=0/1 overrides (A/B).
+            bool tiles = false;
+            if constexpr (sizeof(S) == 8) {
+                auto fn = k_step<T, S, INT_RK45, false, LEAN, true>;
+                static const int force = getenv("QENV_STEP_TILES") ? atoi(getenv("QENV_STEP_TILES")) : -1;
+                const dim3 gt = step_grid(fn, q->N);
+                const int64_t resident = (int64_t)gt.x * b.x;
+                tiles = force < 0 ? q->N >= 8 * resident : (force > 0 && q->N > resident);
+                if (tiles) hipLaunchKernelGGL(fn, gt, b, 0, q->stream, a);
+            }
+            if (!tiles) hipLaunchKernelGGL((k_step<T, S, INT_RK45, false, LEAN>), g, b, 0, q->stream, a);
+            break;
+        }
         case QENV_DP5: hipLaunchKernelGGL((k_step<T, S, INT_DP5, false, LEAN>), g, b, 0, q->stream, a); break;
         default: hipLaunchKernelGGL((k_step<T, S, INT_RK4, false, LEAN>), g, b, 0, q->stream, a); break;
     }

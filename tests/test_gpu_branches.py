@@ -219,3 +219,30 @@ def test_step_branch_census(aq, oracle, dt, variant, training):
     # faces: v(0,1,2), roll 3, yaw 5, w(6,7,8); pitch (4) cannot reach pi/2 through asin, the opt box's yaw limit is > pi
     assert ({0, 1, 2, 3, 6, 7, 8} | ({5} if bb_v[5] < np.pi else set())) <= faces, faces
     assert np.array_equal(bb_v, env.bb_cond)
+
+
+def test_step_tile_loop_equals_one_tile_per_wave(aq):
+    """k_step<..., TILES> (from eight 64-env tiles per resident wave: a wave requests tile t + 1's rows before it integrates
+    tile t) against the one-tile-per-wave kernel that smaller batches run: an env's step does not depend on its batch,
+    so eight 65 536-env handles fed the eighths of a 524 288-env handle's states and actions must return its rows, bit
+    for bit, through episode ends (full step + window push, scipy-exact RK45, fp64 rows)."""
+    n, parts = 524288, 8
+    big = aq.BatchedQuad(n, 0.01, 6, training=True, direct_control=1, T=5)
+    init = big.sample_init_states(11, 0, 0)
+    big.reset(init, return_history=False, push_window=True)
+    q = n // parts
+    small = [aq.BatchedQuad(q, 0.01, 6, training=True, direct_control=1, T=5) for _ in range(parts)]
+    for k, s in enumerate(small):
+        s.reset(init[:, k * q:(k + 1) * q].contiguous(), return_history=False, push_window=True)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(8):   # n = 6: every env's episode ends inside the run (flags and the frozen rows after done included)
+        act = (torch.rand(4, n, device="cuda", dtype=big.dtype, generator=g) * 2 - 1) * 0.5
+        obs, rew, done = big.step(act, push_window=True)
+        for k, s in enumerate(small):
+            o, r, d = s.step(act[:, k * q:(k + 1) * q].contiguous(), push_window=True)
+            sl = slice(k * q, (k + 1) * q)
+            assert torch.equal(o, obs[:, sl]) and torch.equal(r, rew[sl]) and torch.equal(d, done[sl]), (t, k)
+    for k, s in enumerate(small):
+        sl = slice(k * q, (k + 1) * q)
+        assert torch.equal(s.state, big.state[:, sl])
+        assert torch.equal(s.window, big.window[..., sl])   # the observation ring, [.., N]
