@@ -962,10 +962,17 @@ template <typename T, typename M = Mth<T>>
 __device__ __forceinline__ void lqr_law(const T y[13], const Book<T>& bk, const LqrGains<T>& g, T act[4]) {
     using m = M;
     const T F0 = g.kt[0] * y[1], F1 = g.kt[1] * y[3], F2 = g.kt[2] * y[5];
-    const T theta_t = m::atan2(F0, F2 + T(phys::G));
-    const T ct = m::cos(theta_t);
-    const T phi_t = m::atan2(-F1 * ct, F2 + T(phys::G));
-    act[0] = m::div(T(phys::M) * (F2 + T(phys::G)), ct * m::cos(phi_t));
+    // cos(atan2(a, b)) = b / hypot(a, b) (every sign of a and b; atan2(0, 0) = 0): the two cosines of lqr_quad.py:139-141
+    // without their range reductions -- a rounding-level difference from evaluating the cosine of the rounded angle
+    const T Fz = F2 + T(phys::G);
+    const T theta_t = m::atan2(F0, Fz);
+    const T r2t = F0 * F0 + Fz * Fz;
+    const T ct = r2t > T(0) ? Fz * m::rsqrt(r2t) : T(1);
+    const T Fy = -F1 * ct;
+    const T phi_t = m::atan2(Fy, Fz);
+    const T r2p = Fy * Fy + Fz * Fz;
+    const T cp = r2p > T(0) ? Fz * m::rsqrt(r2p) : T(1);
+    act[0] = m::div(T(phys::M) * Fz, ct * cp);
     act[1] = g.ka[0][0] * (bk.ang[0] - phi_t) + g.ka[0][1] * bk.ang_vel[0];
     act[2] = g.ka[1][0] * (bk.ang[1] - theta_t) + g.ka[1][1] * bk.ang_vel[1];
     act[3] = g.ka[2][0] * bk.ang[2] + g.ka[2][1] * bk.ang_vel[2];
