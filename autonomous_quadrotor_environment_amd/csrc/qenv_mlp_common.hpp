@@ -45,4 +45,43 @@ __device__ __forceinline__ float fast_tanh_prescaled(float zs) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// ---- shared by k_mlp_v3 / k_mlp_small (qenv_ppo.hip) and k_mlp_bwd_v3 (qenv_train.hip): the N = 128, T = 5 policy on the bf16
+// matrix cores with three-way split operands
+namespace mlp3 {
+constexpr int H = 128, NT = 4, TW = 5, KW = 75, KS16 = 5;
+constexpr int W1F = 0;                               // uint4 offsets into the image
+constexpr int W2F = W1F + NT * KS16 * 3 * 64;        // 3840
+constexpr int W3T = W2F + NT * NT * 2 * 3 * 64;      // 9984: [128] float4 = W3[0..3][h], rows >= n_out zero
+constexpr int B1 = W3T + H;                          // 10112: 128 floats
+constexpr int B2 = B1 + H / 4;                       // 10144
+constexpr int B3 = B2 + H / 4;                       // 10176: 4 floats, zero beyond n_out
+constexpr int IMAGE_UINT4 = B3 + 1;                  // 10177 -> 162 832 B
+}  // namespace mlp3
+
+// layer 3 on the vector lanes: o[k] += W3[k][row] * h2[row] over the 16 rows register j of this lane half holds in output
+// tile t of layer 2, in register order.  One definition for k_mlp_v3 and k_mlp_small (bit-identical outputs).
+__device__ __forceinline__ void mlp3_layer3(const float4* W3t, int t, int half, const f32x16& h2, float o[4]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 w = W3t[32 * t + acc_row(j, half)];
+        o[0] = fmaf(w.x, h2[j], o[0]); o[1] = fmaf(w.y, h2[j], o[1]);
+        o[2] = fmaf(w.z, h2[j], o[2]); o[3] = fmaf(w.w, h2[j], o[3]);
+    }
+}
+// the two lane halves' partial sums meet: the result is valid in the lower half (which started from the bias)
+__device__ __forceinline__ void mlp3_layer3_finish(float o[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = o[k] + __shfl_xor(o[k], 32);
+}
+
+// N_MFMA times { one MFMA, then N_VALU VALU instructions }: the interleave a scheduling region is asked for (the region's
+// other instructions -- LDS reads, waits -- go where the scheduler likes)
+template <int N_MFMA, int N_VALU> __device__ __forceinline__ void sgb_interleave() {
+#pragma unroll
+    for (int m = 0; m < N_MFMA; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, N_VALU, 0);
+    }
+}
+
 }  // namespace qenv

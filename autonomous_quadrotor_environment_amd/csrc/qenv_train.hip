@@ -273,6 +273,385 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd(const BwdArgs a) {
     }
 }
 
+// ---- k_mlp_bwd_v3: the same pass for the reference's N = 128, T = 5 networks on the bf16 matrix cores -----------------------
+// Three-way split operands as in k_mlp_v3 (qenv_ppo.hip): six v_mfma_f32_32x32x16_bf16 of 32 pipe cycles per 16 k instead of
+// eight v_mfma_f32_32x32x2_f32 of 64 (which also occupy the vector lanes), fp32-accurate.  504 MFMAs per 32-sample tile
+// (layer 1: 120, layer 2: 192, W2^T dZ2: 192) instead of 736; layer 3 and W3^T dz3 (4 real rows / columns) run on the vector
+// lanes.  The forward half is k_mlp_v3's arithmetic instruction for instruction (pre-scaled hidden layers, same product
+// order): the probability ratio of the first epoch after a rollout is exactly 1.
+// W2 is needed twice: as the A operand of layer 2 (row o, eight k = input indices per lane) and of W2^T dZ2 (column i,
+// eight k = output indices per lane).  Two fragment images would be 192 KiB; ONE image of 128 x 128 16-bit elements per
+// bf16 term (256 bytes per row and term, 96 KiB) serves both: a row is stored with bits 2 and 3 of the column index swapped, so the
+// eight elements a forward fragment needs (the k order of an accumulator tile used as the B operand: 16 s + 8 (j >> 2) +
+// 4 half + (j & 3)) are one 16-byte chunk -- one ds_read_b128 -- and the transposed fragment comes from two
+// ds_read_b64_tr_b16 (gfx950's transposing LDS read: 4 rows x 16 columns per 16-lane group, delivered column-major); the
+// 16-byte chunks of a row are XOR-swizzled by the row index so that both kinds of read are bank-conflict free
+// (cdna_hip_programming.md T10 image (b); tools/ubench/dual_image.hip checks the two address maps with exact integer data).
+// Registers (two waves per SIMD, 256): the fp32 copy of H1 is not kept across layer 2 and the backward half -- it is stored
+// (it has to be, for the weight gradients) and its 16 values per output tile are read back (L2 hits) beside the chain
+// that needs them.
+namespace bwd3 {
+constexpr int W2D = mlp3::W2F * 16;                  // byte offset of the dual-use W2 image: [128 rows][3 terms][256 B]
+constexpr int W2D_ROW = 768, W2D_TERM = 256;         // (a row stride of 3 x 64 banks: the bank pattern of 256-byte rows)
+constexpr int LDS_BYTES = mlp3::IMAGE_UINT4 * 16;    // the layout around it is k_mlp_v3's (W1 fragments | W2 | W3T | b1 | b2 | b3)
+__device__ __forceinline__ int img_off(int row, int ch) { return W2D_ROW * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ int sigma(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }   // bits 2 and 3 swapped
+typedef short v4s __attribute__((ext_vector_type(4)));
+}  // namespace bwd3
+
+// sgb_interleave with LDS reads in the pattern: left to itself the scheduler lifts every ds_read of a region to its top (the 16
+// float4 rows of W3 for layer 3 alone are 64 registers) and spills what it read
+template <int N_MFMA, int N_VALU, int N_DS> __device__ __forceinline__ void sgb_interleave_ds() {
+#pragma unroll
+    for (int m = 0; m < N_MFMA; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, N_DS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, N_VALU, 0);
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
+    using namespace mlp3;
+    using namespace bwd3;
+    constexpr int WPB = BLOCK / 64, K1 = KW;
+    constexpr bool ONE_WAVE = BLOCK == 256;   // one wave per SIMD, 512 registers: H1 stays in registers, the next tile's observations
+                                              // are requested a whole tile ahead
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    char* ldsb = reinterpret_cast<char*>(lds4);
+    // ---- the weights, once per launch and workgroup, from the torch layout
+    for (int c = threadIdx.x; c < NT * KS16 * 64; c += BLOCK) {   // W1 fragments (k_mlp_v3's layout)
+        const int ln = c & 63, sk = (c >> 6) % KS16, t = (c >> 6) / KS16;
+        const int k0 = 16 * sk + 8 * (ln >> 5);
+        const float* src = a.W1 + (size_t)(32 * t + (ln & 31)) * K1;
+        float w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w8[i] = (k0 + i) < K1 ? src[k0 + i] * TANH_PRESCALE : 0.f;
+        bf16x8 sp[3];
+        split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lds4[W1F + ((t * KS16 + sk) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+    }
+    for (int idx = threadIdx.x; idx < H * 16; idx += BLOCK) {     // W2: chunk ch of row o = storage columns 8 ch .. 8 ch + 7
+        const int o = idx >> 4, ch = idx & 15;
+        float w8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w8[e] = a.W2[(size_t)o * H + sigma(8 * ch + e)] * TANH_PRESCALE;
+        bf16x8 sp[3];
+        split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4*>(ldsb + W2D + k * W2D_TERM + img_off(o, ch)) = __builtin_bit_cast(uint4, sp[k]);   // (img_off: 768-byte rows)
+    }
+    for (int h = threadIdx.x; h < H; h += BLOCK) {
+        float4 w;
+        w.x = a.W3[h]; w.y = a.n_out > 1 ? a.W3[(size_t)H + h] : 0.f; w.z = a.n_out > 2 ? a.W3[(size_t)2 * H + h] : 0.f;
+        w.w = a.n_out > 3 ? a.W3[(size_t)3 * H + h] : 0.f;
+        lds4[W3T + h] = __builtin_bit_cast(uint4, w);
+        reinterpret_cast<float*>(lds4 + B1)[h] = a.b1[h] * TANH_PRESCALE;
+        reinterpret_cast<float*>(lds4 + B2)[h] = a.b2[h] * TANH_PRESCALE;
+    }
+    if (threadIdx.x < 4) reinterpret_cast<float*>(lds4 + B3)[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    __syncthreads();
+    const uint4* W1f = lds4 + W1F;
+    const float* b3s = reinterpret_cast<const float*>(lds4 + B3);
+
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles_per_chunk = (a.N + 31) / 32, n_tiles = tiles_per_chunk * a.n_chunks;
+    const int64_t tile_stride = (int64_t)gridDim.x * WPB;
+    const uint32_t N32 = (uint32_t)a.N;
+    double loss_acc = 0.0, std_acc = 0.0;
+    // ---- the observations of a tile: element (sk, i) of a lane = row 16 sk + 8 half + i, as raw buffer loads -- the lane's
+    // offset carries the sample and the half's 8 rows, the row offset 16 sk + i is scalar, rows >= 75 fall out of the range check
+    float xw[KS16][8];
+    auto request_x = [&](int64_t tile) {
+        const int64_t c = __builtin_amdgcn_readfirstlane((int)(tile / tiles_per_chunk));
+        const int64_t e = (tile % tiles_per_chunk) * 32 + col;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.obs + (size_t)c * K1 * a.N), 0,
+                                                                            (int)((uint32_t)K1 * N32 * 4u), 0x00020000);
+        const uint32_t voff = e < a.N ? ((uint32_t)e + 8u * (uint32_t)half * N32) * 4u : 0x80000000u;
+#pragma unroll
+        for (int sk = 0; sk < KS16; ++sk)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xw[sk][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)(16 * sk + i) * N32 * 4u, 0));
+    };
+    int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    if (tile < n_tiles) request_x(tile);
+    // The lane parts of the W2 read addresses.  The XOR swizzle mixes lane bits with the chunk number, so an address is not
+    // base + literal: the forward read of chunk 2 n + half of row 32 t + col is fw_a + 16 ((2 n) ^ fw_x) + 768 * 32 t, the
+    // transposed read of rows 32 to + 16 s + 8 jg + 4 half + q, columns of output tile t, is tr_a + 64 (t ^ q) + 32 (g ^ jg)
+    // + 768 (32 to + 16 s + 8 jg): one or two vector instructions per 16-k step of six MFMAs, formed where they are used.
+    // (Kept as per-(t, n) registers they cost 16; as loop invariants every base + literal sum is hoisted out of the tile loop
+    // -- hundreds -- and spilled: the five values are made opaque at the top of every tile.)
+    const int tr_q0 = (lane & 15) >> 2, tr_p = lane & 3, tr_g0 = (lane >> 4) & 1;
+    int fw_a = W2D + W2D_ROW * col, fw_x = half ^ (((col & 3) << 2) | ((col >> 2) & 3));
+    int tr_a = W2D + W2D_ROW * (4 * half + tr_q0) + 8 * (tr_p >> 1) + 16 * ((tr_p & 1) ^ half), tr_q = tr_q0, tr_g = tr_g0;
+    for (; tile < n_tiles; tile += tile_stride) {
+        asm volatile("" ::: "memory");  // keep the (tile-invariant) LDS reads inside the loop (see k_mlp)
+        asm volatile("" : "+v"(fw_a), "+v"(fw_x), "+v"(tr_a), "+v"(tr_q), "+v"(tr_g));
+        // the same for the reads indexed by an accumulator row (32 t + acc_row(j, half) = a literal + 4 half): W3's rows, biases
+        int w3_base = W3T * 16 + 64 * half, b1_base = B1 * 16 + 16 * half, b2_base = B2 * 16 + 16 * half;
+        asm volatile("" : "+v"(w3_base), "+v"(b1_base), "+v"(b2_base));
+        auto w3_row = [&](int t, int j) { return *reinterpret_cast<const float4*>(ldsb + (w3_base + 16 * (32 * t + acc_row(j, 0)))); };
+        const int64_t c = __builtin_amdgcn_readfirstlane((int)(tile / tiles_per_chunk));
+        const int64_t e = (tile % tiles_per_chunk) * 32 + col;
+        const bool valid = e < a.N;
+        const uint32_t ec = (uint32_t)(valid ? e : a.N - 1);
+        const uint32_t voff = valid ? (ec + 4u * (uint32_t)half * N32) * 4u : 0x80000000u;  // rows r and r + 4 share a register
+        const __amdgpu_buffer_rsrc_t h1c = rows_rsrc(a.h1 + (size_t)c * H * a.N, H, N32);
+        const __amdgpu_buffer_rsrc_t h2c = rows_rsrc(a.h2 + (size_t)c * H * a.N, H, N32);
+        const __amdgpu_buffer_rsrc_t dz2c = rows_rsrc(a.dz2 + (size_t)c * H * a.N, H, N32);
+        const __amdgpu_buffer_rsrc_t dz1c = rows_rsrc(a.dz1 + (size_t)c * H * a.N, H, N32);
+        auto row_soff = [&](int t, int j) { return (uint32_t)(32 * t + 8 * (j >> 2) + (j & 3)) * N32 * 4u; };
+        bf16x8 xsp[KS16][3];
+#pragma unroll
+        for (int sk = 0; sk < KS16; ++sk) split3x8(xw[sk], xsp[sk][0], xsp[sk][1], xsp[sk][2]);
+        if (ONE_WAVE && tile + tile_stride < n_tiles) request_x(tile + tile_stride);
+        // ---- forward, layers 1 and 2 as k_mlp_v3's software pipeline (a chain beside the vector work of the previous tile)
+        f32x16 acc1[NT];
+        bf16x8 bsp[NT][2][3];   // H1, then dZ2, as bf16 terms: the B operand of layer 2, then of W2^T dZ2
+        auto l1_chain = [&](int t) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = *reinterpret_cast<const float*>(ldsb + (b1_base + 4 * (32 * t + acc_row(j, 0))));
+            const uint4* frag = W1f + (size_t)t * KS16 * 3 * 64 + lane;
+#pragma unroll
+            for (int sk = 0; sk < KS16; ++sk) {
+                const uint4* f = frag + sk * 3 * 64;
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                             al = __builtin_bit_cast(bf16x8, f[128]);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][1], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xsp[sk][0], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][2], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][0], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][1], acc1[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][0], acc1[t], 0, 0, 0);
+            }
+        };
+        auto l1_finish = [&](int t) {   // tanh, H1 out, and its bf16 terms
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                acc1[t][j] = fast_tanh_prescaled(acc1[t][j]);
+                bstore(h1c, voff, row_soff(t, j), acc1[t][j]);
+            }
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = acc1[t][8 * jh + i];
+                split3x8(v8, bsp[t][jh][0], bsp[t][jh][1], bsp[t][jh][2]);
+            }
+        };
+        // the six products of one 16-k step, smallest first (k_mlp_v3's order)
+        auto six = [&](f32x16& acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        };
+        auto l2_chain = [&](int t, f32x16& acc2, int ti0 = 0, int ti1 = NT) {   // input tiles [ti0, ti1) of output tile t
+            if (ti0 == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc2[j] = *reinterpret_cast<const float*>(ldsb + (b2_base + 4 * (32 * t + acc_row(j, 0))));
+            }
+#pragma unroll
+            for (int ti = ti0; ti < ti1; ++ti)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    // row 32 t + col, chunk 2 (2 ti + s) + half: the lane part comes from fw_base, the rest is one literal
+                    const char* f = ldsb + (fw_a + 16 * ((2 * (2 * ti + s)) ^ fw_x) + W2D_ROW * 32 * t);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f)),
+                                 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f + W2D_TERM)),
+                                 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f + 2 * W2D_TERM));
+                    six(acc2, ah, am, al, bsp[ti][s][0], bsp[ti][s][1], bsp[ti][s][2]);
+                }
+        };
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
+        auto layer3 = [&](int t, const f32x16& hv) {   // mlp3_layer3 with the opaque row base
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float4 w = w3_row(t, j);
+                o[0] = fmaf(w.x, hv[j], o[0]); o[1] = fmaf(w.y, hv[j], o[1]);
+                o[2] = fmaf(w.z, hv[j], o[2]); o[3] = fmaf(w.w, hv[j], o[3]);
+            }
+        };
+        f32x16 h2[NT];
+        __builtin_amdgcn_sched_barrier(0);
+        l1_chain(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 1; t < NT; ++t) {
+            l1_chain(t);
+            l1_finish(t - 1);
+            sgb_interleave_ds<30, 6, 1>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        l2_chain(0, h2[0], 0, NT - 1);
+        l1_finish(NT - 1);
+        sgb_interleave_ds<36, 5, 1>();
+        __builtin_amdgcn_sched_barrier(0);
+        l2_chain(0, h2[0], NT - 1, NT);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 1; t < NT; ++t) {   // chain t beside tanh + layer 3 of t - 1
+            l2_chain(t, h2[t]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) h2[t - 1][j] = fast_tanh_prescaled(h2[t - 1][j]);
+            layer3(t - 1, h2[t - 1]);
+            sgb_interleave_ds<48, 3, 1>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h2[NT - 1][j] = fast_tanh_prescaled(h2[NT - 1][j]);
+        layer3(NT - 1, h2[NT - 1]);
+        // the next tile's observations are requested HERE: vector-memory operations retire in issue order, so a load waits for
+        // every store issued before it -- behind the 256 row stores of the backward half it cost 3 ms of a 9.5 ms launch
+        // (ablation builds, tools/ab_bwd.sh); here only H1's 64 stores, issued a layer ago, are ahead of it.  Its 40 registers
+        // fit because the backward product below walks the k-steps outermost (dZ2 stays fp32 and is split one step at a time).
+        if (!ONE_WAVE && tile + tile_stride < n_tiles) request_x(tile + tile_stride);
+        // ---- output and its pre-activation gradient, in both lane halves
+        const __amdgpu_buffer_rsrc_t r_dz3 = rows_rsrc(a.dz3 + (size_t)c * 4 * a.N, 4, N32);
+        float dz3[4], outv[4], sd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = o[k] + __shfl_xor(o[k], 32);
+            if (a.final_tanh) v = tanhf(v);
+            outv[k] = v;
+            sd[k] = 0.f;
+        }
+        if (a.loss_mode == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < a.n_out) sd[k] = (a.seed + (size_t)c * a.n_out * a.N)[(uint32_t)k * N32 + ec];
+        } else if (a.loss_mode == 1) {  // k_ppo_loss, actor part, same operation order (see k_mlp_bwd)
+            const float* ac = a.actions + (size_t)c * 4 * a.N;
+            const float* lo = a.old_logprob + (size_t)c * 4 * a.N;
+            float lp = 0.f, lp_old = 0.f, d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = ac[(uint32_t)k * N32 + ec] - outv[k];
+                lp += -0.5f * d[k] * d[k] * a.inv_var + a.log_norm;
+                lp_old += lo[(uint32_t)k * N32 + ec];
+            }
+            const float ratio = (float)exp((double)(lp - lp_old));
+            const float A = (a.adv + (size_t)c * a.N)[ec];
+            const float clipped = fminf(fmaxf(ratio, 1.f - a.eps_clip), 1.f + a.eps_clip);
+            const float s1 = ratio * A, s2 = clipped * A;
+            const bool use1 = s1 <= s2;  // torch.min picks surr1 on ties
+            const float wgt = a.weight ? (a.weight + (size_t)c * a.N)[ec] : 1.f;
+            const bool live = (use1 || (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip)) && wgt != 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sd[k] = live ? -A * ratio * d[k] * a.inv_var * a.inv_B : 0.f;
+            if (valid && half == 0 && wgt != 0.f) {
+                loss_acc += -(double)(use1 ? s1 : s2);
+                float dls = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dls += d[k] * d[k] * a.inv_var - 1.f;
+                if (live) std_acc += (double)(-A * ratio) * (double)(dls * a.inv_std);
+            }
+        } else {  // critic: c_value * (V - ret)^2
+            const float wgt = a.weight ? (a.weight + (size_t)c * a.N)[ec] : 1.f;
+            const float err = wgt != 0.f ? outv[0] - (a.returns + (size_t)c * a.N)[ec] : 0.f;
+            sd[0] = 2.f * a.c_value * err * a.inv_B;
+            if (valid && half == 0) loss_acc += (double)err * (double)err;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dz3[k] = a.final_tanh ? sd[k] * (1.f - outv[k] * outv[k]) : sd[k];
+            bstore(r_dz3, (valid && half == 0) ? ec * 4u : 0x80000000u, (uint32_t)k * N32 * 4u, dz3[k]);
+        }
+        // ---- backward.  dZ2 = (W3^T dz3) (1 - H2^2) on the vector lanes (W3 as [h][4] rows: one broadcast read per row; read
+        // AGAIN through a base the optimiser cannot equate with layer 3's -- kept from there the rows are 256 registers' worth
+        // of live values across the loss block); dH1 = W2^T dZ2 on the matrix cores, the A fragments by transposing reads of
+        // the same W2 image.  The 16-k steps are the OUTER loop: step ks feeds the eight dZ2 values of rows 32 to + 16 s + ...
+        // to the four output tiles' accumulators (four independent chains), and the vector work of step ks + 1 -- its eight
+        // dZ2 values, the H2 / dZ2 row stores, the split into bf16 terms -- sits beside those 24 MFMAs: the 128 row stores
+        // leave the wave spread over the walk instead of as one burst in front of it (a wave alone on its SIMD stalls on a full
+        // store queue; ablation: the stores were 2.9 of this kernel's 6.4 ms).  dZ1 = dH1 (1 - H1^2) / (2 log2 e): the
+        // image holds the pre-scaled W2.
+        int w3_base2 = w3_base;
+        asm volatile("" : "+v"(w3_base2));
+        bf16x8 bt[2][3];   // the B operand of step ks: bt[ks & 1]
+        auto dz2_step = [&](int ks) {   // rows of k-step ks: registers 8 s .. 8 s + 7 of tile to
+            const int to = ks >> 1, sj = ks & 1;
+            float v8[8];
+#pragma unroll
+            for (int i2 = 0; i2 < 8; ++i2) {
+                const int j2 = 8 * sj + i2;
+                const float4 w = *reinterpret_cast<const float4*>(ldsb + (w3_base2 + 16 * (32 * to + acc_row(j2, 0))));
+                const float g = fmaf(w.w, dz3[3], fmaf(w.z, dz3[2], fmaf(w.y, dz3[1], w.x * dz3[0])));
+                const float hv = h2[to][j2];
+                bstore(h2c, voff, row_soff(to, j2), hv);
+                v8[i2] = g * (1.f - hv * hv);
+                bstore(dz2c, voff, row_soff(to, j2), v8[i2]);
+            }
+            split3x8(v8, bt[ks & 1][0], bt[ks & 1][1], bt[ks & 1][2]);
+        };
+        f32x16 dd[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j2 = 0; j2 < 16; ++j2) dd[t][j2] = 0.f;
+        dz2_step(0);
+        // swizzled chunk of a transposed read = (4 t + 2 g + (p & 1)) ^ (4 q + 2 jg + half)   (row & 3 = q, (row >> 2) & 3 = 2 jg + half)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2 * NT; ++ks) {
+            const int to = ks >> 1, sj = ks & 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tb0 = tr_a + 64 * (t ^ tr_q) + 32 * tr_g, tb1 = tr_a + 64 * (t ^ tr_q) + 32 * (tr_g ^ 1) + W2D_ROW * 8;
+                const char* f0 = ldsb + (tb0 + W2D_ROW * (32 * to + 16 * sj));
+                const char* f1 = ldsb + (tb1 + W2D_ROW * (32 * to + 16 * sj));
+                bf16x8 af[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const v4s lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(f0 + m * W2D_TERM));
+                    const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(f1 + m * W2D_TERM));
+                    const short f8 __attribute__((ext_vector_type(8))) = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    af[m] = __builtin_bit_cast(bf16x8, f8);
+                }
+                six(dd[t], af[0], af[1], af[2], bt[ks & 1][0], bt[ks & 1][1], bt[ks & 1][2]);
+            }
+            if (ks + 1 < 2 * NT) dz2_step(ks + 1);
+            sgb_interleave_ds<24, 5, 2>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // H1 as this wave stored it (read at L2: glc), a tile ahead of the tile being finished
+        constexpr float INV_C = 1.0f / TANH_PRESCALE;
+        float h1r[2][16];
+        auto h1_request = [&](int t) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                h1r[t & 1][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h1c, voff, row_soff(t, j), 1));
+        };
+        if (!ONE_WAVE) h1_request(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (!ONE_WAVE && t + 1 < NT) h1_request(t + 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float hv = ONE_WAVE ? acc1[t][j] : h1r[t & 1][j];
+                bstore(dz1c, voff, row_soff(t, j), (dd[t][j] * INV_C) * (1.f - hv * hv));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (a.loss_mode != 0) {  // one atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_xor(loss_acc, off);
+        if (lane == 0) atomicAdd(&a.sums[a.loss_mode], loss_acc);
+        if (a.loss_mode == 1) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) std_acc += __shfl_xor(std_acc, off);
+            if (lane == 0) atomicAdd(&a.sums[4], std_acc);
+        }
+    }
+}
+
 // ---- weight gradients: C[M][Nn] += sum over samples A[m][s] * B[n][s]  (+ row sums of A = bias gradients)
 struct WgradArgs {
     int64_t N;
@@ -554,6 +933,23 @@ static int launch_bwd(BwdArgs& a, int hidden, void* stream) {
     int64_t blocks = (n_tiles + wpb - 1) / wpb;
     if (blocks > 256) blocks = 256;
     hipError_t e;
+    // QENV_BWD_BF16: 1 (default) = k_mlp_bwd_v3 for the N = 128, T = 5 networks, one wave per SIMD; 2 = the same kernel with two
+    // waves per SIMD (256 registers: it spills, 36 ms per epoch against 24.3); 0 = the fp32-MFMA kernel (29.3) -- A/B runs
+    static const int bwd_bf16 = getenv("QENV_BWD_BF16") ? atoi(getenv("QENV_BWD_BF16")) : 1;
+    if (bwd_bf16 && wide && hidden == mlp3::H && k_in == mlp3::KW) {
+        if (bwd_bf16 == 2) {
+            e = allow_dynamic_lds((const void*)k_mlp_bwd_v3<512>, (size_t)bwd3::LDS_BYTES);
+            if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd_v3)");
+            hipLaunchKernelGGL((k_mlp_bwd_v3<512>), dim3((unsigned)blocks), dim3(512), (size_t)bwd3::LDS_BYTES, (hipStream_t)stream, a);
+            return check_launch("k_mlp_bwd_v3");
+        }
+        int64_t b4 = (n_tiles + 3) / 4;
+        if (b4 > 256) b4 = 256;
+        e = allow_dynamic_lds((const void*)k_mlp_bwd_v3<256>, (size_t)bwd3::LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_bwd_v3)");
+        hipLaunchKernelGGL((k_mlp_bwd_v3<256>), dim3((unsigned)b4), dim3(256), (size_t)bwd3::LDS_BYTES, (hipStream_t)stream, a);
+        return check_launch("k_mlp_bwd_v3");
+    }
 #define QENV_BWD_CASE(HH)                                                                                                   \
     case HH:                                                                                                                 \
         if (wide) {                                                                                                          \

@@ -251,14 +251,15 @@ def _torch_nets(w, dtype=torch.float64):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("hidden", [16, 32, 64, 128])
-def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden, fused):
+@pytest.mark.parametrize("hidden,shape", [(16, (3, 200)), (32, (3, 200)), (64, (3, 200)), (128, (3, 200)), (128, (8, 5000))])
+def test_ppo_update_gradients_and_adam_vs_torch_autograd(aq, hidden, shape, fused):
     """Backward pass (MFMA), weight/bias gradients (split-K GEMM) and the Adam step of PpoLearner against torch
     autograd + torch.optim.Adam on the reference's loss (ppo.py:185-203), fp64 torch as the yardstick.  fused: the
     loss evaluated inside the backward kernel (qenv_mlp_backward_ppo, the default) or forward / qenv_ppo_loss /
-    backward as separate launches."""
+    backward as separate launches.  The (8, 5000) shape is past the 1 024 sample tiles from which the N = 128 network runs
+    k_mlp_bwd_v3 (split-bf16 matrix cores, one W2 image for the row reads and the transposing reads), ragged last tile."""
     torch.manual_seed(0)
-    n, N, K = 3, 200, 75
+    (n, N), K = shape, 75
     w = aq.ActorCriticWeights.random(hidden, K, 4, seed=3)
     w.std = 0.1
     obs = torch.randn(n, K, N, device="cuda")
