@@ -668,9 +668,15 @@ struct WgradArgs {
 // whole walk and adds them to C once at the end.  Two workgroups per CU (NW/2 waves per SIMD): a wave's staging,
 // barrier and LDS waits are covered by the MFMAs of the other (one workgroup of 4 waves per CU: matrix pipe 44 %
 // busy; two: 60 %).
-template <int MT, int NTN, int NW>
+// BF16: the products on the bf16 matrix cores with three-way split operands (k_mlp_v3's arithmetic): the sample index is the k of
+// this product and runs along the LDS rows, so a lane's eight consecutive samples are an MFMA fragment -- two ds_read_b128 from
+// rows padded to 68 words (16-byte aligned, conflict-free for the 16-lane groups of a 128-bit read), split in registers, six
+// v_mfma_f32_32x32x16_bf16 of 32 cycles per 16 samples and output tile instead of eight v_mfma_f32_32x32x2_f32 of 64.  The
+// global -> LDS staging is unchanged (fully coalesced row loads; fragments loaded straight from global memory -- 16 bytes per
+// lane at a 128-byte stride -- thrashed the vector L1: 25.7 ms per epoch against 24.1).
+template <int MT, int NTN, int NW, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) {  // NW/2 waves per SIMD = two workgroups per CU
-    constexpr int LD = 65, ROWS = (MT + NTN) * 32, TPW = (MT * NTN + NW - 1) / NW;
+    constexpr int LD = BF16 ? 68 : 65, ROWS = (MT + NTN) * 32, TPW = (MT * NTN + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                 // [MT*32][65]
     float* Bs = As + MT * 32 * LD;   // [NTN*32][65]
@@ -748,6 +754,36 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) { 
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
         int tm0, tn0;
         tile_of(tid0, tm0, tn0);
+        if constexpr (BF16) {
+            auto frag = [&](const float* rows, int tile32, int s, bf16x8 (&sp)[3]) {   // samples 16 s + 8 half + 0..7 of row 32 tile32 + col
+                const float4* p4 = reinterpret_cast<const float4*>(rows + (32 * tile32 + col) * LD + 16 * s + 8 * half);
+                const float4 lo = p4[0], hi = p4[1];
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                split3x8(v, sp[0], sp[1], sp[2]);
+            };
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a3[3], b3[3];
+                if (SAME_A) frag(As, tm0, s, a3);
+                if (SAME_B) frag(Bs, tn0, s, b3);
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    const int tid = tid0 + q;
+                    if (FULL || tid < MT * NTN) {
+                        int tm, tn;
+                        tile_of(tid, tm, tn);
+                        if (!SAME_A) frag(As, tm, s, a3);
+                        if (!SAME_B) frag(Bs, tn, s, b3);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1], acc[q], 0, 0, 0);   // smallest products first
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[2], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0], acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        } else
 #pragma unroll 4
         for (int ks = 0; ks < 32; ++ks) {
             const int sidx = 2 * ks + half;
@@ -815,9 +851,27 @@ template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream
     // NW = 8 / 6 (4 / 3 waves per SIMD with two workgroups per CU) was measured and is NOT used: under the 128 / 168 VGPR cap
     // hipcc shuttles the accumulator tiles between VGPRs and AGPRs around every MFMA (dW2 3.0 -> 4.9 ms, dW1 2.4 -> 5.8 ms)
     constexpr int NW = 4;
-    const size_t lds = sizeof(float) * (size_t)(MT + NTN) * 32 * 65;
     const int64_t n_tiles = ((a.N + 63) / 64) * a.n_chunks;
     const int64_t blocks = n_tiles < 512 ? n_tiles : 512;
+    if constexpr (MT == 4 && NTN == 4) {   // dW2 of the N = 128 networks: 2.78 -> 2.53 ms at 8.4 M samples (dW1, 128 x 75: 2.07 -> 2.18, not
+        // used: the staging, not the matrix loop, limits these kernels); QENV_WGRAD_BF16=0 keeps the fp32-MFMA kernel (A/B runs)
+        static const int bf16 = getenv("QENV_WGRAD_BF16") ? atoi(getenv("QENV_WGRAD_BF16")) : 1;
+        if (bf16 && n_tiles >= 512) {
+            const size_t lds3 = sizeof(float) * (size_t)(MT + NTN) * 32 * 68;
+            hipError_t e3 = allow_dynamic_lds((const void*)k_wgrad<MT, NTN, NW, true>, lds3);
+            if (e3 != hipSuccess) return fail_hip(e3, "hipFuncSetAttribute(k_wgrad bf16)");
+            hipLaunchKernelGGL((k_wgrad<MT, NTN, NW, true>), dim3((unsigned)blocks), dim3(NW * 64), lds3, stream, a);
+            int rc3 = check_launch("k_wgrad(bf16)");
+            if (rc3 == 0 && a.partial) {
+                const int64_t mn = (int64_t)a.M * a.Nn, tot = mn + a.M;
+                hipLaunchKernelGGL(k_sum_wgrad_slots, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, a.partial, (int)blocks, mn,
+                                   (int64_t)a.M, a.C, a.rowsum);
+                rc3 = check_launch("k_sum_wgrad_slots");
+            }
+            return rc3;
+        }
+    }
+    const size_t lds = sizeof(float) * (size_t)(MT + NTN) * 32 * 65;
     hipError_t e = allow_dynamic_lds((const void*)k_wgrad<MT, NTN, NW>, lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_wgrad)");
     hipLaunchKernelGGL((k_wgrad<MT, NTN, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, stream, a);
