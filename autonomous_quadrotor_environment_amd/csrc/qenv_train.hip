@@ -734,8 +734,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) { 
     constexpr bool SAME_A = (NTN % TPW) == 0;
     constexpr bool SAME_B = !SAME_A && (MT % TPW) == 0;
     const int tid0 = wave_s * TPW;
+    // BF16, 4 x 4 output tiles: a wave owns a 2 x 2 block (two A and two B fragments per 16 samples feed four tiles: four operand
+    // splits per 24 MFMAs instead of the five of a row of tiles -- the bf16 variant is bound by the vector work of the splits)
+    constexpr bool BLOCK22 = BF16 && MT == 4 && NTN == 4 && NW == 4;
     auto tile_of = [&](int tid, int& tm, int& tn) {
-        if (SAME_B) { tm = tid % MT; tn = tid / MT; }
+        if (BLOCK22) { const int w = tid / TPW, q = tid % TPW; tm = 2 * (w >> 1) + (q >> 1); tn = 2 * (w & 1) + (q & 1); }
+        else if (SAME_B) { tm = tid % MT; tn = tid / MT; }
         else { tm = tid / NTN; tn = tid % NTN; }
     };
     if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
@@ -761,6 +765,25 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_wgrad(const WgradArgs a) { 
                 const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 split3x8(v, sp[0], sp[1], sp[2]);
             };
+            if constexpr (BLOCK22) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    bf16x8 a2[2][3], b2[2][3];
+                    frag(As, tm0, s, a2[0]); frag(As, tm0 + 1, s, a2[1]);
+                    frag(Bs, tn0, s, b2[0]); frag(Bs, tn0 + 1, s, b2[1]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bf16x8 (&a3)[3] = a2[q >> 1];
+                        const bf16x8 (&b3)[3] = b2[q & 1];
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[2], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0], acc[q], 0, 0, 0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 bf16x8 a3[3], b3[3];
