@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 5
+QENV_ABI_VERSION = 6
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -48,7 +48,8 @@ class PpoStepArgs(C.Structure):  # qenv_ppo_step_args (include/qenv.h)
     _fields_ = [("k_in", C.c_int32), ("hidden", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3")] + \
                [("std", C.c_double), ("noise", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_uint64), ("env_offset", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("out_mean", "out_action", "out_logprob", "obs_store", "out_reward", "out_done", "out_mask",
-                                          "out_valid")] + [("inband", C.c_int32), ("key_by_episode", C.c_int32)]
+                                          "out_valid")] + [("inband", C.c_int32), ("key_by_episode", C.c_int32), ("obs_rows_from", C.c_int32),
+                                                           ("obs_slices", C.c_int32)]
 
 
 # every symbol include/qenv.h declares: (name, restype, argtypes)
@@ -83,6 +84,7 @@ SYMBOLS = {
     "qenv_attach_sensor": (_i, [_vp, _vp, _vp, C.c_uint64, _i64, _i, _dptr, _vp, C.c_uint64]),
     "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_dense_tail_chunks": (_i, [_i64, C.c_int32, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_dense_tail_chunks_strided": (_i, [_i64, C.c_int32, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),
     "qenv_policy_act": (_i, [_vp, _i, _i] + [_vp] * 6 + [C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp, _vp, _vp]),
     "qenv_sample_init_states": (_i, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),

@@ -252,6 +252,8 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     // they share their SIMDs with the policy forward, the gathered forward of the reset envs costs 65 us and the two
     // streams meet twice per step; with few resets per step (episodes that run their 500 steps) the side chain is shorter
     // than the main one and it pays (tests/tools/ab_ppo_overlap.py measures both and checks bit-identity)
+    if ((p->obs_rows_from != 0 || p->obs_slices != 0) && !p->inband)
+        return fail(QENV_ERR_ARG, "qenv_ppo_step: the slice layout of stored observations needs the in-band schedule (one window slice per env and step)");
     if (p->inband) {
         // in-band warm-up: policy + step, the restart in the step kernel's epilogue, the warm-up steps ride the next T steps
         if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
@@ -259,7 +261,8 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
         exi.ar_on = 2; exi.ar_seed = p->seed; exi.ar_episode = p->step; exi.ar_env_offset = p->env_offset;
         exi.ar_key_episode = p->key_by_episode; exi.out_valid = p->out_valid;
         int rci = policy_act_subset(q, p->k_in, p->hidden, p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->std, p->noise, p->seed, p->step,
-                                    p->env_offset, p->out_mean, p->out_action, p->out_logprob, p->obs_store, nullptr, nullptr, nullptr);
+                                    p->env_offset, p->out_mean, p->out_action, p->out_logprob, p->obs_store, nullptr, nullptr, nullptr,
+                                    p->obs_rows_from);
         if (rci == QENV_OK)
             rci = QENV_DISPATCH(q, do_step, q, p->out_action, nullptr, nullptr, p->out_reward, p->out_done, p->out_mask, QENV_STEP_NO_AUX,
                                 q->win_head, &exi);
@@ -294,7 +297,7 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     const int32_t* list_n = q->counters + cur;
     auto act = [&](const uint8_t* skip, const int32_t* li, const int32_t* ln) {
         return policy_act_subset(q, p->k_in, p->hidden, p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, p->std, p->noise, p->seed, p->step,
-                                 p->env_offset, p->out_mean, p->out_action, p->out_logprob, p->obs_store, skip, li, ln);
+                                 p->env_offset, p->out_mean, p->out_action, p->out_logprob, p->obs_store, skip, li, ln, p->obs_rows_from);
     };
     auto step = [&](const uint8_t* skip, const int32_t* li, const int32_t* ln) {
         ex.env_skip = skip; ex.list_idx = li; ex.list_count = ln;
@@ -365,7 +368,12 @@ int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args* first, int n_steps) {
         a.noise = adv(first->noise, 4 * N * esz, t);
         a.out_action = adv(first->out_action, 4 * N * esz, t);
         a.out_logprob = adv(first->out_logprob, 4 * N * esz, t);
-        a.obs_store = (float*)adv(first->obs_store, (size_t)15 * q->cfg.T * N * sizeof(float), t);
+        if (first->obs_slices) {   // one 15-float slice per step (see qenv.h): step 0 as the caller set it up, then the newest slice only
+            a.obs_store = (float*)adv(first->obs_store, (size_t)15 * N * sizeof(float), t);
+            if (t > 0) a.obs_rows_from = 15 * (q->cfg.T - 1);
+        } else {
+            a.obs_store = (float*)adv(first->obs_store, (size_t)15 * q->cfg.T * N * sizeof(float), t);
+        }
         a.out_reward = adv(first->out_reward, N * esz, t);
         a.out_mask = adv(first->out_mask, N * esz, t);
         a.out_valid = adv(first->out_valid, N * esz, t);

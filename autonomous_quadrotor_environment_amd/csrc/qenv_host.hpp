@@ -169,6 +169,6 @@ int ppo_flush(qenv_s* q);
 int policy_act_subset(qenv_s* q, int k_in, int hidden, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                       const float* b3, double std, const void* noise, uint64_t seed, uint64_t step, int64_t env_offset,
                       void* out_mean, void* out_action, void* out_logprob, float* obs_store, const uint8_t* env_skip,
-                      const int32_t* list_idx, const int32_t* list_count);
+                      const int32_t* list_idx, const int32_t* list_count, int obs_rows_from = 0);
 
 }  // namespace qenv

@@ -64,6 +64,12 @@ struct MlpArgs {
     int32_t* zero_word;
     // k_mlp_v3: null, or the weights already in the kernel's LDS layout (qenv_mlp_prepare): staging is then a plain copy
     const uint4* image;
+    // The SLICE layout of stored observations (k_mlp_v3 / k_mlp_small; launch_mlp refuses it elsewhere).  The window of step t is
+    // the five newest 15-float slices, so consecutive windows overlap in four of them: a rollout stores ONE slice per step into
+    // an array [(n_steps + T - 1) * 15][N] and the window of step t is its rows 15 t .. 15 t + 15 T - 1 -- the [n][15 T][N]
+    // layout with a chunk stride of 15 N instead of 15 T N.
+    int32_t obs_rows_from;      // obs_store: only rows >= this are written (15 (T - 1): the newest slice; 0: the whole window)
+    int64_t win_chunk_stride;   // n_chunks > 1: elements between consecutive chunks of `win` (0 = 15 T N, dense)
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1);
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         const uint32_t e4 = e < a.N ? (uint32_t)e * 4u : 0x80000000u;
         // the descriptor must be PROVABLY wave-uniform (the tile index comes from threadIdx.x >> 6): otherwise hipcc wraps every
         // one of the 40 buffer loads in a waterfall loop (readfirstlane x 4, compare, saveexec, branch)
-        const uint64_t base = (uint64_t)(a.win + chunk * (int64_t)KW * a.N);
+        const uint64_t base = (uint64_t)(a.win + chunk * (a.win_chunk_stride ? a.win_chunk_stride : (int64_t)KW * a.N));
         const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);          // (the builtin returns int:
         const uint32_t base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));  //  no sign extension into bit 32+)
         const uint64_t base_u = ((uint64_t)base_hi << 32) | (uint64_t)base_lo;
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const uint32_t k = (uint32_t)(16 * sk + i) + kh;
-                        if (k < (uint32_t)KW) obs_c[k * n32 + e32] = xw[sk][i];
+                        if (k < (uint32_t)KW && k >= (uint32_t)a.obs_rows_from) obs_c[k * n32 + e32] = xw[sk][i];
                     }
                 }
                 split3x8(xw[sk], xsp[sk][0], xsp[sk][1], xsp[sk][2]);
@@ -912,7 +918,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         const int64_t chunk = a.n_chunks > 1 ? gtile / tiles_per_chunk : 0;
         const int64_t tile = gtile - chunk * tiles_per_chunk;
         if (a.list_idx && tile * 32 >= n_list) break;  // block-uniform: no barrier is skipped by a part of the block
-        const float* __restrict__ winc = a.win + chunk * (int64_t)K1 * a.N;
+        const float* __restrict__ winc = a.win + chunk * (a.win_chunk_stride ? a.win_chunk_stride : (int64_t)K1 * a.N);
         const int64_t j_list = tile * 32 + col;
         const int64_t e = a.list_idx ? (j_list < n_list ? (int64_t)a.list_idx[j_list] : a.N) : j_list;
         const bool valid = e < a.N;
@@ -936,7 +942,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
                     v8[i] = x;
                     if (a.obs_store && valid && t == 0) {
                         const int k = 16 * sk + 8 * half + i;
-                        if (k < K1) a.obs_store[(int64_t)k * a.N + e] = x;
+                        if (k < K1 && k >= a.obs_rows_from) a.obs_store[(int64_t)k * a.N + e] = x;
                     }
                 }
                 bf16x8 xh, xm, xl;
@@ -967,7 +973,7 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int k = 2 * s + half;
-                if (k < K1) a.obs_store[(int64_t)k * a.N + e] = xs[s];
+                if (k < K1 && k >= a.obs_rows_from) a.obs_store[(int64_t)k * a.N + e] = xs[s];
             }
         }
         // layer 1, output tile t: k-step s pairs window elements 2s (lanes 0-31) and 2s+1 (lanes 32-63)
@@ -1324,6 +1330,12 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
             hipLaunchKernelGGL((k_mlp_v3<BLOCK, SAMPLE>), dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
             return check_launch("k_mlp_v3");
         }
+    }
+    if (a.obs_rows_from != 0 || (a.win_chunk_stride != 0 && a.win_chunk_stride != (int64_t)15 * T * a.N))
+        return fail(QENV_ERR_ARG, "the slice layout of stored observations (obs_slices / chunk stride) is implemented for hidden 64 / 128 "
+                                  "with T = 5 (k_mlp_small, k_mlp_v3)");
+    if constexpr (H == 128 && TW == 5 && W2_LDS) {
+        constexpr int NT = HP / 32, KS16 = (15 * TW + 15) / 16;
         if (mlp_bf16_layer2() >= 2) {
             const size_t lds = sizeof(float) * ((size_t)NT * KS16 * 3 * 64 * 4 + (size_t)NT * NT * 2 * 3 * 64 * 4 + 4 * HP + 2 * HP + 32);
             if (lds > 160 * 1024) return fail(QENV_ERR_ARG, "qenv_mlp_forward: weights do not fit the 160 KiB LDS");
@@ -1352,6 +1364,8 @@ static int launch_mlp(const MlpArgs& a, int T, hipStream_t stream) {
 // N = 256: the LDS-staged wide kernel whenever W1 and one W2 block fit (T <= 8); QENV_MLP_WIDE=0 keeps the kernel it
 // replaced (W2 read from global memory inside the MFMA chain) for A/B runs
 template <bool SAMPLE> static int launch_mlp_256(const MlpArgs& a, int T, hipStream_t stream) {
+    if (a.obs_rows_from != 0 || (a.win_chunk_stride != 0 && a.win_chunk_stride != (int64_t)15 * T * a.N))
+        return fail(QENV_ERR_ARG, "the slice layout of stored observations is implemented for hidden 64 / 128 with T = 5");
     static const int wide = getenv("QENV_MLP_WIDE") ? atoi(getenv("QENV_MLP_WIDE")) : 1;
     if (wide && !a.list_idx) {
         bool fits = false;
@@ -2006,15 +2020,16 @@ int qenv_policy_act(qenv_t q, int k_in, int hidden, const float* W1, const float
 int qenv::policy_act_subset(qenv_s* q, int k_in, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
                             const float* W3, const float* b3, double std, const void* noise, uint64_t seed, uint64_t step,
                             int64_t env_offset, void* out_mean, void* out_action, void* out_logprob, float* obs_store,
-                            const uint8_t* env_skip, const int32_t* list_idx, const int32_t* list_count) {
+                            const uint8_t* env_skip, const int32_t* list_idx, const int32_t* list_count, int obs_rows_from) {
     if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out_action) return fail(QENV_ERR_ARG, "qenv_policy_act: null argument");
+    if (obs_rows_from < 0 || obs_rows_from >= 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_ppo_step: obs_rows_from must be in [0, 15*T)");
     if (!(std > 0)) return fail(QENV_ERR_ARG, "qenv_policy_act: std must be positive");
     if (k_in != 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_policy_act: k_in (row length of W1) must be 15*T of the handle");
     MlpArgs a{};
     a.win = q->window; a.N = q->N; a.T = q->cfg.T; a.head = q->win_head; a.n_out = 4; a.final_tanh = 1;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out_mean;
     a.out_f64 = q->cfg.dtype == QENV_F64;
-    a.obs_store = obs_store; a.n_chunks = 1;
+    a.obs_store = obs_store; a.n_chunks = 1; a.obs_rows_from = obs_rows_from;
     a.noise = noise; a.seed = seed; a.step = step; a.env_offset = env_offset;
     a.std = std; a.log_norm = -std::log(std) - 0.9189385332046727;  // -log(std) - 0.5 log(2 pi)
     a.out_action = out_action; a.out_logprob = out_logprob;
@@ -2037,14 +2052,23 @@ extern "C" {
 int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, int n_out, int final_tanh, const float* x,
                            const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                            const float* b3, float* out, void* stream) {
+    return qenv_dense_tail_chunks_strided(n, n_chunks, 0, k_in, hidden, n_out, final_tanh, x, W1, b1, W2, b2, W3, b3, out, stream);
+}
+
+int qenv_dense_tail_chunks_strided(int64_t n, int32_t n_chunks, int64_t chunk_stride, int k_in, int hidden, int n_out, int final_tanh,
+                                   const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                   const float* b3, float* out, void* stream) {
     if (!x || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_dense_tail: null argument");
     if (n <= 0 || n_chunks < 1 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_dense_tail: bad sizes");
+    if (chunk_stride < 0) return fail(QENV_ERR_ARG, "qenv_dense_tail_chunks_strided: negative chunk stride");
+    if (chunk_stride != 0 && chunk_stride != (int64_t)k_in * n && k_in != 75)
+        return fail(QENV_ERR_ARG, "qenv_dense_tail_chunks_strided: a chunk stride other than K*n needs the 75-float observation (K = 75)");
     if ((int64_t)k_in * n >= ((int64_t)1 << 31)) return fail(QENV_ERR_ARG, "qenv_dense_tail: K*n must stay below 2^31");
     if (k_in == 75) {  // the controller's 75-float observation (T = 5): W1 fits the LDS whole -> the k_mlp kernel,
         MlpArgs m{};   // reading each chunk as a window ring with head 0 (row r of a chunk = window element r)
         m.win = x; m.N = n; m.T = 5; m.head = 0; m.n_out = n_out; m.final_tanh = final_tanh;
         m.W1 = W1; m.b1 = b1; m.W2 = W2; m.b2 = b2; m.W3 = W3; m.b3 = b3; m.out = out; m.out_f64 = 0;
-        m.obs_store = nullptr; m.n_chunks = n_chunks;
+        m.obs_store = nullptr; m.n_chunks = n_chunks; m.win_chunk_stride = chunk_stride;
         switch (hidden) {
             case 16: return launch_mlp<16, 5, 512, true>(m, 5, (hipStream_t)stream);
             case 32: return launch_mlp<32, 5, 512, true>(m, 5, (hipStream_t)stream);

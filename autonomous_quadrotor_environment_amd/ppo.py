@@ -435,8 +435,11 @@ class PpoLearner:
                 raise ValueError("minibatch epochs over an in-band rollout are not implemented (full-batch epochs are)")
             v32 = valid[:n].to(torch.float32).contiguous()
             n_valid = int(v32.sum().item())
+            obs = rollout.obs[:n]
+            if not obs.is_contiguous():   # observations stored as slices (PolicyRollout.slice_obs): ONE dense copy for all epochs
+                obs = obs.contiguous()
             for _ in range(self.K_epochs):
-                out.append(self.gradients(rollout.obs[:n], rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n],
+                out.append(self.gradients(obs, rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n],
                                           valid=v32, n_valid=n_valid))
                 self.adam_step()
             return out
@@ -496,13 +499,18 @@ class PolicyRollout:
     streams shard-invariant)."""
 
     def __init__(self, env: BatchedQuad, weights: ActorCriticWeights, horizon, store_obs=False, auto_reset=False,
-                 seed=0, env_offset=0, inband=False, key_by_episode=False):
+                 seed=0, env_offset=0, inband=False, key_by_episode=False, slice_obs=None):
         """inband (with auto_reset): IN-BAND warm-up (qenv_ppo_step, include/qenv.h) -- an env whose episode ends is reset in
         the step kernel's epilogue and the T warm-up steps of that reset are its next T regular steps (zero_control forced,
         window refilled in place); those rows of the rollout get `valid` = 0 and are left out of GAE's moments and of the
         loss (finish() and PpoLearner.update take care of it).  No warm-up launch: a step is policy + env step.  The valid
         rows of an env are the samples the default schedule collects for the same episodes, T rows later per restart.
-        key_by_episode: an env's n-th restart draws its state from the stream of n, not of the step it happens in."""
+        key_by_episode: an env's n-th restart draws its state from the stream of n, not of the step it happens in.
+        slice_obs (None = whenever possible: in-band schedule, stored observations, hidden 128, T = 5): the observations are
+        stored as ONE 15-float slice per step -- under the in-band schedule every env pushes exactly one slice per step, so
+        the windows of consecutive steps overlap in T - 1 slices; `obs` is then a strided VIEW [horizon, 15 T, N] of the
+        slice array [(horizon + T - 1) * 15, N] (same indexing, a fifth of the memory and of the store traffic; the
+        critic reads it in place, the learner takes one contiguous copy per update)."""
         assert env.direct_control_flag, "the PPO controller commands the four rotors (direct_control=1)"
         self.env, self.w, self.horizon = env, weights, int(horizon)
         self.auto_reset, self.seed, self.env_offset = bool(auto_reset), int(seed), int(env_offset)
@@ -528,7 +536,15 @@ class PolicyRollout:
         self.masks = torch.ones(H, N, device=dev, dtype=dt)
         self.valid = torch.ones(H, N, device=dev, dtype=dt) if self.inband else None   # 0: a restarted env's warm-up row
         self.values = torch.zeros(H + 1, N, device=dev, dtype=dt)
-        self.obs = torch.zeros(H, 15 * env.T, N, device=dev, dtype=torch.float32) if store_obs else None
+        can_slice = bool(store_obs and self.inband and env.T == 5 and weights.hidden == 128)
+        if slice_obs and not can_slice:
+            raise ValueError("slice_obs needs store_obs, the in-band schedule, hidden 128 and T = 5")
+        self.slice_obs = can_slice if slice_obs is None else bool(slice_obs)
+        if self.slice_obs:
+            self._obs_slices = torch.zeros((H + env.T - 1) * 15, N, device=dev, dtype=torch.float32)
+            self.obs = torch.as_strided(self._obs_slices, (H, 15 * env.T, N), (15 * N, N, 1))
+        else:
+            self.obs = torch.zeros(H, 15 * env.T, N, device=dev, dtype=torch.float32) if store_obs else None
         self.mean = torch.zeros(4, N, device=dev, dtype=dt)
         self.done = torch.zeros(N, device=dev, dtype=torch.uint8)
         self.init = torch.zeros(13, N, device=dev, dtype=dt)
@@ -564,7 +580,8 @@ class PolicyRollout:
             env.ppo_step(w, self.seed, self.global_step + 1, self.env_offset, self.actions[t], self.logprobs[t], self.mean,
                          store, self.rewards[t], self.done, self.masks[t], noise=noise,
                          valid=None if self.valid is None else self.valid[t], inband=self.inband,
-                         key_by_episode=self.key_by_episode)
+                         key_by_episode=self.key_by_episode,
+                         obs_rows_from=15 * (env.T - 1) if (self.slice_obs and t > 0) else 0)
             self.t += 1
             self.global_step += 1
             return
@@ -624,7 +641,7 @@ class PolicyRollout:
                           self.mean.data_ptr(), self.actions[t0].data_ptr(), self.logprobs[t0].data_ptr(),
                           None if self.obs is None else self.obs[t0].data_ptr(), self.rewards[t0].data_ptr(), self.done.data_ptr(),
                           self.masks[t0].data_ptr(), None if self.valid is None else self.valid[t0].data_ptr(), int(self.inband),
-                          int(self.key_by_episode))
+                          int(self.key_by_episode), 15 * (env.T - 1) if (self.slice_obs and t0 > 0) else 0, int(self.slice_obs))
         env._bind()
         L.check(L.lib.qenv_ppo_rollout(env._h, C.byref(a), n_steps), "qenv_ppo_rollout")
         self.t += n_steps
@@ -639,9 +656,9 @@ class PolicyRollout:
             if self._values_f32 is None:
                 self._values_f32 = torch.empty(self.horizon, env.n_envs, device=env.device, dtype=torch.float32)
             out = self._values_f32[:n]
-        L.check(L.lib.qenv_dense_tail_chunks(env.n_envs, n, 15 * env.T, self.w.hidden, 1, 0, L.ptr(self.obs),
-                                             *[L.ptr(x) for x in W], L.ptr(out), _stream(env.device)),
-                "qenv_dense_tail_chunks")
+        L.check(L.lib.qenv_dense_tail_chunks_strided(env.n_envs, n, 15 * env.n_envs if self.slice_obs else 0, 15 * env.T,
+                                                     self.w.hidden, 1, 0, L.ptr(self.obs), *[L.ptr(x) for x in W], L.ptr(out),
+                                                     _stream(env.device)), "qenv_dense_tail_chunks_strided")
         if out.dtype != self.values.dtype:
             self.values[:n].copy_(out)
         return self.values[:n]
@@ -726,7 +743,7 @@ class StreamShardedRollout:
                                            ro.logprobs[t].data_ptr(), None if ro.obs is None else ro.obs[t].data_ptr(),
                                            ro.rewards[t].data_ptr(), ro.done.data_ptr(), ro.masks[t].data_ptr(),
                                            None if ro.valid is None else ro.valid[t].data_ptr(), int(ro.inband),
-                                           int(ro.key_by_episode)))
+                                           int(ro.key_by_episode), 15 * (env.T - 1) if (ro.slice_obs and t > 0) else 0, 0))
             out.append((env._h, per_t, float(w.std)))
         self._C = C
         return out

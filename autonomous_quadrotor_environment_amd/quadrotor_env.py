@@ -508,10 +508,12 @@ class BatchedQuad:
         return out
 
     def ppo_step(self, weights, seed, step, env_offset, actions, logprob, mean, obs_store, reward, done, mask, noise=None,
-                 valid=None, inband=False, key_by_episode=False):
+                 valid=None, inband=False, key_by_episode=False, obs_rows_from=0):
         """One step of the rollout worker loop with auto-reset (qenv_ppo_step): policy_act + step(NO_AUX, push_window) +
         reset_sampled(mask=done), bit-identical buffers, with the reset envs' warm-up overlapped with the next step (it
-        stays PENDING after the call: ppo_flush(), or any other call that touches the env, completes it)."""
+        stays PENDING after the call: ppo_flush(), or any other call that touches the env, completes it).
+        obs_rows_from (in-band schedule, hidden 64 / 128, T = 5): only rows >= it of the window are written to obs_store --
+        15 (T - 1) stores the newest slice alone (the slice layout of PolicyRollout, include/qenv.h)."""
         key = (id(weights), weights.actor[0].data_ptr())
         if getattr(self, "_ppo_checked", None) != key:  # validate a weight set once, not on every step
             self._check_head(weights.head("actor"), "actor", n_out=4)
@@ -530,7 +532,8 @@ class BatchedQuad:
                           None if mean is None else mean.data_ptr(), actions.data_ptr(),
                           None if logprob is None else logprob.data_ptr(), None if obs_store is None else obs_store.data_ptr(),
                           reward.data_ptr(), done.data_ptr(), None if mask is None else mask.data_ptr(),
-                          None if valid is None else valid.data_ptr(), int(bool(inband)), int(bool(key_by_episode)))
+                          None if valid is None else valid.data_ptr(), int(bool(inband)), int(bool(key_by_episode)),
+                          int(obs_rows_from), 0)
         self._bind()
         L.check(L.lib.qenv_ppo_step(self._h, C.byref(a)), "qenv_ppo_step")
 

@@ -565,6 +565,7 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
            "schedule": (schedule if controller == "ppo_rollout" else None)}
     if controller == "ppo_rollout" and schedule == "inband":   # share of the rollout rows that are policy steps (the others are
         ros = [ro] if shards == 1 else ro.ros                   # the restarted envs' warm-up steps: env steps, but no samples)
+        res["obs_layout"] = "slices" if all(getattr(r, "slice_obs", False) for r in ros) else "windows"
         res["valid_row_fraction"] = float(sum(float(r.valid[:r.t].sum()) for r in ros) / max(1, sum(r.valid[:r.t].numel() for r in ros)))
     return res, env, (controller, flags, no_graph, bytes_per_step, n_global)
 
@@ -670,7 +671,7 @@ def slice_of(r, name, handle):
            "achieved": rf["achieved"], "roofline_unit": rf["unit"], "stream_shards": r["stream_shards"],
            "episode_steps": r["episode_steps"], "envs_per_kernel_launch": rf.get("envs_per_launch", r["envs_per_gpu"]),
            "all_gathered_returns": r["all_gather_len"], "all_gather_us": r["all_gather_us"]}
-    for k in ("schedule", "valid_row_fraction"):
+    for k in ("schedule", "valid_row_fraction", "obs_layout"):
         if r.get(k) is not None:
             out[k] = r[k]
     for k in ("valu", "mfma_cycles_per_tile", "algorithmic", "bf16_products_tflops"):
@@ -714,7 +715,7 @@ def main():
                    "parallelism": f"env-sharded x{world}", "stream_shards_per_gpu": res["stream_shards"],
                    "episode_steps": res["episode_steps"],
                    "finite": res["finite"], "weights": res["weights"], "schedule": res.get("schedule"),
-                   "valid_row_fraction": res.get("valid_row_fraction"),
+                   "valid_row_fraction": res.get("valid_row_fraction"), "obs_layout": res.get("obs_layout"),
                    "all_gathered_returns": res["all_gather_len"], "all_gather_us": res["all_gather_us"]},
         "timing": {"regions": res["regions"], "statistic": "median of the K-step regions (each barrier+sync bracketed)",
                    "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],

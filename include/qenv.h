@@ -39,7 +39,7 @@ extern "C" {
  * 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
  * 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
-#define QENV_ABI_VERSION 5
+#define QENV_ABI_VERSION 6
 
 typedef struct qenv_s *qenv_t;
 
@@ -320,6 +320,11 @@ int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, 
 int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, int n_out, int final_tanh,
                            const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
                            const float *W3, const float *b3, float *out, void *stream);
+/* ABI 6.  The same with `chunk_stride` elements between consecutive chunks of x (0 = K*n, dense): K = 75 observations
+ * stored as slices (qenv_ppo_step_args.obs_slices) are read in place with chunk_stride = 15*n. */
+int qenv_dense_tail_chunks_strided(int64_t n, int32_t n_chunks, int64_t chunk_stride, int k_in, int hidden, int n_out,
+                                   int final_tanh, const float *x, const float *W1, const float *b1, const float *W2,
+                                   const float *b2, const float *W3, const float *b3, float *out, void *stream);
 
 /* Replaces ActorCritic.act's sampling (model.py:62-68): action = mean + std * eps,
  * logprob = Normal(mean, std).log_prob(action) per dimension.
@@ -390,6 +395,16 @@ typedef struct {
      * whenever it starts. */
     void *out_valid;                            /* [N] in the handle's dtype, nullable: 0 for a warm-up row, else 1 */
     int32_t inband, key_by_episode;
+    /* ABI 6.  The SLICE layout of stored observations.  The window the policy sees at step t is the T newest 15-float
+     * slices {action, v, q, q_dot} (dl_in_gen.dl_input), and every env pushes exactly one slice per step under the in-band
+     * schedule -- consecutive windows overlap in T - 1 slices.  obs_rows_from > 0: obs_store receives only rows >=
+     * obs_rows_from of the window (15 (T - 1): the newest slice).  obs_slices != 0 (qenv_ppo_rollout): obs_store is an array
+     * [(n_steps + T - 1) * 15][N]; step t writes at row 15 t -- step 0 as obs_rows_from of `first` says (0: the whole window,
+     * i.e. the rollout's first T slices), every later step only its newest slice -- so that afterwards the window of step t
+     * is rows 15 t .. 15 t + 15 T - 1: the [n_steps][15 T][N] layout read with a chunk stride of 15 N
+     * (qenv_dense_tail_chunks_strided; a fifth of the store traffic and of the buffer).  inband only (a warm-up LAUNCH pushes
+     * T slices in one step); hidden 64 / 128 with T = 5. */
+    int32_t obs_rows_from, obs_slices;
 } qenv_ppo_step_args;
 int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args *args);
 int qenv_ppo_flush(qenv_t q);

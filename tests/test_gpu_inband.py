@@ -220,3 +220,38 @@ def test_ppo_rollout_call_equals_the_step_calls(aq, inband):
         for k, (x, y) in enumerate(zip(outs[0][rep], outs[1][rep])):
             assert torch.equal(x, y), (rep, k)
     assert int(outs[0][1][10].sum()) > n   # episodes did end and restart
+
+
+def test_slice_observation_store_equals_the_window_store(aq):
+    """PolicyRollout(slice_obs=True) -- ONE 15-float slice per step under the in-band schedule, `obs` a strided view of the
+    slice array (qenv_ppo_step_args.obs_rows_from / obs_slices, qenv_dense_tail_chunks_strided) -- against the dense
+    [horizon, 75, N] store of the same rollout: observations, critic values, returns, advantages and the learner's gradients
+    bit for bit, through episode ends (n = 9: every env restarts several times), via step() and via run()."""
+    n, H, n_max = 2080, 40, 9      # 65 tiles: the staged kernel k_mlp_v3 (k_mlp_small up to 64 tiles)
+    res = {}
+    for mode in ("dense", "slices_step", "slices_run", "small_slices"):
+        w, _ = _weights(aq)            # a fresh copy per mode: the learner below updates it
+        n_envs = 96 if mode == "small_slices" else n
+        env = aq.BatchedQuad(n_envs, 0.01, n_max, training=True, direct_control=1, T=5, **LEAN)
+        ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=5, inband=True, key_by_episode=True,
+                              slice_obs=(mode != "dense"))
+        assert ro.slice_obs == (mode != "dense")
+        ro.start()
+        if mode == "slices_run":
+            ro.run(7); ro.run(H - 7)     # a second call from t0 > 0 stores only newest slices from its first step on
+        else:
+            for _ in range(H):
+                ro.step()
+        ret, adv = ro.finish(ddof=0, group=False, bootstrap=True, deterministic=True)   # (the moments' sums in slot order)
+        learner = aq.PpoLearner(w, K_epochs=1, deterministic=True)   # (fp32 atomics otherwise: sums in launch order)
+        learner.update(ro, ret, adv)
+        grads = torch.cat([learner._state[(h, k)][0].flatten() for h in ("actor", "critic") for k in range(6)])
+        res[mode] = (ro.obs.clone(), ro.values.clone(), ret.clone(), adv.clone(), grads.clone(), ro.valid.clone())
+        if mode != "dense":
+            assert ro._obs_slices.shape == ((H + 4) * 15, n_envs) and not ro.obs.is_contiguous()
+    for mode in ("slices_step", "slices_run"):
+        for a, b, name in zip(res["dense"], res[mode], ("obs", "values", "returns", "advantages", "gradients", "valid")):
+            assert torch.equal(a, b), (mode, name, float((a.double() - b.double()).abs().max()))
+    # the small-batch kernel honours the same two fields: its windows are the slices it stored
+    obs = res["small_slices"][0]
+    assert torch.equal(obs[1:, :60], obs[:-1, 15:])
