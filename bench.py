@@ -654,8 +654,12 @@ def next_rows(dev, policy):
     samples = n * S
     fl = samples * 2 * (75 * 128 + 128 * 128 + 128 * 4 + 75 * 128 + 128 * 128 + 128) * 3   # forward + 2x backward, both heads
     out["ppo_update_epoch"] = {"samples": samples, "valid_samples": int(float(ro.valid[:S].sum())), "seconds": dt,
-                               "samples_per_s": samples / dt, "kernels": "k_mlp_bwd (fused loss), k_wgrad, k_adam; fp32 MFMA",
-                               "algorithmic_TFLOPs": fl / dt / 1e12, "frac_of_fp32_mfma_peak": fl / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "samples_per_s": samples / dt,
+                               "kernels": "k_mlp_bwd_v3 (fused loss; split-bf16 matrix cores), k_wgrad (dW2 split-bf16, dW1 / dW3 fp32 MFMA), k_adam",
+                               "algorithmic_TFLOPs": fl / dt / 1e12,
+                               "hbm_GB_per_epoch": 2 * 37.3, "hbm_GBps": 2 * 37.3e9 / dt / 1e9,
+                               "bound": "hbm (H1, H2, dZ2, dZ1 written by the backward kernel and read back by the weight-gradient "
+                                        "kernels: 37 GB per head; DESIGN.md 4d)",
                                "weights": policy_label(policy), "schedule": "inband"}
     return out
 
