@@ -761,21 +761,26 @@ def test_weights_of_another_window_are_refused(aq):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("inband", [False, True])
 @pytest.mark.parametrize("shards", [2, 3])
-def test_stream_sharded_rollout_is_the_single_batch_rollout(aq, shards):
+def test_stream_sharded_rollout_is_the_single_batch_rollout(aq, shards, inband):
     """StreamShardedRollout (the GPU's env range as S shards on S streams): every rollout buffer of the union equals the
     single-batch PolicyRollout bit for bit (trajectories, Philox streams and resets are keyed by the global env index),
-    returns too; the advantages are normalised with the moments of ALL shards (summed in another order: 1e-12)."""
+    returns too; the advantages are normalised with the moments of ALL shards (summed in another order: 1e-12).
+    inband: the in-band schedule with the observations stored as slices (the configuration bench.py's config 5 runs; the
+    second horizon starts from slot 0 again and must store its whole first window)."""
     import torch
     N, H = 1000, 24
+    kw = dict(inband=True, key_by_episode=True) if inband else {}
     w = aq.ActorCriticWeights.random(128, 75, 4, device="cuda", seed=2); w.std = 0.3
 
     def make_env(lo, hi):
         return aq.BatchedQuad(hi - lo, 0.01, 40, training=True, direct_control=1, T=5, dtype=torch.float64, compute="lean")
-    one = aq.PolicyRollout(make_env(0, N), w, H, store_obs=True, auto_reset=True, seed=9, env_offset=100)
+    one = aq.PolicyRollout(make_env(0, N), w, H, store_obs=True, auto_reset=True, seed=9, env_offset=100, **kw)
     one.start()
-    sh = aq.StreamShardedRollout(make_env, N, w, H, shards=shards, seed=9, env_offset=100, store_obs=True, auto_reset=True)
+    sh = aq.StreamShardedRollout(make_env, N, w, H, shards=shards, seed=9, env_offset=100, store_obs=True, auto_reset=True, **kw)
     sh.start()
+    assert one.slice_obs == inband and all(r.slice_obs == inband for r in sh.ros)
     for rep in range(2):   # the second horizon starts with resets pending from the first
         one.t = 0; sh.t = 0
         for _ in range(H):
@@ -783,7 +788,7 @@ def test_stream_sharded_rollout_is_the_single_batch_rollout(aq, shards):
         ret1, adv1 = one.finish(ddof=0, group=False)
         outs = sh.finish(ddof=0, group=False)
         torch.cuda.synchronize()
-        for name in ("actions", "logprobs", "rewards", "masks", "obs", "values"):
+        for name in ("actions", "logprobs", "rewards", "masks", "obs", "values") + (("valid",) if inband else ()):
             got = torch.cat([getattr(r, name) for r in sh.ros], dim=-1)
             assert torch.equal(got, getattr(one, name)), (rep, name)
         assert torch.equal(torch.cat([o[0] for o in outs], dim=-1), ret1)
