@@ -1505,8 +1505,195 @@ __global__ __launch_bounds__(256) void k_dense_tail(const DenseArgs a) {
     }
 }
 
+// ---- k_dense_tail_v3: the H = 64 dense tail (rl_nn_model.py: 800 -> 64 -> 64 -> 3) on the bf16 matrix cores ---------------------
+// Three-way split operands (k_mlp_v3's arithmetic: six v_mfma_f32_32x32x16_bf16 of 32 cycles per 16 k and output tile instead of
+// eight v_mfma_f32_32x32x2_f32 of 64; pre-scaled hidden layers; layer 3 on the vector lanes).  W1 (K x 64: 200 KiB at K = 800) does
+// not fit the LDS in any form: it streams through in chunks of 64 k as READY fragments -- every thread of the 512 loads the eight
+// consecutive k of one (row, k-step, lane half) straight from the torch-layout rows (32 contiguous bytes), splits them and writes
+// the three bf16 terms where the MFMA reads them; double-buffered, one barrier per chunk, the next chunk's weights and the next
+// chunk's features in flight during the current chunk's 48 MFMAs.  One workgroup of eight waves per CU: a W1 chunk is staged
+// once for eight 32-sample tiles (the vector L1 passes ~12 B per clock and CU: the features are 100 KiB per tile, W1's share 25).
+// Needs K % 8 == 0 (aligned 32-byte fragment loads); other shapes keep k_dense_tail.
+namespace dt3 {
+constexpr int H = 64, NT = 2, KC = 64, KSC = KC / 16;             // k-steps of 16 per chunk
+constexpr int W1B = NT * KSC * 3 * 64;                            // uint4 per W1 chunk buffer (1 536 -> 24 KiB)
+constexpr int W2F = 2 * W1B;                                      // W2 fragments: [t][ti][jh][3][64] (1 536 uint4)
+constexpr int W3T = W2F + NT * NT * 2 * 3 * 64;                   // [64] float4 rows of W3
+constexpr int B1 = W3T + H, B2 = B1 + H / 4, B3 = B2 + H / 4, LDS_UINT4 = B3 + 1;
+}  // namespace dt3
+
+__global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
+    using namespace dt3;
+    constexpr int BLOCK = 512, WPB = 8;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    // ---- layer 2 / 3 weights and the biases, once per launch and workgroup
+    for (int c = threadIdx.x; c < NT * NT * 2 * 64; c += BLOCK) {   // W2: lane (col, half) holds W2[32 t + col][32 ti + acc_row(8 jh + i, half)]
+        const int ln = c & 63, jh = (c >> 6) & 1, ti = (c >> 7) % NT, t = (c >> 7) / NT;
+        const float* src = a.W2 + (size_t)(32 * t + (ln & 31)) * H + 32 * ti + 16 * jh + 4 * (ln >> 5);
+        const float w8[8] = {src[0] * TANH_PRESCALE, src[1] * TANH_PRESCALE, src[2] * TANH_PRESCALE, src[3] * TANH_PRESCALE,
+                             src[8] * TANH_PRESCALE, src[9] * TANH_PRESCALE, src[10] * TANH_PRESCALE, src[11] * TANH_PRESCALE};
+        bf16x8 sp[3];
+        split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lds4[W2F + (((t * NT + ti) * 2 + jh) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+    }
+    for (int h = threadIdx.x; h < H; h += BLOCK) {
+        float4 w;
+        w.x = a.W3[h]; w.y = a.n_out > 1 ? a.W3[(size_t)H + h] : 0.f; w.z = a.n_out > 2 ? a.W3[(size_t)2 * H + h] : 0.f;
+        w.w = a.n_out > 3 ? a.W3[(size_t)3 * H + h] : 0.f;
+        lds4[W3T + h] = __builtin_bit_cast(uint4, w);
+        reinterpret_cast<float*>(lds4 + B1)[h] = a.b1[h] * TANH_PRESCALE;
+        reinterpret_cast<float*>(lds4 + B2)[h] = a.b2[h] * TANH_PRESCALE;
+    }
+    if (threadIdx.x < 4) reinterpret_cast<float*>(lds4 + B3)[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    const float4* W3t = reinterpret_cast<const float4*>(lds4 + W3T);
+    const float* b1s = reinterpret_cast<const float*>(lds4 + B1);
+    const float* b2s = reinterpret_cast<const float*>(lds4 + B2);
+    const float* b3s = reinterpret_cast<const float*>(lds4 + B3);
+
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles_per_chunk = (a.N + 31) / 32;
+    const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
+    const int64_t rounds = (n_tiles + (int64_t)gridDim.x * WPB - 1) / ((int64_t)gridDim.x * WPB);
+    const uint32_t N32 = (uint32_t)a.N;
+    const int n_kc = (a.K + KC - 1) / KC;
+    // this thread's W1 fragment of a chunk: output row 32 wt + (wl & 31), k-step ws, lane half wl >> 5
+    const int wl = threadIdx.x & 63, ws = (threadIdx.x >> 6) & 3, wt = threadIdx.x >> 8;
+    const float* w1row = a.W1 + (size_t)(32 * wt + (wl & 31)) * a.K + 16 * ws + 8 * (wl >> 5);
+    for (int64_t r = 0; r < rounds; ++r) {
+        asm volatile("" ::: "memory");
+        const int64_t gtile = (r * gridDim.x + blockIdx.x) * WPB + wave;
+        const int64_t chunk = gtile < n_tiles ? gtile / tiles_per_chunk : 0;
+        const int64_t tile = gtile - chunk * tiles_per_chunk;
+        float* __restrict__ outc = a.out + chunk * (int64_t)a.n_out * a.N;
+        const int64_t e = tile * 32 + col;
+        const bool valid = gtile < n_tiles && e < a.N;
+        // the features of a tile: element (s, i) of a lane = row kc + 16 s + 8 half + i, raw buffer loads (the lane's offset
+        // carries the sample and the half's 8 rows; rows >= K fall out of the range check)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + chunk * (int64_t)a.K * a.N), 0,
+                                                                            (int)((uint32_t)a.K * N32 * 4u), 0x00020000);
+        const uint32_t voff = valid ? ((uint32_t)e + 8u * (uint32_t)half * N32) * 4u : 0x80000000u;
+        float xw[KSC][8];
+        auto request_x = [&](int kc) {
+#pragma unroll
+            for (int s = 0; s < KSC; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    xw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)(kc + 16 * s + i) * N32 * 4u, 0));
+        };
+        float4 wlo, whi;
+        auto request_w1 = [&](int kc) {   // (k beyond K: zeros -- K % 8 == 0, so a fragment is inside or outside as a whole)
+            const bool in = kc + 16 * ws + 8 * (wl >> 5) < a.K;
+            const float4* p4 = reinterpret_cast<const float4*>(w1row + (in ? kc : 0));
+            wlo = p4[0]; whi = p4[1];
+            if (!in) { wlo = make_float4(0.f, 0.f, 0.f, 0.f); whi = wlo; }
+        };
+        f32x16 acc1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
+        request_w1(0);
+        request_x(0);
+        for (int ic = 0; ic < n_kc; ++ic) {
+            const int kc = ic * KC;
+            {   // this thread's fragment of chunk ic -> its three bf16 terms in buffer ic & 1
+                const float w8[8] = {wlo.x * TANH_PRESCALE, wlo.y * TANH_PRESCALE, wlo.z * TANH_PRESCALE, wlo.w * TANH_PRESCALE,
+                                     whi.x * TANH_PRESCALE, whi.y * TANH_PRESCALE, whi.z * TANH_PRESCALE, whi.w * TANH_PRESCALE};
+                bf16x8 sp[3];
+                split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lds4[(ic & 1) * W1B + ((wt * KSC + ws) * 3 + k) * 64 + wl] = __builtin_bit_cast(uint4, sp[k]);
+            }
+            bf16x8 xsp[KSC][3];
+#pragma unroll
+            for (int s = 0; s < KSC; ++s) split3x8(xw[s], xsp[s][0], xsp[s][1], xsp[s][2]);
+            __syncthreads();   // chunk ic is staged (and every wave has left chunk ic - 1, whose buffer chunk ic + 1 will overwrite)
+            if (ic + 1 < n_kc) { request_w1(kc + KC); request_x(kc + KC); }
+            const uint4* frag = lds4 + (ic & 1) * W1B + lane;
+#pragma unroll
+            for (int s = 0; s < KSC; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const uint4* f = frag + ((t * KSC + s) * 3) * 64;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                                 al = __builtin_bit_cast(bf16x8, f[128]);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[s][1], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xsp[s][0], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[s][2], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[s][0], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[s][1], acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[s][0], acc1[t], 0, 0, 0);
+                }
+        }
+        __syncthreads();   // every wave has left the last chunk: the next round restages buffer 0
+        // ---- layer 2 on the matrix cores, layer 3 on the vector lanes (see k_mlp_v3)
+        bf16x8 bsp[NT][2][3];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[t][j] = fast_tanh_prescaled(acc1[t][j]);
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = acc1[t][8 * jh + i];
+                split3x8(v8, bsp[t][jh][0], bsp[t][jh][1], bsp[t][jh][2]);
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = b2s[32 * t + acc_row(j, half)];
+            const uint4* frag = lds4 + W2F + (size_t)t * NT * 2 * 3 * 64 + lane;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const uint4* f = frag + (ti * 2 + jh) * 3 * 64;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                                 al = __builtin_bit_cast(bf16x8, f[128]);
+                    const bf16x8 bh = bsp[ti][jh][0], bm = bsp[ti][jh][1], bl = bsp[ti][jh][2];
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh_prescaled(acc2[j]);
+            mlp3_layer3(W3t, t, half, acc2, o);
+        }
+        mlp3_layer3_finish(o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = o[k];
+            if (a.final_tanh) v = tanhf(v);
+            if (valid && half == 0 && k < a.n_out) outc[(int64_t)k * a.N + e] = v;
+        }
+    }
+}
+
 template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream) {
     constexpr int HP = H < 32 ? 32 : H;
+    if constexpr (H == 64) {   // QENV_DENSE_BF16=0 keeps the fp32-MFMA kernel (A/B runs)
+        static const int bf16 = getenv("QENV_DENSE_BF16") ? atoi(getenv("QENV_DENSE_BF16")) : 1;
+        const int64_t n_tiles3 = ((a.N + 31) / 32) * a.n_chunks;
+        if (bf16 && a.K % 8 == 0 && n_tiles3 >= 2048) {
+            const size_t lds3 = sizeof(uint4) * (size_t)dt3::LDS_UINT4;
+            hipError_t e3 = allow_dynamic_lds((const void*)k_dense_tail_v3, lds3);
+            if (e3 != hipSuccess) return fail_hip(e3, "hipFuncSetAttribute(k_dense_tail_v3)");
+            int64_t blocks3 = (n_tiles3 + 7) / 8;
+            if (blocks3 > 256) blocks3 = 256;
+            hipLaunchKernelGGL(k_dense_tail_v3, dim3((unsigned)blocks3), dim3(512), lds3, stream, a);
+            return check_launch("k_dense_tail_v3");
+        }
+    }
     const size_t lds = sizeof(float) * (64 * (HP + 1) + HP * HP + 32 * HP + 2 * HP + 32);
     hipError_t e = allow_dynamic_lds((const void*)k_dense_tail<H>, lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_dense_tail)");

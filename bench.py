@@ -631,10 +631,14 @@ def next_rows(dev, policy):
     y = torch.empty(n_out, N, device=dev)
     us = kernel_launch_us(lambda: aq.dense_tail(x, W, final_tanh=True, out=y), 1, "fused", reps=4)
     flops = 2.0 * N * (K * H + H * H + H * n_out)
-    out["dense_tail_800_64_64_3"] = {"samples": N, "kernel": "k_dense_tail<64>", "kernel_us": us, "samples_per_s": N / us * 1e6,
-                                     "bound": "mfma (fp32 32x32x2)", "algorithmic_TFLOPs": flops / us / 1e6,
-                                     "frac_of_fp32_mfma_peak": flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                                     "hbm_GBps": (K + n_out) * 4 * N / us / 1e3, "data": "synthetic U(-1,1) features"}
+    mfma3 = (K // 16 + (1 if K % 16 else 0) + 4) * 2 * 6     # split-bf16 32x32x16 MFMAs per 32-sample tile: layers 1 and 2, two output tiles
+    out["dense_tail_800_64_64_3"] = {"samples": N, "kernel": "k_dense_tail_v3 (split-bf16 matrix cores, fp32-accurate; W1 streamed as fragments)",
+                                     "kernel_us": us, "samples_per_s": N / us * 1e6,
+                                     "bound": "vector-L1 fill (features 100 KiB + W1 share 25 KiB per 32-sample tile at ~12 B/clk/CU) / hbm",
+                                     "algorithmic_TFLOPs": flops / us / 1e6,
+                                     "mfma_pipe_busy_at_nominal_clock": mfma3 * 32 * (N / 32) / 1024 / (us * 1e-6 * MAX_CLOCK_GHZ * 1e9),
+                                     "hbm_GBps": (K + n_out) * 4 * N / us / 1e3, "hbm_frac": (K + n_out) * 4 * N / us / 1e3 / HBM_PEAK_GBPS,
+                                     "data": "synthetic U(-1,1) features"}
     del x, y
     n, S = 65536, 128
     w = load_policy(policy, dev)

@@ -207,7 +207,10 @@ def test_dense_tail_rl_nn_model_shape(aq, oracle):
     """rl_nn_model.py dense tail 800 -> 64 -> 64 -> 3 (tanh x3) and its critic twin (-> 1, no final tanh) on
     synthetic U(-1,1) features, against the fp64 oracle MLP; ragged N."""
     rng = np.random.RandomState(9)
-    for K, H, n_out, ft, N in ((800, 64, 3, True, 1000), (800, 64, 1, False, 37), (130, 32, 4, True, 4096), (75, 128, 4, True, 333)):
+    # (800, 64, ., ., 65 541): past the 2 048 sample tiles from which H = 64 runs k_dense_tail_v3 (split-bf16 matrix cores, W1 streamed
+    # as ready fragments), ragged last tile; (72, 64, ...): a K that is not a multiple of the 64-k chunk
+    for K, H, n_out, ft, N in ((800, 64, 3, True, 1000), (800, 64, 1, False, 37), (130, 32, 4, True, 4096), (75, 128, 4, True, 333),
+                               (800, 64, 3, True, 65541), (72, 64, 1, False, 65600)):
         def lin(o, i):
             b = 1.0 / np.sqrt(i)
             return rng.uniform(-b, b, (o, i)), rng.uniform(-b, b, o)
