@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU box: k_step launch time with and without the tile loop (QENV_STEP_GRID_LANES / QENV_STEP_TILES) at three batch sizes, both
+# row types, then the step / rollout / in-band tests (tests/tools/time_step_one.py).
 set -e
 for n in 131072 262144 524288; do
   python tests/tools/time_step_one.py $n
