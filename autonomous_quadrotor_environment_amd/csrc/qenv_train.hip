@@ -509,7 +509,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
         layer3(NT - 1, h2[NT - 1]);
         // the next tile's observations are requested HERE: vector-memory operations retire in issue order, so a load waits for
         // every store issued before it -- behind the 256 row stores of the backward half it cost 3 ms of a 9.5 ms launch
-        // (ablation builds, tools/ab_bwd.sh); here only H1's 64 stores, issued a layer ago, are ahead of it.  Its 40 registers
+        // (ablation builds during development); here only H1's 64 stores, issued a layer ago, are ahead of it.  Its 40 registers
         // fit because the backward product below walks the k-steps outermost (dZ2 stays fp32 and is split one step at a time).
         if (!ONE_WAVE && tile + tile_stride < n_tiles) request_x(tile + tile_stride);
         // ---- output and its pre-activation gradient, in both lane halves
