@@ -22,10 +22,13 @@ def net(ws, final_tanh):
             lin.weight.copy_(W.double()); lin.bias.copy_(b.double())
     return m
 
+rng_wide = np.random.RandomState((int(sys.argv[1]) if len(sys.argv) > 1 else 0) + 7919)   # its own stream: the cases of a seed stay as recorded
 for case in range(n_cases):
     hidden = int(rng.choice([16, 32, 64, 128]))
     n = int(rng.randint(1, 7))
     N = int(rng.choice([1, 31, 32, 33, 63, 64, 65, 100, 257, 700, int(rng.randint(1, 1500))]))
+    if rng_wide.randint(8) == 0:   # one case in eight: past 1 024 sample tiles, where the N = 128 networks run k_mlp_bwd_v3 and the bf16 dW2
+        hidden, n, N = 128, int(rng_wide.randint(8, 14)), int(rng_wide.choice([4096, 4100, 5000, 6001, 4097]))
     std = float(rng.choice([0.1, 0.3])); eps_clip = float(rng.choice([0.1, 0.2])); c_value = float(rng.choice([0.5, 1.0]))
     det = bool(rng.randint(2))
     w = aq.ActorCriticWeights.random(hidden, 75, 4, seed=int(rng.randint(1 << 30)))
