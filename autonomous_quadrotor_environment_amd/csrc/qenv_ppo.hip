@@ -1250,6 +1250,252 @@ __global__ __launch_bounds__(256) void k_mlp_wide(const MlpArgs a) {
     }
 }
 
+// ---- k_mlp_wide_v3: the N = 256, T = 5 policy forward on the bf16 matrix cores -----------------------------------------------
+// k_mlp_v3's arithmetic (three-way split operands on v_mfma_f32_32x32x16_bf16, pre-scaled hidden layers, layer 3 on the vector
+// lanes) for the reference's 256-wide networks (solved/nn_old_solved_256_*.pth).  Neither weight matrix fits the LDS as
+// fragments (W1 120 KiB, W2 384 KiB), so BOTH layers stream through one double-buffered block of 48 KiB, one output tile of 32
+// rows at a time (sixteen blocks per tile round: eight of layer 1 with 5 k-steps, eight of layer 2 with 16): every thread
+// loads the eight consecutive k of up to four (row, k-step, lane half) fragments from the torch-layout rows, splits them and
+// writes the three bf16 terms where the MFMA reads them -- one barrier per block, the next block's rows in flight during the
+// current block's MFMAs (k_dense_tail_v3's scheme).  One wave per SIMD: a wave keeps all of H1 as bf16 terms (192 registers).
+// 1 008 MFMAs of 32 cycles per 32-env tile instead of 1 324 of 64.
+namespace wide3 {
+constexpr int H = 256, NT = 8, TW = 5, KW = 75, KS1 = 5, KS2 = 16;
+constexpr int BUF = KS2 * 3 * 64;                     // uint4 per weight block buffer (3 072 -> 48 KiB)
+constexpr int W3T = 2 * BUF;                          // [256] float4 rows of W3
+constexpr int B1 = W3T + H, B2 = B1 + H / 4, B3 = B2 + H / 4, ROWTAB = B3 + 1, LDS_UINT4 = ROWTAB + 20;
+}  // namespace wide3
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(256) void k_mlp_wide_v3(const MlpArgs a) {
+    using namespace wide3;
+    constexpr int BLOCK = 256, WPB = 4;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0;
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles_per_chunk = (a.N + 31) / 32;
+    const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
+    const int64_t rounds = (n_tiles + (int64_t)gridDim.x * WPB - 1) / ((int64_t)gridDim.x * WPB);
+    const uint32_t N32 = (uint32_t)a.N;
+    // ---- layer 3's rows, the biases, the ring's row offsets (see k_mlp_v3)
+    for (int h = threadIdx.x; h < H; h += BLOCK) {
+        float4 w;
+        w.x = a.W3[h]; w.y = a.n_out > 1 ? a.W3[(size_t)H + h] : 0.f; w.z = a.n_out > 2 ? a.W3[(size_t)2 * H + h] : 0.f;
+        w.w = a.n_out > 3 ? a.W3[(size_t)3 * H + h] : 0.f;
+        lds4[W3T + h] = __builtin_bit_cast(uint4, w);
+        reinterpret_cast<float*>(lds4 + B1)[h] = a.b1[h] * TANH_PRESCALE;
+        reinterpret_cast<float*>(lds4 + B2)[h] = a.b2[h] * TANH_PRESCALE;
+    }
+    if (threadIdx.x < 4) reinterpret_cast<float*>(lds4 + B3)[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    uint32_t* rowtab = reinterpret_cast<uint32_t*>(lds4 + ROWTAB);   // [half][40]
+    if (threadIdx.x < 80) {
+        const int hf = threadIdx.x / 40, slot = threadIdx.x % 40;
+        const int k = 16 * (slot >> 3) + 8 * hf + (slot & 7);
+        int sl = a.head + (k < KW ? k : 0) / 15;
+        if (sl >= TW) sl -= TW;
+        rowtab[threadIdx.x] = k < KW ? (uint32_t)(sl * 15 + k % 15) * N32 * 4u : 0x80000000u;
+    }
+    const float* b3s = reinterpret_cast<const float*>(lds4 + B3);
+    __syncthreads();
+    const uint4* rowq = reinterpret_cast<const uint4*>(rowtab) + 10 * half;
+
+    // ---- the weight blocks.  Block b < 8: output tile b of layer 1 (KS1 k-steps: 320 fragments); b >= 8: output tile b - 8 of
+    // layer 2 (KS2 k-steps: 1 024 fragments).  Fragment f of a block = (k-step f >> 6, lane f & 63); thread i takes f = i + 256 u.
+    float4 wq[2][4][2];   // the rows of the next two blocks: set b & 1
+    auto request_block = [&](int b, float4 (&wq)[4][2]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = (int)threadIdx.x + BLOCK * u, ln = f & 63, ks = f >> 6;
+            if (b < NT) {
+                const int k0 = 16 * ks + 8 * (ln >> 5);
+                const float* src = a.W1 + (size_t)(32 * b + (ln & 31)) * KW + k0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {   // (75-float rows: no 16-byte alignment)
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (ks < KS1 && k0 + 4 * q + i < KW) ? src[4 * q + i] : 0.f;
+                    wq[u][q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {   // lane (col, half) of k-step (ti, jh) holds W2[32 t + col][32 ti + acc_row(8 jh + i, half)]
+                const int ti = ks >> 1, jh = ks & 1;
+                const float* src = a.W2 + (size_t)(32 * (b - NT) + (ln & 31)) * H + 32 * ti + 16 * jh + 4 * (ln >> 5);
+                wq[u][0] = *reinterpret_cast<const float4*>(src);
+                wq[u][1] = *reinterpret_cast<const float4*>(src + 8);
+            }
+        }
+    };
+    auto put_block = [&](int b, const float4 (&wq)[4][2]) {
+        const int nf = b < NT ? KS1 * 64 : KS2 * 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = (int)threadIdx.x + BLOCK * u;
+            if (f < nf) {
+                const float w8[8] = {wq[u][0].x * TANH_PRESCALE, wq[u][0].y * TANH_PRESCALE, wq[u][0].z * TANH_PRESCALE, wq[u][0].w * TANH_PRESCALE,
+                                     wq[u][1].x * TANH_PRESCALE, wq[u][1].y * TANH_PRESCALE, wq[u][1].z * TANH_PRESCALE, wq[u][1].w * TANH_PRESCALE};
+                bf16x8 sp[3];
+                split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lds4[(b & 1) * BUF + ((f >> 6) * 3 + k) * 64 + (f & 63)] = __builtin_bit_cast(uint4, sp[k]);
+            }
+        }
+    };
+    for (int64_t r = 0; r < rounds; ++r) {
+        asm volatile("" ::: "memory");
+        const int64_t gtile = (r * gridDim.x + blockIdx.x) * WPB + wave;
+        const bool has = gtile < n_tiles;
+        const int64_t gt = has ? gtile : n_tiles - 1;
+        const int64_t chunk = a.n_chunks > 1 ? gt / tiles_per_chunk : 0;
+        const int64_t tile = gt - chunk * tiles_per_chunk;
+        const int64_t out_off = chunk * (int64_t)a.n_out * a.N;
+        const int64_t e = tile * 32 + col;
+        const bool valid = has && e < a.N && !(a.env_skip && a.env_skip[e < a.N ? e : 0]);
+        const uint32_t e32 = (uint32_t)(e < a.N ? e : a.N - 1);
+        request_block(0, wq[0]);
+        request_block(1, wq[1]);
+        // ---- the window (raw buffer loads through the row table, see k_mlp_v3) -> bf16 terms; the observation copy
+        float xw[KS1][8];
+        {
+            const uint32_t e4 = (has && e < a.N) ? (uint32_t)e * 4u : 0x80000000u;
+            const uint64_t base = (uint64_t)(a.win + chunk * (int64_t)KW * a.N);
+            const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            const uint32_t base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+            const uint64_t base_u = ((uint64_t)base_hi << 32) | (uint64_t)base_lo;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base_u, 0, (int)((uint32_t)KW * N32 * 4u), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const uint4 rq = rowq[q];
+                const uint32_t off[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    xw[(4 * q + c) >> 3][(4 * q + c) & 7] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off[c] + e4, 0, 0));
+            }
+        }
+        bf16x8 xsp[KS1][3];
+        {
+            float* __restrict__ obs_c = a.obs_store ? a.obs_store + chunk * (int64_t)KW * a.N : nullptr;
+#pragma unroll
+            for (int sk = 0; sk < KS1; ++sk) {
+                if (obs_c && valid) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t k = (uint32_t)(16 * sk + i) + 8u * (uint32_t)half;
+                        if (k < (uint32_t)KW) obs_c[k * N32 + e32] = xw[sk][i];
+                    }
+                }
+                split3x8(xw[sk], xsp[sk][0], xsp[sk][1], xsp[sk][2]);
+            }
+        }
+        bf16x8 bsp[NT][2][3];   // H1 as bf16 terms: layer 2's B operand
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
+        // lane parts of the LDS addresses indexed by an accumulator row (32 t + acc_row(j, half) = a literal + 4 half), opaque per round:
+        // as loop invariants every base + literal sum is hoisted out of the round loop and spilled (see k_mlp_bwd_v3)
+        int w3_base = W3T * 16 + 64 * half, b1_base = B1 * 16 + 16 * half, b2_base = B2 * 16 + 16 * half;
+        asm volatile("" : "+v"(w3_base), "+v"(b1_base), "+v"(b2_base));
+        const char* ldsb = reinterpret_cast<const char*>(lds4);
+        // Block pipeline: when a phase starts block b is staged in buffer b & 1 and the rows of blocks b + 1, b + 2 are in the two
+        // register sets (landed / in flight).  The phase issues block b's MFMAs with the split + LDS write of block b + 1 among
+        // them (buffer (b + 1) & 1 was last read in phase b - 1, which every wave left before the barrier that opened this phase),
+        // then requests block b + 2 into the set it has just emptied... no: into the set block b occupied (free since phase b - 1).
+        put_block(0, wq[0]);
+        __syncthreads();
+        request_block(2, wq[0]);
+        // ---- layer 1: eight blocks, output tile b -> tanh -> its bf16 terms
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const uint4* frag = lds4 + (b & 1) * BUF + lane;
+            f32x16 acc;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = *reinterpret_cast<const float*>(ldsb + (b1_base + 4 * (32 * b + acc_row(j, 0))));
+#pragma unroll
+            for (int sk = 0; sk < KS1; ++sk) {
+                const uint4* f = frag + sk * 3 * 64;
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                             al = __builtin_bit_cast(bf16x8, f[128]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xsp[sk][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xsp[sk][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[sk][0], acc, 0, 0, 0);
+            }
+            put_block(b + 1, wq[(b + 1) & 1]);          // (b + 1 <= 8: the first layer-2 block)
+            sgb_interleave<30, 6>();                    // the split among the chain's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            request_block(b + 3, wq[(b + 1) & 1]);      // the set just emptied: two phases until it is put
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fast_tanh_prescaled(acc[j]);
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = acc[8 * jh + i];
+                split3x8(v8, bsp[b][jh][0], bsp[b][jh][1], bsp[b][jh][2]);
+            }
+            __syncthreads();
+        }
+        // ---- layer 2 + layer 3: eight blocks, two per iteration of a loop that is not unrolled further (the register set of
+        // a block is a compile-time index)
+        auto l2_phase = [&](int t, auto set_c) {
+            constexpr int SET = decltype(set_c)::value;   // = (NT + t) & 1
+            const int b = NT + t;
+            const uint4* frag = lds4 + (b & 1) * BUF + lane;
+            f32x16 acc;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = *reinterpret_cast<const float*>(ldsb + (b2_base + 4 * (32 * t + acc_row(j, 0))));
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const uint4* f = frag + (ti * 2 + jh) * 3 * 64;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, f[0]), am = __builtin_bit_cast(bf16x8, f[64]),
+                                 al = __builtin_bit_cast(bf16x8, f[128]);
+                    const bf16x8 bh = bsp[ti][jh][0], bm = bsp[ti][jh][1], bl = bsp[ti][jh][2];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+            if (t + 1 < NT) put_block(b + 1, wq[SET ^ 1]);
+            sgb_interleave<96, 2>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 3 < NT) request_block(b + 3, wq[SET ^ 1]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float hv = fast_tanh_prescaled(acc[j]);
+                const float4 w = *reinterpret_cast<const float4*>(ldsb + (w3_base + 16 * (32 * t + acc_row(j, 0))));
+                o[0] = fmaf(w.x, hv, o[0]); o[1] = fmaf(w.y, hv, o[1]); o[2] = fmaf(w.z, hv, o[2]); o[3] = fmaf(w.w, hv, o[3]);
+            }
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int t = 0; t < NT; t += 2) {
+            l2_phase(t, std::integral_constant<int, 0>{});       // block 8 + t: even
+            l2_phase(t + 1, std::integral_constant<int, 1>{});
+        }
+        mlp3_layer3_finish(o);
+        float outv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = o[k];
+            if (a.final_tanh) v = tanhf(v);  // the 4 outputs keep the exact tanh
+            outv[k] = v;
+            if (valid && half == 0 && k < a.n_out && a.out) {
+                if (a.out_f64) ((double*)a.out)[out_off + (int64_t)k * a.N + e] = (double)v;
+                else ((float*)a.out)[out_off + (int64_t)k * a.N + e] = v;
+            }
+        }
+        if constexpr (SAMPLE) {
+            if (valid && half == 0) sample_store(a, e, outv);
+        }
+    }
+}
+
 template <int H, int TW, bool SAMPLE> static int launch_mlp_wide(const MlpArgs& a, int T, hipStream_t stream, bool& fits) {
     const int K1P = (15 * T + 1) & ~1;
     const size_t fixed = sizeof(float) * ((size_t)K1P * H + 4 * H + 2 * H + 32), blockb = sizeof(float) * 32 * (H + 1);
@@ -1367,6 +1613,18 @@ template <bool SAMPLE> static int launch_mlp_256(const MlpArgs& a, int T, hipStr
     if (a.obs_rows_from != 0 || (a.win_chunk_stride != 0 && a.win_chunk_stride != (int64_t)15 * T * a.N))
         return fail(QENV_ERR_ARG, "the slice layout of stored observations is implemented for hidden 64 / 128 with T = 5");
     static const int wide = getenv("QENV_MLP_WIDE") ? atoi(getenv("QENV_MLP_WIDE")) : 1;
+    // QENV_MLP_WIDE: 1 (default) = k_mlp_wide_v3 for T = 5 (split-bf16 matrix cores), at every batch size (one kernel: results do not
+    // depend on how a batch is sharded); 2 = round 2's fp32-MFMA wide kernel; 0 = the kernel that one replaced
+    if (wide == 1 && !a.list_idx && T == 5 && (int64_t)15 * 5 * a.N * 4 < ((int64_t)1 << 31)) {
+        const int64_t n_tiles = ((a.N + 31) / 32) * a.n_chunks;
+        int64_t blocks = (n_tiles + 3) / 4;
+        if (blocks > 256) blocks = 256;
+        const size_t lds = sizeof(uint4) * (size_t)wide3::LDS_UINT4;
+        hipError_t e = allow_dynamic_lds((const void*)k_mlp_wide_v3<SAMPLE>, lds);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_wide_v3)");
+        hipLaunchKernelGGL((k_mlp_wide_v3<SAMPLE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+        return check_launch("k_mlp_wide_v3");
+    }
     if (wide && !a.list_idx) {
         bool fits = false;
         const int rc = T == 5 ? launch_mlp_wide<256, 5, SAMPLE>(a, T, stream, fits) : launch_mlp_wide<256, 0, SAMPLE>(a, T, stream, fits);
