@@ -1,6 +1,7 @@
-"""GPU box: the N = 256 policy forward, LDS-staged wide kernel (default) against the kernel it replaced (QENV_MLP_WIDE=0).
-Each kernel runs in its own process (the switch is read once); the parent compares the outputs bit for bit and prints the
-launch times.  python tests/tools/ab_mlp_wide.py"""
+"""GPU box: the N = 256 policy forward: round 2's LDS-staged fp32-MFMA wide kernel (QENV_MLP_WIDE=2) against the kernel it
+replaced (QENV_MLP_WIDE=0), bit for bit, and the launch times of both next to round 3's split-bf16 kernel (the default, T = 5
+only; its own accuracy check against fp64 torch is tests/tools/fuzz_mlp.py).  Each kernel runs in its own process (the switch
+is read once).  python tests/tools/ab_mlp_wide.py"""
 import json, os, subprocess, sys, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -44,16 +45,16 @@ if __name__ == "__main__":
         child()
         sys.exit(0)
     runs = {}
-    for wide in ("1", "0"):
+    for wide in ("1", "2", "0"):
         env = dict(os.environ, QENV_MLP_WIDE=wide)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
         if p.returncode != 0:
             print(p.stdout[-2000:], p.stderr[-4000:]); sys.exit(1)
         runs[wide] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
     bad = 0
-    for k in runs["1"]:
-        w, o = runs["1"][k], runs["0"][k]
+    for k in runs["2"]:
+        w, o, v3 = runs["2"][k], runs["0"][k], runs["1"][k]
         same = w["sha"] == o["sha"] and w["finite"]
-        bad += not same
-        print(f"{k:12s} wide {w['us']:9.2f} us   old {o['us']:9.2f} us   bit-identical {same}")
+        bad += (not same) or (not v3["finite"])
+        print(f"{k:12s} default {v3['us']:9.2f} us   wide(fp32) {w['us']:9.2f} us   old {o['us']:9.2f} us   wide == old bit for bit: {same}")
     sys.exit(1 if bad else 0)
