@@ -25,6 +25,8 @@ p.add_argument("--digest", action="store_true", help="print a SHA-256 of the fin
 p.add_argument("--log", default="")
 p.add_argument("--handle", default="f32", choices=["f32", "lean", "f64"], help="env handle (lean = the parity-qualified one)")
 p.add_argument("--learn-std", action="store_true", help="train the action std too (model.py fixed_std=False)")
+p.add_argument("--inband", action="store_true", help="the in-band warm-up schedule (a restart's warm-up steps ride the next T steps; rows flagged "
+                                                      "invalid) with the observations stored as slices: a rollout step is policy + env step")
 a = p.parse_args()
 
 w = aq.ActorCriticWeights.random(a.hidden, 75, 4, seed=a.seed)
@@ -32,7 +34,7 @@ w.std = 0.1
 HKW = {"f32": dict(dtype=torch.float32), "lean": dict(dtype=torch.float64, compute="lean"), "f64": dict(dtype=torch.float64)}[a.handle]
 env = aq.BatchedQuad(a.envs, 0.01, 1000, training=True, direct_control=1, T=5, integrator=a.integrator, **HKW)
 env.robust_control = a.robust  # PolicyRollout then draws the episode parameters / gusts from Philox at every (re)start
-ro = aq.PolicyRollout(env, w, a.horizon, store_obs=True, auto_reset=True, seed=a.seed)
+ro = aq.PolicyRollout(env, w, a.horizon, store_obs=True, auto_reset=True, seed=a.seed, inband=a.inband)
 ro.keep_init = a.separate_reset
 learner = aq.PpoLearner(w, lr=a.lr, deterministic=a.deterministic, learn_std=a.learn_std)
 ro.start()
@@ -41,8 +43,11 @@ t0 = time.time()
 total_steps = 0
 for u in range(1, a.updates + 1):
     ro.t = 0
-    for _ in range(a.horizon):
-        ro.step()
+    if a.inband:
+        ro.run(a.horizon)   # the whole horizon as one library call
+    else:
+        for _ in range(a.horizon):
+            ro.step()
     ret, adv = ro.finish(ddof=0, group=False, bootstrap=True, deterministic=a.deterministic)  # horizon-truncated episodes bootstrap from the critic
     losses = learner.update(ro, ret, adv)
     total_steps += a.envs * a.horizon
