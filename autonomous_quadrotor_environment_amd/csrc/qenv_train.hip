@@ -431,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 acc1[t][j] = fast_tanh_prescaled(acc1[t][j]);
-                bstore(h1c, voff, row_soff(t, j), acc1[t][j]);
+                if (!ONE_WAVE) bstore(h1c, voff, row_soff(t, j), acc1[t][j]);   // (ONE_WAVE: two per k-step of layer 2, below)
             }
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
@@ -489,6 +489,56 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
             sgb_interleave_ds<30, 6, 1>();
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (ONE_WAVE) {
+            // Where H1's row stores go.  A CU's vector-memory path passes ~10-13 B per clock in either direction and its four waves
+            // share it: a wave that issues stores back to back spends ~105 cycles on each (256 bytes), whatever their width, cache
+            // policy or order (measured: the same rows as dwordx4 stores, nt / sc1, XCD-aware tile order -- no change), and with
+            // one wave per SIMD nothing else runs meanwhile; hipcc bunches the stores of a scheduling region whatever the
+            // sched_group_barrier pattern asks for.  So layer 2 is cut into one region per 16-k step (6 MFMAs): each carries two of the
+            // previous output tile's tanh + layer-3 rows and TWO H1 row stores -- a store every ~100 cycles, beside matrix work.
+            auto l2_kstep = [&](int t, f32x16& acc2, int r) {   // k-step r = (input tile r >> 1, half-tile r & 1) of output tile t
+                const int ti = r >> 1, s2 = r & 1;
+                if (r == 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc2[j] = *reinterpret_cast<const float*>(ldsb + (b2_base + 4 * (32 * t + acc_row(j, 0))));
+                }
+                const char* f = ldsb + (fw_a + 16 * ((2 * (2 * ti + s2)) ^ fw_x) + W2D_ROW * 32 * t);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f)),
+                             am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f + W2D_TERM)),
+                             al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f + 2 * W2D_TERM));
+                six(acc2, ah, am, al, bsp[ti][s2][0], bsp[ti][s2][1], bsp[ti][s2][2]);
+            };
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    l2_kstep(t, h2[t], r);
+                    if (t == 0) {   // beside output tile 0: tanh + split of layer 1's last tile (its terms are needed from k-step 6 on)
+                        if (r < 4) {
+#pragma unroll
+                            for (int j = 4 * r; j < 4 * r + 4; ++j) acc1[NT - 1][j] = fast_tanh_prescaled(acc1[NT - 1][j]);
+                        }
+                        if (r == 2 || r == 4) {
+                            const int jh = r == 2 ? 0 : 1;
+                            float v8[8];
+#pragma unroll
+                            for (int i2 = 0; i2 < 8; ++i2) v8[i2] = acc1[NT - 1][8 * jh + i2];
+                            split3x8(v8, bsp[NT - 1][jh][0], bsp[NT - 1][jh][1], bsp[NT - 1][jh][2]);
+                        }
+                    } else {        // beside output tile t: tanh + layer 3 of rows 2 r, 2 r + 1 of tile t - 1
+#pragma unroll
+                        for (int j = 2 * r; j < 2 * r + 2; ++j) {
+                            h2[t - 1][j] = fast_tanh_prescaled(h2[t - 1][j]);
+                            const float4 w = w3_row(t - 1, j);
+                            o[0] = fmaf(w.x, h2[t - 1][j], o[0]); o[1] = fmaf(w.y, h2[t - 1][j], o[1]);
+                            o[2] = fmaf(w.z, h2[t - 1][j], o[2]); o[3] = fmaf(w.w, h2[t - 1][j], o[3]);
+                        }
+                    }
+                    bstore(h1c, voff, row_soff(t, 2 * r), acc1[t][2 * r]);
+                    bstore(h1c, voff, row_soff(t, 2 * r + 1), acc1[t][2 * r + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
         l2_chain(0, h2[0], 0, NT - 1);
         l1_finish(NT - 1);
         sgb_interleave_ds<36, 5, 1>();
@@ -503,6 +553,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
             layer3(t - 1, h2[t - 1]);
             sgb_interleave_ds<48, 3, 1>();
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) h2[NT - 1][j] = fast_tanh_prescaled(h2[NT - 1][j]);
