@@ -652,6 +652,11 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2 * NT; ++ks) {
             const int to = ks >> 1, sj = ks & 1;
+            // one scheduling region per output tile (6 MFMAs): the first computes step ks + 1's eight dZ2 values beside its MFMAs,
+            // the other three carry that step's 16 row stores (H2, dZ2) a few at a time -- bunched behind the 24 MFMAs they block
+            // the wave for ~1.7 k cycles with nothing in the matrix pipe (see layer 2 above)
+            const int ksn = ks + 1, ton = ksn >> 1, sjn = ksn & 1;
+            float v8n[8], hvn[8];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int tb0 = tr_a + 64 * (t ^ tr_q) + 32 * tr_g, tb1 = tr_a + 64 * (t ^ tr_q) + 32 * (tr_g ^ 1) + W2D_ROW * 8;
@@ -666,9 +671,32 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
                     af[m] = __builtin_bit_cast(bf16x8, f8);
                 }
                 six(dd[t], af[0], af[1], af[2], bt[ks & 1][0], bt[ks & 1][1], bt[ks & 1][2]);
+                if (ONE_WAVE && ksn < 2 * NT) {
+                    if (t == 0) {
+#pragma unroll
+                        for (int i2 = 0; i2 < 8; ++i2) {
+                            const int j2 = 8 * sjn + i2;
+                            const float4 w = *reinterpret_cast<const float4*>(ldsb + (w3_base2 + 16 * (32 * ton + acc_row(j2, 0))));
+                            const float g = fmaf(w.w, dz3[3], fmaf(w.z, dz3[2], fmaf(w.y, dz3[1], w.x * dz3[0])));
+                            hvn[i2] = h2[ton][j2];
+                            v8n[i2] = g * (1.f - hvn[i2] * hvn[i2]);
+                        }
+                    } else {
+                        const int lo = t == 1 ? 0 : (t == 2 ? 3 : 6), hi = t == 1 ? 3 : (t == 2 ? 6 : 8);
+#pragma unroll
+                        for (int i2 = lo; i2 < hi; ++i2) {
+                            bstore(h2c, voff, row_soff(ton, 8 * sjn + i2), hvn[i2]);
+                            bstore(dz2c, voff, row_soff(ton, 8 * sjn + i2), v8n[i2]);
+                        }
+                        if (t == NT - 1) split3x8(v8n, bt[ksn & 1][0], bt[ksn & 1][1], bt[ksn & 1][2]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if (ks + 1 < 2 * NT) dz2_step(ks + 1);
-            sgb_interleave_ds<24, 5, 2>();
+            if (!ONE_WAVE) {
+                if (ks + 1 < 2 * NT) dz2_step(ks + 1);
+                sgb_interleave_ds<24, 5, 2>();
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // H1 as this wave stored it (read at L2: glc), a tile ahead of the tile being finished
