@@ -619,10 +619,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_bwd_v3(const BwdArgs a) {
         // of live values across the loss block); dH1 = W2^T dZ2 on the matrix cores, the A fragments by transposing reads of
         // the same W2 image.  The 16-k steps are the OUTER loop: step ks feeds the eight dZ2 values of rows 32 to + 16 s + ...
         // to the four output tiles' accumulators (four independent chains), and the vector work of step ks + 1 -- its eight
-        // dZ2 values, the H2 / dZ2 row stores, the split into bf16 terms -- sits beside those 24 MFMAs: the 128 row stores
-        // leave the wave spread over the walk instead of as one burst in front of it (a wave alone on its SIMD stalls on a full
-        // store queue; ablation: the stores were 2.9 of this kernel's 6.4 ms).  dZ1 = dH1 (1 - H1^2) / (2 log2 e): the
-        // image holds the pre-scaled W2.
+        // dZ2 values, the H2 / dZ2 row stores, the split into bf16 terms -- sits beside those 24 MFMAs, the stores a few per
+        // output tile (ONE_WAVE: see the regions below).  dZ1 = dH1 (1 - H1^2) / (2 log2 e): the image holds the pre-scaled W2.
         int w3_base2 = w3_base;
         asm volatile("" : "+v"(w3_base2));
         bf16x8 bt[2][3];   // the B operand of step ks: bt[ks & 1]
