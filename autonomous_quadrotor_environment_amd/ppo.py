@@ -546,6 +546,7 @@ class PolicyRollout:
         else:
             self.obs = torch.zeros(H, 15 * env.T, N, device=dev, dtype=torch.float32) if store_obs else None
         self.mean = torch.zeros(4, N, device=dev, dtype=dt)
+        self.store_mean = False   # True: the fused rollout step also writes the policy mean of its last step here (4 more row stores)
         self.done = torch.zeros(N, device=dev, dtype=torch.uint8)
         self.init = torch.zeros(13, N, device=dev, dtype=dt)
         self.t = 0
@@ -577,7 +578,8 @@ class PolicyRollout:
             raise ValueError("inband=True needs the fused step (stochastic policy, stored observations or no critic, no "
                              "robust_control, keep_init off)")
         if fused:
-            env.ppo_step(w, self.seed, self.global_step + 1, self.env_offset, self.actions[t], self.logprobs[t], self.mean,
+            env.ppo_step(w, self.seed, self.global_step + 1, self.env_offset, self.actions[t], self.logprobs[t],
+                         self.mean if self.store_mean else None,
                          store, self.rewards[t], self.done, self.masks[t], noise=noise,
                          valid=None if self.valid is None else self.valid[t], inband=self.inband,
                          key_by_episode=self.key_by_episode,
@@ -638,7 +640,7 @@ class PolicyRollout:
         W = w.head("actor")
         a = L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[x.data_ptr() for x in W], float(w.std),
                           None if nz is None else nz.data_ptr(), int(self.seed), int(self.global_step + 1), int(self.env_offset),
-                          self.mean.data_ptr(), self.actions[t0].data_ptr(), self.logprobs[t0].data_ptr(),
+                          self.mean.data_ptr() if self.store_mean else None, self.actions[t0].data_ptr(), self.logprobs[t0].data_ptr(),
                           None if self.obs is None else self.obs[t0].data_ptr(), self.rewards[t0].data_ptr(), self.done.data_ptr(),
                           self.masks[t0].data_ptr(), None if self.valid is None else self.valid[t0].data_ptr(), int(self.inband),
                           int(self.key_by_episode), 15 * (env.T - 1) if (self.slice_obs and t0 > 0) else 0, int(self.slice_obs))
@@ -739,7 +741,8 @@ class StreamShardedRollout:
             per_t = []
             for t in range(ro.horizon):
                 per_t.append(L.PpoStepArgs(int(W[0].shape[1]), int(W[0].shape[0]), *[x.data_ptr() for x in W], float(w.std), None,
-                                           int(ro.seed), 0, int(ro.env_offset), ro.mean.data_ptr(), ro.actions[t].data_ptr(),
+                                           int(ro.seed), 0, int(ro.env_offset), ro.mean.data_ptr() if ro.store_mean else None,
+                                           ro.actions[t].data_ptr(),
                                            ro.logprobs[t].data_ptr(), None if ro.obs is None else ro.obs[t].data_ptr(),
                                            ro.rewards[t].data_ptr(), ro.done.data_ptr(), ro.masks[t].data_ptr(),
                                            None if ro.valid is None else ro.valid[t].data_ptr(), int(ro.inband),
