@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 6
+QENV_ABI_VERSION = 7
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -92,6 +92,7 @@ SYMBOLS = {
     "qenv_ppo_step": (_i, [_vp, _vp]),
     "qenv_ppo_flush": (_i, [_vp]),
     "qenv_ppo_rollout": (_i, [_vp, _vp, _i]),
+    "qenv_policy_rollout": (_i, [_vp, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _vp, _vp]),
     "qenv_outer_velpid": (_i, [_vp, _vp, C.c_int32]),
     "qenv_outer_pospi": (_i, [_vp, _vp, C.c_double, C.c_double, C.c_double]),
     "qenv_outer_reset": (_i, [_vp, _vp]),

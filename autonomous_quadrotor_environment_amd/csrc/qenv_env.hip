@@ -228,6 +228,20 @@ static int ar_warmup(qenv_s* q, int parity) {
     return rc;
 }
 
+// k_ppo_fused (policy + env step of a whole rollout in one launch, qenv_env_impl.hpp) covers the reference's controller
+// (75-128-128-4, T = 5) on the scipy-exact integrator, without the per-env extras the separate calls support.
+// QENV_PPO_FUSED=0 keeps the two launches per step (A/B runs, and what the fused launch is tested against).
+static bool ppo_fused_ok(const qenv_s* q, int k_in, int hidden) {
+    static const int on = getenv("QENV_PPO_FUSED") ? atoi(getenv("QENV_PPO_FUSED")) : 1;
+    return on && hidden == 128 && k_in == 75 && q->cfg.T == 5 && q->cfg.integrator == QENV_RK45 && q->cfg.direct_control && !q->robust &&
+           !q->sens.ws && q->outer.kind == QENV_OUTER_NONE && (int64_t)300 * q->N <= ((int64_t)1 << 30);
+}
+static const void* fused_image(const qenv_s* q, const float* W1) {
+    for (int h = 0; h < 2; ++h)
+        if (q->prep[h].image && q->prep[h].W1 == W1 && q->prep[h].n_out == 4) return q->prep[h].image;
+    return nullptr;
+}
+
 int qenv::ppo_flush(qenv_s* q) {
     if (!q->ar_pending) return QENV_OK;
     q->ar_pending = 0;
@@ -357,6 +371,14 @@ int qenv_mix(qenv_t q, int64_t n, const void* action, void* out_w, void* out_fm,
 int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args* first, int n_steps) {
     if (!q || !first) return fail(QENV_ERR_ARG, "qenv_ppo_rollout: null argument");
     if (n_steps < 0) return fail(QENV_ERR_ARG, "qenv_ppo_rollout: negative n_steps");
+    if (n_steps > 0 && first->inband && first->W1 && first->out_action && ppo_fused_ok(q, first->k_in, first->hidden)) {
+        // the whole horizon as ONE launch (k_ppo_fused): the argument checks of qenv_ppo_step / qenv_policy_act, then the launch
+        if (!(first->std > 0)) return fail(QENV_ERR_ARG, "qenv_policy_act: std must be positive");
+        if (first->obs_rows_from < 0 || first->obs_rows_from >= 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_ppo_step: obs_rows_from must be in [0, 15*T)");
+        if (!first->b1 || !first->W2 || !first->b2 || !first->W3 || !first->b3) return fail(QENV_ERR_ARG, "qenv_policy_act: null argument");
+        if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+        return QENV_DISPATCH(q, do_ppo_fused, q, first, n_steps, 0, fused_image(q, first->W1));
+    }
     const size_t esz = q->cfg.dtype == QENV_F64 ? 8 : 4;
     const size_t N = (size_t)q->N;
     auto adv = [&](const void* p, size_t bytes_per_step, int t) -> void* {
@@ -378,6 +400,33 @@ int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args* first, int n_steps) {
         a.out_mask = adv(first->out_mask, N * esz, t);
         a.out_valid = adv(first->out_valid, N * esz, t);
         const int rc = qenv_ppo_step(q, &a);
+        if (rc != QENV_OK) return rc;
+    }
+    return QENV_OK;
+}
+
+int qenv_policy_rollout(qenv_t q, int k_in, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
+                        const float* W3, const float* b3, int n_steps, void* out_actions, void* out_reward, uint8_t* out_done,
+                        void* out_mask) {
+    if (!q || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out_actions) return fail(QENV_ERR_ARG, "qenv_policy_rollout: null argument");
+    if (n_steps < 0) return fail(QENV_ERR_ARG, "qenv_policy_rollout: negative n_steps");
+    if (k_in != 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_policy_rollout: k_in (row length of W1) must be 15*T of the handle");
+    if (!q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_policy_rollout: the policy commands the four rotors (direct_control=1)");
+    if (n_steps == 0) return QENV_OK;
+    if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+    const size_t esz = q->cfg.dtype == QENV_F64 ? 8 : 4, N = (size_t)q->N;
+    if (ppo_fused_ok(q, k_in, hidden)) {
+        qenv_ppo_step_args a{};
+        a.k_in = k_in; a.hidden = hidden; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+        a.out_action = out_actions; a.out_reward = out_reward; a.out_done = out_done; a.out_mask = out_mask;
+        return QENV_DISPATCH(q, do_ppo_fused, q, &a, n_steps, 1, fused_image(q, W1));
+    }
+    for (int t = 0; t < n_steps; ++t) {   // the same as separate calls
+        void* act = (char*)out_actions + 4 * N * esz * (size_t)t;
+        int rc = qenv_mlp_forward(q, k_in, hidden, 4, 1, W1, b1, W2, b2, W3, b3, act, nullptr);
+        if (rc == QENV_OK)
+            rc = qenv_step(q, act, nullptr, out_reward ? (char*)out_reward + N * esz * (size_t)t : nullptr, out_done,
+                           out_mask ? (char*)out_mask + N * esz * (size_t)t : nullptr, QENV_STEP_NO_AUX | QENV_STEP_PUSH_WINDOW);
         if (rc != QENV_OK) return rc;
     }
     return QENV_OK;

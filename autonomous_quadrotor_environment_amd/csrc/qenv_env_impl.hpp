@@ -9,6 +9,7 @@
 #pragma once
 #include "qenv_host.hpp"
 #include "qenv_sensor.hpp"
+#include "qenv_mlp3.hpp"
 #include <type_traits>
 
 namespace qenv {
@@ -441,6 +442,177 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
             if (!more) break;
             cur = nxt;
             g = gn;
+        }
+    }
+}
+
+// ---- the policy and the env step of a whole rollout in ONE launch --------------------------------------------------------
+// n_steps x (policy forward [+ sampling], env step) for the reference's N = 128, T = 5 controller (ppo.py:239-262; the evaluation
+// loop ppo_quad_eval.py:44-62 without sampling).  As two launches per step (k_mlp_v3, k_step) a rollout step of 65 536 envs is
+// mostly fixed cost: every launch of the forward stages 159 KiB of weights per workgroup (13 k of its ~40 k cycles), every
+// launch of the step kernel starts with a load round trip that one wave per SIMD cannot hide, and both pay launch + drain.
+// Here a wave OWNS its 64-env blocks for the whole rollout: per step and block it runs mlp3_tile_forward on the block's two
+// 32-env tiles and then step_one on the 64 envs -- the same device functions on the same buffers in the same order as the two
+// kernels, so every buffer is bit-identical to the stepwise path (tests) -- and the weights are staged once per launch.
+// Nothing crosses waves (an env's window, action and state are touched by its own wave only): no grid-wide synchronisation,
+// only the wave's own memory ordering between the phases: its stores of one phase are the loads of the next, on the same CU --
+// a WORKGROUP-scope fence (a wait for the stores; the CU's vector L1 is coherent with the CU's own writes).  An agent-scope
+// fence writes back / invalidates the XCD's L2 every time (measured: the window loads that follow took 25 k cycles).
+// The ring offsets: k_mlp_v3's table holds the 80 row offsets of ONE ring head; here the head moves inside the launch, so the
+// table is that of head 0 and a load adds head * 15 rows and wraps (v_add, v_sub, v_min_u32: an offset beyond the ring comes
+// back as the smaller of (off, off - ring bytes), whichever did not wrap through 2^32).
+// Diagnostic build only (-DQENV_FUSED_STAMPS, tests/tools/fused_stamps.py): s_memtime stamps of a wave's phases in its last step.
+#if defined(QENV_FUSED_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
+__device__ unsigned long long g_fused_stamps[1024 * 16];
+#define FUSED_STAMP(slot)                                                                                      \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 1024)                             \
+            g_fused_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = t_;                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#else
+#define FUSED_STAMP(slot) do { } while (0)
+#endif
+
+template <typename T, typename S> struct FusedArgs {
+    StepArgs<T, S> st;   // the step kernel's arguments of step 0
+    MlpArgs ml;          // the policy forward's arguments of step 0
+    int32_t n_steps;
+    int32_t obs_slices;  // stored observations as slices: step t > 0 stores its newest slice only (see qenv.h)
+    // bytes by which the per-step arrays advance from one step to the next (0: the array is scratch / not per step)
+    int64_t adv_act, adv_logp, adv_noise, adv_obs, adv_row;
+};
+
+template <typename T, typename S, int INTEG, bool LEAN, bool SAMPLE>
+__global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
+    using namespace mlp3;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int64_t N = fa.ml.N;
+    const uint32_t N32 = (uint32_t)N;
+    // ---- the weights, once per launch
+    if (fa.ml.image) {
+        for (int base = threadIdx.x; base < IMAGE_UINT4; base += 8 * 256) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = base + u * 256; v[u] = fa.ml.image[i < IMAGE_UINT4 ? i : IMAGE_UINT4 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (base + u * 256 < IMAGE_UINT4) lds4[base + u * 256] = v[u];
+        }
+    } else {
+        mlp3_build_image(lds4, fa.ml.W1, fa.ml.b1, fa.ml.W2, fa.ml.b2, fa.ml.W3, fa.ml.b3, fa.ml.n_out, (int)threadIdx.x, 256);
+    }
+    uint32_t* rowtab = reinterpret_cast<uint32_t*>(lds4 + IMAGE_UINT4);   // [half][40]: byte offset of window element k at ring head 0
+    if (threadIdx.x < 80) {
+        const int hf = threadIdx.x / 40, slot = threadIdx.x % 40;
+        const int k = 16 * (slot >> 3) + 8 * hf + (slot & 7);
+        rowtab[threadIdx.x] = k < KW ? (uint32_t)k * N32 * 4u : 0x80000000u;
+    }
+    __syncthreads();
+    const uint4* rowq = reinterpret_cast<const uint4*>(rowtab) + 10 * half;
+    const uint32_t ring_bytes = (uint32_t)KW * N32 * 4u;
+    const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc((void*)fa.ml.win, 0, (int)ring_bytes, 0x00020000);
+    const int64_t n_blocks = (N + 63) / 64;
+    const int64_t wave_stride = (int64_t)gridDim.x * 4;
+#pragma unroll 1
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blocks; blk += wave_stride) {
+#pragma unroll 1
+        for (int t = 0; t < fa.n_steps; ++t) {
+            asm volatile("" ::: "memory");   // (the weights and the table in LDS are loop-invariant: nothing of them is to be hoisted)
+            const int head = (fa.ml.head + t) % TW;   // wave-uniform
+            // ---- this step's view of the per-step arrays
+            MlpArgs m = fa.ml;
+            m.step = fa.ml.step + (uint64_t)t;
+            if (m.noise) m.noise = (const char*)fa.ml.noise + fa.adv_noise * t;
+            if (SAMPLE) {
+                m.out_action = (char*)fa.ml.out_action + fa.adv_act * t;
+                if (m.out_logprob) m.out_logprob = (char*)fa.ml.out_logprob + fa.adv_logp * t;
+            } else {
+                m.out = (char*)fa.ml.out + fa.adv_act * t;
+            }
+            if (m.obs_store) m.obs_store = (float*)((char*)fa.ml.obs_store + fa.adv_obs * t);
+            if (fa.obs_slices && t > 0) m.obs_rows_from = 15 * (TW - 1);
+            // ---- the policy on the block's two 32-env tiles
+            FUSED_STAMP(0);
+#pragma unroll 1
+            for (int tl = 0; tl < 2; ++tl) {
+                const int64_t e = blk * 64 + 32 * tl + col;
+                if (blk * 64 + 32 * tl >= N) break;   // (wave-uniform: a ragged last block has one tile)
+                const bool valid = e < N;
+                const uint32_t e32 = (uint32_t)(valid ? e : N - 1);
+                float xw[KS16][8];
+                {
+                    const uint32_t hb = (uint32_t)head * 15u * N32 * 4u + (valid ? (uint32_t)e * 4u : 0x80000000u);
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) {
+                        const uint4 r = rowq[q];
+                        const uint32_t t0[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t off = t0[c] + hb, offw = off - ring_bytes;
+                            xw[(4 * q + c) >> 3][(4 * q + c) & 7] =
+                                __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ring, off < offw ? off : offw, 0, 0));
+                        }
+                    }
+                }
+                bf16x8 xsp[KS16][3];
+                {
+                    uint32_t n32 = N32;
+                    uint32_t kh = 8u * (uint32_t)half;
+                    asm volatile("" : "+s"(n32), "+v"(kh));
+                    float* __restrict__ obs_c = m.obs_store;
+#pragma unroll
+                    for (int sk = 0; sk < KS16; ++sk) {
+                        if (obs_c && valid) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const uint32_t k = (uint32_t)(16 * sk + i) + kh;
+                                if (k < (uint32_t)KW && k >= (uint32_t)m.obs_rows_from) obs_c[k * n32 + e32] = xw[sk][i];
+                            }
+                        }
+                        split3x8(xw[sk], xsp[sk][0], xsp[sk][1], xsp[sk][2]);
+                    }
+                }
+                FUSED_STAMP(1 + 3 * tl);
+                float o[4];
+                mlp3_tile_forward(lds4, lane, half, xsp, o);
+                FUSED_STAMP(2 + 3 * tl);
+                float outv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = o[k];
+                    if (m.final_tanh) v = tanhf(v);
+                    outv[k] = v;
+                    if (valid && half == 0 && k < m.n_out && m.out) {
+                        if (m.out_f64) ((double*)m.out)[(int64_t)k * N + e] = (double)v;
+                        else ((float*)m.out)[(int64_t)k * N + e] = v;
+                    }
+                }
+                if constexpr (SAMPLE) {
+                    if (valid && half == 0) sample_store(m, e, outv);
+                }
+                FUSED_STAMP(3 + 3 * tl);
+            }
+            // ---- the env step of the block's 64 envs on the actions just written
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            FUSED_STAMP(7);
+            {
+                StepArgs<T, S> s = fa.st;
+                s.actions = (const S*)(SAMPLE ? m.out_action : m.out);
+                if (s.out_reward) s.out_reward = (S*)((char*)fa.st.out_reward + fa.adv_row * t);
+                if (s.out_mask) s.out_mask = (S*)((char*)fa.st.out_mask + fa.adv_row * t);
+                if (s.out_valid) s.out_valid = (S*)((char*)fa.st.out_valid + fa.adv_row * t);
+                s.win_slot = head;
+                s.ar_episode = fa.st.ar_episode + (uint64_t)t;
+                StepIn<T, S> in;
+                step_load(s, blk * 64 + lane, in);
+                if (in.active) step_one<T, S, INTEG, false, LEAN>(s, in);
+            }
+            FUSED_STAMP(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            FUSED_STAMP(9);
         }
     }
 }
@@ -1092,10 +1264,11 @@ struct StepExtra {
     int32_t ar_key_episode; void* out_valid;
 };
 
-template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
-                                                     void* out_reward, uint8_t* out_done, void* out_mask, int flags_in,
-                                                     int win_slot, const StepExtra* ex = nullptr) {
-    const int flags = flags_in & QENV_STEP_MODE_MASK;
+// the step kernel's argument block for one qenv_step-like call (and the host-side bookkeeping that goes with it: the sensor's
+// call counter, the prev_ang flag)
+template <typename T, typename S> StepArgs<T, S> make_step_args(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
+                                                                 void* out_reward, uint8_t* out_done, void* out_mask, int flags,
+                                                                 int win_slot, const StepExtra* ex) {
     StepArgs<T, S> a;
     a.cfg = make_cfg<T>(q);
     a.ws = (S*)q->ws; a.wsi = q->wsi; a.N = q->N;
@@ -1138,8 +1311,16 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
     // touching the angle rows; an unmasked full step re-synchronises all of them
     if (flags == QENV_STEP_DYNAMICS_ONLY) q->ang_ok = 0;
     else if (!mask) q->ang_ok = 1;
-    const dim3 g = env_grid(q->N), b(env_block());
     a.gust = q->gust;
+    return a;
+}
+
+template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, const void* actions, const uint8_t* mask, void* out_obs,
+                                                     void* out_reward, uint8_t* out_done, void* out_mask, int flags_in,
+                                                     int win_slot, const StepExtra* ex = nullptr) {
+    const int flags = flags_in & QENV_STEP_MODE_MASK;
+    const StepArgs<T, S> a = make_step_args<T, S>(q, actions, mask, out_obs, out_reward, out_done, out_mask, flags, win_slot, ex);
+    const dim3 g = env_grid(q->N), b(env_block());
     if (q->robust) {
         if (flags == QENV_STEP_DYNAMICS_ONLY)
             return fail(QENV_ERR_ARG, "robust_control: the gusts follow the step counter, dynamics-only steps are not available");
@@ -1176,6 +1357,57 @@ template <typename T, typename S, bool LEAN = false> int do_step(qenv_s* q, cons
         default: hipLaunchKernelGGL((k_step<T, S, INT_RK4, false, LEAN>), g, b, 0, q->stream, a); break;
     }
     return check_launch("k_step");
+}
+
+// qenv_ppo_rollout (in-band schedule) / qenv_policy_rollout as ONE launch of k_ppo_fused.  The caller (qenv_env.hip) has checked
+// that the configuration is one the kernel covers (ppo_fused_ok).
+template <typename T, typename S, bool LEAN = false> int do_ppo_fused(qenv_s* q, const qenv_ppo_step_args* p, int n_steps, int deterministic,
+                                                                      const void* image) {
+    constexpr size_t esz = sizeof(S);
+    const size_t N = (size_t)q->N;
+    StepExtra ex{};
+    if (!deterministic) {
+        ex.ar_on = 2; ex.ar_seed = p->seed; ex.ar_episode = p->step; ex.ar_env_offset = p->env_offset;
+        ex.ar_key_episode = p->key_by_episode; ex.out_valid = p->out_valid;
+    }
+    FusedArgs<T, S> fa;
+    fa.st = make_step_args<T, S>(q, p->out_action, nullptr, nullptr, p->out_reward, p->out_done, p->out_mask, QENV_STEP_NO_AUX, q->win_head,
+                                 deterministic ? nullptr : &ex);
+    MlpArgs& m = fa.ml;
+    m = MlpArgs{};
+    m.win = q->window; m.N = q->N; m.T = q->cfg.T; m.head = q->win_head; m.n_out = 4; m.final_tanh = 1;
+    m.W1 = p->W1; m.b1 = p->b1; m.W2 = p->W2; m.b2 = p->b2; m.W3 = p->W3; m.b3 = p->b3;
+    m.out = deterministic ? p->out_action : p->out_mean;
+    m.out_f64 = q->cfg.dtype == QENV_F64;
+    m.obs_store = p->obs_store; m.n_chunks = 1; m.obs_rows_from = p->obs_rows_from;
+    m.noise = p->noise; m.seed = p->seed; m.step = p->step; m.env_offset = p->env_offset;
+    m.std = p->std; m.log_norm = deterministic ? 0.0 : -std::log(p->std) - 0.9189385332046727;
+    m.out_action = p->out_action; m.out_logprob = p->out_logprob;
+    m.image = (const uint4*)image;
+    fa.n_steps = n_steps;
+    fa.obs_slices = p->obs_slices;
+    fa.adv_act = (int64_t)(4 * N * esz); fa.adv_logp = (int64_t)(4 * N * esz); fa.adv_noise = (int64_t)(4 * N * esz);
+    fa.adv_obs = (int64_t)((p->obs_slices ? (size_t)15 : (size_t)15 * q->cfg.T) * N * sizeof(float));
+    fa.adv_row = (int64_t)(N * esz);
+    const int64_t n_blocks = ((int64_t)N + 63) / 64;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    int64_t blocks = (n_blocks + 3) / 4;
+    if (blocks > cus) blocks = cus;   // one resident workgroup per CU (its LDS holds the weights); a wave walks its blocks
+    const size_t lds = sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4 + 80 * sizeof(uint32_t);
+    hipError_t e;
+    if (deterministic) {
+        auto fn = k_ppo_fused<T, S, INT_RK45, LEAN, false>;
+        if ((e = allow_dynamic_lds((const void*)fn, lds)) != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_ppo_fused)");
+        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), lds, q->stream, fa);
+    } else {
+        auto fn = k_ppo_fused<T, S, INT_RK45, LEAN, true>;
+        if ((e = allow_dynamic_lds((const void*)fn, lds)) != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_ppo_fused)");
+        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), lds, q->stream, fa);
+    }
+    const int rc = check_launch("k_ppo_fused");
+    if (rc == QENV_OK) q->win_head = (q->win_head + n_steps) % q->cfg.T;
+    return rc;
 }
 
 template <typename T, typename S, int INTEG, bool LEAN> static void launch_rollout(qenv_s* q, int controller, const RolloutArgs<T, S>& a) {
@@ -1352,7 +1584,8 @@ template <typename T, typename S, bool LEAN> int do_method(qenv_s* q, int what, 
                                        const StepExtra*);                                                                \
     X template int do_rollout<T, S, LEAN>(qenv_s*, int, int, const double*, int, int, const void*);                      \
     X template int do_reset<T, S, LEAN>(qenv_s*, const void*, const uint8_t*, void*, void*, int, const ResetSample*);     \
-    X template int do_method<T, S, LEAN>(qenv_s*, int, int64_t, const void* const*, void* const*);
+    X template int do_method<T, S, LEAN>(qenv_s*, int, int64_t, const void* const*, void* const*);                       \
+    X template int do_ppo_fused<T, S, LEAN>(qenv_s*, const qenv_ppo_step_args*, int, int, const void*);
 #ifndef QENV_ENV_UNIT_F32
 QENV_ENV_INSTANCES(extern, float, float, false)
 #endif

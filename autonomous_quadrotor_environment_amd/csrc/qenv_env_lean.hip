@@ -5,3 +5,9 @@
 namespace qenv {
 QENV_ENV_INSTANCES(, double, double, true)
 }  // namespace qenv
+
+#ifdef QENV_FUSED_STAMPS
+extern "C" int qenv_debug_fused_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qenv::g_fused_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif

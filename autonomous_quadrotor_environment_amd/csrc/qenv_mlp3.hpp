@@ -1,0 +1,259 @@
+// qenv_mlp3.hpp -- the N = 128, T = 5 policy forward on the bf16 matrix cores as device functions: the argument block, the weight
+// image, one 32-env tile of layers 1-3 and ActorCritic.act's sampling.  Shared by k_mlp_v3 (qenv_ppo.hip: one launch per
+// policy step) and k_ppo_fused (qenv_env_impl.hpp: policy and env step of a whole rollout in one launch) -- one definition, so
+// the two produce the same bits.
+#pragma once
+#include "qenv_mlp_common.hpp"
+#include <cstdint>
+
+namespace qenv {
+
+struct MlpArgs {
+    const float* win;   // [15*T][N] ring
+    int64_t N;
+    int32_t T, head, n_out, final_tanh;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    void* out;          // [n_out][N]
+    int32_t out_f64;
+    float* obs_store;   // null or [15*T][N]: the window in time order
+    int32_t n_chunks;   // > 1: win = [n_chunks][15*T][N] stored observations (head 0), out = [n_chunks][n_out][N]
+    // SAMPLE instantiations (qenv_policy_act): ActorCritic.act's sampling in the epilogue of the actor forward
+    const void* noise;  // null (Philox) or injected [4][N] standard normals in the handle's dtype
+    uint64_t seed, step;
+    int64_t env_offset;
+    double std, log_norm;
+    void *out_action, *out_logprob;  // [4][N] in the handle's dtype; logprob nullable
+    // overlapped PPO step: nothing is stored for an env whose byte in env_skip is set (its tile is computed anyway) ...
+    const uint8_t* env_skip;
+    // ... or: only the envs list_idx[0 .. *list_count) are evaluated, gathered into dense tiles (k_mlp_small only)
+    const int32_t* list_idx;
+    const int32_t* list_count;
+    // cleared by the first thread of the launch: the length counter of the reset list that the step kernel FOLLOWING this
+    // policy forward on the stream appends to (qenv_ppo_step: saves a 4-byte memset launch, ~5 us, per rollout step)
+    int32_t* zero_word;
+    // k_mlp_v3: null, or the weights already in the kernel's LDS layout (qenv_mlp_prepare): staging is then a plain copy
+    const uint4* image;
+    // The SLICE layout of stored observations (k_mlp_v3 / k_mlp_small; launch_mlp refuses it elsewhere).  The window of step t is
+    // the five newest 15-float slices, so consecutive windows overlap in four of them: a rollout stores ONE slice per step into
+    // an array [(n_steps + T - 1) * 15][N] and the window of step t is its rows 15 t .. 15 t + 15 T - 1 -- the [n][15 T][N]
+    // layout with a chunk stride of 15 N instead of 15 T N.
+    int32_t obs_rows_from;      // obs_store: only rows >= this are written (15 (T - 1): the newest slice; 0: the whole window)
+    int64_t win_chunk_stride;   // n_chunks > 1: elements between consecutive chunks of `win` (0 = 15 T N, dense)
+};
+
+// ---- counter-based RNG: Philox4x32-10 (Salmon et al. 2011) --------------------------------------
+// One call = 4 x 32 random bits as a pure function of (key, counter): any env/step can be drawn
+// independently, so streams are identical whatever the sharding or launch order.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    float sn, cs;
+    sincosf(6.283185307179586f * u01(b), &sn, &cs);
+    z0 = r * cs; z1 = r * sn;
+}
+
+// k_sample_action for the env of this lane, from the four means the lane holds (same streams, same arithmetic)
+__device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const float mean[4]) {
+    float z[4];
+    if (a.noise) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            z[k] = a.out_f64 ? (float)((const double*)a.noise)[(int64_t)k * a.N + e] : ((const float*)a.noise)[(int64_t)k * a.N + e];
+    } else {
+        const uint64_t g = (uint64_t)(a.env_offset + e);
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)a.step, (uint32_t)(a.step >> 32)};
+        philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32) ^ 0xAC710Du);
+        box_muller(c[0], c[1], z[0], z[1]);
+        box_muller(c[2], c[3], z[2], z[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (a.out_f64) {
+            const double eps = (double)z[k];
+            ((double*)a.out_action)[(int64_t)k * a.N + e] = (double)mean[k] + a.std * eps;
+            if (a.out_logprob) ((double*)a.out_logprob)[(int64_t)k * a.N + e] = -0.5 * eps * eps + a.log_norm;
+        } else {
+            const float eps = z[k];
+            ((float*)a.out_action)[(int64_t)k * a.N + e] = mean[k] + (float)a.std * eps;
+            if (a.out_logprob) ((float*)a.out_logprob)[(int64_t)k * a.N + e] = -0.5f * eps * eps + (float)a.log_norm;
+        }
+    }
+}
+
+// the image from the fp32 torch-layout weights, written by `nthr` threads (a workgroup into LDS, or a small grid into
+// global memory: qenv_mlp_prepare).  Fragment layouts: see k_mlp.
+__device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, const float* b1, const float* W2, const float* b2,
+                                                 const float* W3, const float* b3, int n_out, int tid, int nthr) {
+    using namespace mlp3;
+    for (int c = tid; c < NT * KS16 * 64; c += nthr) {   // W1: lane (col, half) holds W1[32 t + col][16 s + 8 half + i]
+        const int ln = c & 63, sk = (c >> 6) % KS16, t = (c >> 6) / KS16;
+        const int k0 = 16 * sk + 8 * (ln >> 5);
+        const float* src = W1 + (size_t)(32 * t + (ln & 31)) * KW;
+        float w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w8[i] = (k0 + i) < KW ? src[k0 + i] * TANH_PRESCALE : 0.f;   // (see fast_tanh_prescaled)
+        bf16x8 sp[3];
+        split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) img[W1F + ((t * KS16 + sk) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+    }
+    for (int c = tid; c < NT * NT * 2 * 64; c += nthr) { // W2: lane (col, half) holds W2[32 t + col][32 ti + acc_row(8 jh + i, half)]
+        const int ln = c & 63, jh = (c >> 6) & 1, ti = (c >> 7) % NT, t = (c >> 7) / NT;
+        const float* src = W2 + (size_t)(32 * t + (ln & 31)) * H + 32 * ti + 16 * jh + 4 * (ln >> 5);
+        const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
+        const float w8[8] = {lo4.x * TANH_PRESCALE, lo4.y * TANH_PRESCALE, lo4.z * TANH_PRESCALE, lo4.w * TANH_PRESCALE,
+                             hi4.x * TANH_PRESCALE, hi4.y * TANH_PRESCALE, hi4.z * TANH_PRESCALE, hi4.w * TANH_PRESCALE};
+        bf16x8 sp[3];
+        split3x8(w8, sp[0], sp[1], sp[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) img[W2F + (((t * NT + ti) * 2 + jh) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
+    }
+    for (int h = tid; h < H; h += nthr) {
+        float4 w;
+        w.x = W3[h]; w.y = n_out > 1 ? W3[(size_t)H + h] : 0.f; w.z = n_out > 2 ? W3[(size_t)2 * H + h] : 0.f;
+        w.w = n_out > 3 ? W3[(size_t)3 * H + h] : 0.f;
+        img[W3T + h] = __builtin_bit_cast(uint4, w);
+    }
+    for (int q4 = tid; q4 < H / 4; q4 += nthr) {
+        const float4 x1 = *reinterpret_cast<const float4*>(b1 + 4 * q4), x2 = *reinterpret_cast<const float4*>(b2 + 4 * q4);
+        const float4 s1 = {x1.x * TANH_PRESCALE, x1.y * TANH_PRESCALE, x1.z * TANH_PRESCALE, x1.w * TANH_PRESCALE};
+        const float4 s2 = {x2.x * TANH_PRESCALE, x2.y * TANH_PRESCALE, x2.z * TANH_PRESCALE, x2.w * TANH_PRESCALE};
+        img[B1 + q4] = __builtin_bit_cast(uint4, s1);
+        img[B2 + q4] = __builtin_bit_cast(uint4, s2);
+    }
+    if (tid == 0) {
+        float4 b;
+        b.x = b3[0]; b.y = n_out > 1 ? b3[1] : 0.f; b.z = n_out > 2 ? b3[2] : 0.f; b.w = n_out > 3 ? b3[3] : 0.f;
+        img[B3] = __builtin_bit_cast(uint4, b);
+    }
+}
+
+
+// ---- layers 1-3 of ONE 32-env tile for a wave that has its SIMD to itself (k_ppo_fused: one wave per SIMD) ---------------
+// The arithmetic is k_mlp_v3's, instruction for instruction: per output tile the same chain of v_mfma_f32_32x32x16_bf16 in the
+// same order (six products of the three-way split operands per 16 k, smallest first), the same tanh, the same split, layer 3 as
+// the same FMAs in the same order -- the two kernels are compared bit for bit by the tests.  What differs is the SCHEDULE.  A
+// lone wave has nobody to hide behind: the matrix pipe runs only while this wave's stream feeds it, and an MFMA takes 32 cycles
+// of which the issue port is busy for 8 -- the vector work of the PREVIOUS output tile (tanh + split into the next layer's B
+// operand, or tanh + layer 3) has to sit BETWEEN the MFMAs of this one.  k_mlp_v3 asks for that with one scheduling region per
+// chain (sched_group_barrier); with 512 registers to play with hipcc honours it only in small regions (in a region of 30-48
+// MFMAs it issued the chain as a burst and the vector work as a block: 20.5 k cycles per tile, the sum of the two).  So every
+// 16-k step is its own region here: six MFMAs, a sixth .. an eighth of the previous tile's vector work, and the LDS reads of the
+// NEXT step's three weight fragments (a step's MFMAs never wait for their own reads).
+// lds4: the image (mlp3 layout); xsp: the tile's window as bf16 terms; o: the four outputs before the final tanh, valid in the
+// lower lane half.
+__device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, int half, const bf16x8 (&xsp)[mlp3::KS16][3],
+                                                  float (&o)[4]) {
+    using namespace mlp3;
+    const uint4* W1f = lds4 + W1F;
+    const uint4* W2f = lds4 + W2F;
+    const float4* W3t = reinterpret_cast<const float4*>(lds4 + W3T);
+    const float* b1s = reinterpret_cast<const float*>(lds4 + B1);
+    const float* b2s = reinterpret_cast<const float*>(lds4 + B2);
+    const float* b3s = reinterpret_cast<const float*>(lds4 + B3);
+    struct Frag { bf16x8 h, m, l; };
+    auto ld = [&](const uint4* f) {
+        Frag r;
+        r.h = __builtin_bit_cast(bf16x8, f[0]); r.m = __builtin_bit_cast(bf16x8, f[64]); r.l = __builtin_bit_cast(bf16x8, f[128]);
+        return r;
+    };
+    auto f1 = [&](int t, int sk) { return W1f + (size_t)((t * KS16 + sk) * 3) * 64 + lane; };
+    auto f2 = [&](int t, int u) { return W2f + (size_t)((t * NT * 2 + u) * 3) * 64 + lane; };   // u = 2 ti + jh
+    auto bias = [&](f32x16& a, const float* b, int t) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = b[32 * t + acc_row(j, half)];
+    };
+    auto mf6 = [&](f32x16& a, const Frag& f, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {   // smallest products first
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.m, bm, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, bh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bl, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.m, bh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bm, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bh, a, 0, 0, 0);
+    };
+    f32x16 acc1[NT];
+    bf16x8 bsp[NT][2][3];
+    // the vector work behind layer-1 output tile t in four parts: tanh of registers 0-7, their split (layer 2's B operand of
+    // k-step 2 t), tanh of registers 8-15, their split
+    auto finish1 = [&](int t, int part) {
+        const int jh = part >> 1;
+        if ((part & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc1[t][8 * jh + i] = fast_tanh_prescaled(acc1[t][8 * jh + i]);
+        } else {
+            float v8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v8[i] = acc1[t][8 * jh + i];
+            split3x8(v8, bsp[t][jh][0], bsp[t][jh][1], bsp[t][jh][2]);
+        }
+    };
+    // the vector work behind layer-2 output tile t in eight parts: tanh + layer 3 of registers 2 p, 2 p + 1 (mlp3_layer3's FMAs
+    // in its order)
+    auto finish2 = [&](int t, const f32x16& a2, int p) {
+#pragma unroll
+        for (int j = 2 * p; j < 2 * p + 2; ++j) {
+            const float h2 = fast_tanh_prescaled(a2[j]);
+            const float4 w = W3t[32 * t + acc_row(j, half)];
+            o[0] = fmaf(w.x, h2, o[0]); o[1] = fmaf(w.y, h2, o[1]);
+            o[2] = fmaf(w.z, h2, o[2]); o[3] = fmaf(w.w, h2, o[3]);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
+    Frag cur = ld(f1(0, 0));
+    bias(acc1[0], b1s, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- layer 1: chain t beside tanh + split of tile t - 1
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int sk = 0; sk < KS16; ++sk) {
+            const Frag nxt = ld(sk + 1 < KS16 ? f1(t, sk + 1) : (t + 1 < NT ? f1(t + 1, 0) : f2(0, 0)));
+            mf6(acc1[t], cur, xsp[sk][0], xsp[sk][1], xsp[sk][2]);
+            if (t > 0 && sk < 4) finish1(t - 1, sk);
+            if (sk == 3 && t + 1 < NT) bias(acc1[t + 1], b1s, t + 1);   // the next chain's start values, a region ahead
+            if (t > 0 && sk < 4) sgb_interleave<6, 7>();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    // ---- layer 2: chain 0 beside tanh + split of layer-1 tile 3 (its k-steps 6, 7 read that tile's terms: the four parts ride
+    // on k-steps 0-3); chain t beside tanh + layer 3 of tile t - 1; the start values of a chain are read a few regions early
+    // into `b2n` (its accumulator still holds the tile before last until the previous chain's last region)
+    f32x16 acc2[2], b2n;
+    bias(acc2[0], b2s, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t > 0) acc2[t & 1] = b2n;
+#pragma unroll
+        for (int u = 0; u < 2 * NT; ++u) {
+            const bool last = t + 1 == NT && u + 1 == 2 * NT;
+            const Frag nxt = last ? cur : ld(u + 1 < 2 * NT ? f2(t, u + 1) : f2(t + 1, 0));
+            mf6(acc2[t & 1], cur, bsp[u >> 1][u & 1][0], bsp[u >> 1][u & 1][1], bsp[u >> 1][u & 1][2]);
+            if (t == 0) {
+                if (u < 4) { finish1(NT - 1, u); sgb_interleave<6, 7>(); }
+            } else {
+                finish2(t - 1, acc2[(t - 1) & 1], u);
+                sgb_interleave<6, 3>();
+            }
+            if (u == 5 && t + 1 < NT) bias(b2n, b2s, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) finish2(NT - 1, acc2[(NT - 1) & 1], p);
+    mlp3_layer3_finish(o);
+}
+
+}  // namespace qenv

@@ -8,6 +8,7 @@
 //   visual_landing/rl_reward_fuction.py:3-102      visual_reward
 #include "qenv_host.hpp"
 #include "qenv_mlp_common.hpp"
+#include "qenv_mlp3.hpp"
 #include "qenv_sensor.hpp"
 
 namespace qenv {
@@ -38,70 +39,6 @@ __global__ __launch_bounds__(256) void k_window_push(float* win, int64_t N, int 
 // across the lane halves as one k-step, reading the matching two weight columns.  No LDS
 // round trip, no shuffles between layers.  Weights are staged once per workgroup into LDS,
 // transposed to [k][h] so the 32 lanes of a half read 32 consecutive floats (conflict-free).
-
-struct MlpArgs {
-    const float* win;   // [15*T][N] ring
-    int64_t N;
-    int32_t T, head, n_out, final_tanh;
-    const float *W1, *b1, *W2, *b2, *W3, *b3;
-    void* out;          // [n_out][N]
-    int32_t out_f64;
-    float* obs_store;   // null or [15*T][N]: the window in time order
-    int32_t n_chunks;   // > 1: win = [n_chunks][15*T][N] stored observations (head 0), out = [n_chunks][n_out][N]
-    // SAMPLE instantiations (qenv_policy_act): ActorCritic.act's sampling in the epilogue of the actor forward
-    const void* noise;  // null (Philox) or injected [4][N] standard normals in the handle's dtype
-    uint64_t seed, step;
-    int64_t env_offset;
-    double std, log_norm;
-    void *out_action, *out_logprob;  // [4][N] in the handle's dtype; logprob nullable
-    // overlapped PPO step: nothing is stored for an env whose byte in env_skip is set (its tile is computed anyway) ...
-    const uint8_t* env_skip;
-    // ... or: only the envs list_idx[0 .. *list_count) are evaluated, gathered into dense tiles (k_mlp_small only)
-    const int32_t* list_idx;
-    const int32_t* list_count;
-    // cleared by the first thread of the launch: the length counter of the reset list that the step kernel FOLLOWING this
-    // policy forward on the stream appends to (qenv_ppo_step: saves a 4-byte memset launch, ~5 us, per rollout step)
-    int32_t* zero_word;
-    // k_mlp_v3: null, or the weights already in the kernel's LDS layout (qenv_mlp_prepare): staging is then a plain copy
-    const uint4* image;
-    // The SLICE layout of stored observations (k_mlp_v3 / k_mlp_small; launch_mlp refuses it elsewhere).  The window of step t is
-    // the five newest 15-float slices, so consecutive windows overlap in four of them: a rollout stores ONE slice per step into
-    // an array [(n_steps + T - 1) * 15][N] and the window of step t is its rows 15 t .. 15 t + 15 T - 1 -- the [n][15 T][N]
-    // layout with a chunk stride of 15 N instead of 15 T N.
-    int32_t obs_rows_from;      // obs_store: only rows >= this are written (15 (T - 1): the newest slice; 0: the whole window)
-    int64_t win_chunk_stride;   // n_chunks > 1: elements between consecutive chunks of `win` (0 = 15 T N, dense)
-};
-
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1);
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1);
-
-// k_sample_action for the env of this lane, from the four means the lane holds (same streams, same arithmetic)
-__device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const float mean[4]) {
-    float z[4];
-    if (a.noise) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            z[k] = a.out_f64 ? (float)((const double*)a.noise)[(int64_t)k * a.N + e] : ((const float*)a.noise)[(int64_t)k * a.N + e];
-    } else {
-        const uint64_t g = (uint64_t)(a.env_offset + e);
-        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)a.step, (uint32_t)(a.step >> 32)};
-        philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32) ^ 0xAC710Du);
-        box_muller(c[0], c[1], z[0], z[1]);
-        box_muller(c[2], c[3], z[2], z[3]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (a.out_f64) {
-            const double eps = (double)z[k];
-            ((double*)a.out_action)[(int64_t)k * a.N + e] = (double)mean[k] + a.std * eps;
-            if (a.out_logprob) ((double*)a.out_logprob)[(int64_t)k * a.N + e] = -0.5 * eps * eps + a.log_norm;
-        } else {
-            const float eps = z[k];
-            ((float*)a.out_action)[(int64_t)k * a.N + e] = mean[k] + (float)a.std * eps;
-            if (a.out_logprob) ((float*)a.out_logprob)[(int64_t)k * a.N + e] = -0.5f * eps * eps + (float)a.log_norm;
-        }
-    }
-}
 
 // Diagnostic build only (-DQENV_MLP_STAMPS, tools/mlp_stamps.py): s_memtime stamps of k_mlp's phases per wave.  The product
 // build compiles none of it.
@@ -466,60 +403,12 @@ __global__ __launch_bounds__(BLOCK) void k_mlp(const MlpArgs a) {
 // Layers 1 and 2 are k_mlp<.,.,.,.,.,2>'s arithmetic instruction for instruction (same products, same order).
 // k_mlp_small<.,.,.,3> mirrors layer 3 (mlp3_layer3): the two kernels stay bit-identical (shard invariance).
 
-// the image from the fp32 torch-layout weights, written by `nthr` threads (a workgroup into LDS, or a small grid into
-// global memory: qenv_mlp_prepare).  Fragment layouts: see k_mlp.
-__device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, const float* b1, const float* W2, const float* b2,
-                                                 const float* W3, const float* b3, int n_out, int tid, int nthr) {
-    using namespace mlp3;
-    for (int c = tid; c < NT * KS16 * 64; c += nthr) {   // W1: lane (col, half) holds W1[32 t + col][16 s + 8 half + i]
-        const int ln = c & 63, sk = (c >> 6) % KS16, t = (c >> 6) / KS16;
-        const int k0 = 16 * sk + 8 * (ln >> 5);
-        const float* src = W1 + (size_t)(32 * t + (ln & 31)) * KW;
-        float w8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w8[i] = (k0 + i) < KW ? src[k0 + i] * TANH_PRESCALE : 0.f;   // (see fast_tanh_prescaled)
-        bf16x8 sp[3];
-        split3x8(w8, sp[0], sp[1], sp[2]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) img[W1F + ((t * KS16 + sk) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
-    }
-    for (int c = tid; c < NT * NT * 2 * 64; c += nthr) { // W2: lane (col, half) holds W2[32 t + col][32 ti + acc_row(8 jh + i, half)]
-        const int ln = c & 63, jh = (c >> 6) & 1, ti = (c >> 7) % NT, t = (c >> 7) / NT;
-        const float* src = W2 + (size_t)(32 * t + (ln & 31)) * H + 32 * ti + 16 * jh + 4 * (ln >> 5);
-        const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
-        const float w8[8] = {lo4.x * TANH_PRESCALE, lo4.y * TANH_PRESCALE, lo4.z * TANH_PRESCALE, lo4.w * TANH_PRESCALE,
-                             hi4.x * TANH_PRESCALE, hi4.y * TANH_PRESCALE, hi4.z * TANH_PRESCALE, hi4.w * TANH_PRESCALE};
-        bf16x8 sp[3];
-        split3x8(w8, sp[0], sp[1], sp[2]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) img[W2F + (((t * NT + ti) * 2 + jh) * 3 + k) * 64 + ln] = __builtin_bit_cast(uint4, sp[k]);
-    }
-    for (int h = tid; h < H; h += nthr) {
-        float4 w;
-        w.x = W3[h]; w.y = n_out > 1 ? W3[(size_t)H + h] : 0.f; w.z = n_out > 2 ? W3[(size_t)2 * H + h] : 0.f;
-        w.w = n_out > 3 ? W3[(size_t)3 * H + h] : 0.f;
-        img[W3T + h] = __builtin_bit_cast(uint4, w);
-    }
-    for (int q4 = tid; q4 < H / 4; q4 += nthr) {
-        const float4 x1 = *reinterpret_cast<const float4*>(b1 + 4 * q4), x2 = *reinterpret_cast<const float4*>(b2 + 4 * q4);
-        const float4 s1 = {x1.x * TANH_PRESCALE, x1.y * TANH_PRESCALE, x1.z * TANH_PRESCALE, x1.w * TANH_PRESCALE};
-        const float4 s2 = {x2.x * TANH_PRESCALE, x2.y * TANH_PRESCALE, x2.z * TANH_PRESCALE, x2.w * TANH_PRESCALE};
-        img[B1 + q4] = __builtin_bit_cast(uint4, s1);
-        img[B2 + q4] = __builtin_bit_cast(uint4, s2);
-    }
-    if (tid == 0) {
-        float4 b;
-        b.x = b3[0]; b.y = n_out > 1 ? b3[1] : 0.f; b.z = n_out > 2 ? b3[2] : 0.f; b.w = n_out > 3 ? b3[3] : 0.f;
-        img[B3] = __builtin_bit_cast(uint4, b);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_mlp_prepare(uint4* image, const float* W1, const float* b1, const float* W2, const float* b2,
                                                      const float* W3, const float* b3, int n_out) {
     mlp3_build_image(image, W1, b1, W2, b2, W3, b3, n_out, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
 }
 
-template <int BLOCK, bool SAMPLE, bool PIPE = true>
+template <int BLOCK, bool SAMPLE>
 __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
     using namespace mlp3;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
@@ -571,12 +460,9 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         }
     };
 
-    // ---- the weights.  With a prepared image: W1 / W3 / biases by every wave, barrier; W2 (96 of the 159 KiB) by the UPPER
-    // half of the waves while the lower half already runs layer 1 of its first tile -- a second barrier in front of layer 2
-    // joins them, after which the two waves of every SIMD are one layer-1 phase apart (the stagger that lets one wave's
-    // vector-heavy phase meet the other's matrix-heavy one).  Without an image every wave splits its share of the fp32
-    // weights as before.
-    bool w2_pending = false;
+    // ---- the weights.  With a prepared image the staging is a copy (W1 / W3 / biases, then W2: every wave takes part); without
+    // one every wave splits its share of the fp32 weights.  The upper half of the waves asks for its first window after the
+    // barrier, the lower half before it (see below).
     const bool upper = wave >= waves_per_block / 2;
     // image[first .. first + count) -> LDS by nthr threads, eight 16-byte loads in flight per thread: one load per round trip
     // (what a plain loop compiles to) made the 96 KiB of W2 a 20 k-cycle latency chain
@@ -680,6 +566,8 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         // by a handful of VALU instructions throughout: ~5 VALU issue slots hide under a v_mfma_f32_32x32x16_bf16 in the
         // same wave's stream (tools/ubench/mfma_fill.hip), while an MFMA-only phase of one wave next to a VALU-only phase
         // of the other wave of the SIMD -- what the un-pipelined loop produced -- costs both (81 cycles per MFMA).
+        // (mlp3_tile_forward in qenv_mlp3.hpp is the same arithmetic scheduled for a wave that is alone on its SIMD, for
+        // k_ppo_fused -- the two are compared bit for bit by the tests of the fused rollout)
         f32x16 acc1[NT];
         bf16x8 bsp[NT][2][3];
         auto l1_chain = [&](int t) {
@@ -735,12 +623,7 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
-        if (w2_pending && upper) {   // (wave-uniform) the upper half stages W2, then joins the lower half in front of ITS layer 2
-            copy_image(W2F, W3T - W2F, (int)threadIdx.x - BLOCK / 2, BLOCK / 2);
-            __syncthreads();
-            w2_pending = false;
-        }
-        if constexpr (PIPE) {
+        {
             __builtin_amdgcn_sched_barrier(0);
             l1_chain(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -751,14 +634,15 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
                 sgb_interleave<30, 6>();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (w2_pending) { __syncthreads(); w2_pending = false; }   // the lower half: W2 has been staged meanwhile
             f32x16 acc2[2];
             l2_chain(0, acc2[0], 0, NT - 1); // its first 36 MFMAs read bsp[0..2] only: beside tanh + split of layer-1 tile 3
             l1_finish(NT - 1);
             sgb_interleave<36, 5>();
             __builtin_amdgcn_sched_barrier(0);
             l2_chain(0, acc2[0], NT - 1, NT);
-            if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);   // see below
+            // the NEXT tile's window is requested here: its 40 registers are free again (the window lives on as xsp until layer 1
+            // ends, the activations as bsp from here), and the rest of layer 2 + layer 3 give the loads ~10 k cycles to land
+            if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 1; t < NT; ++t) {   // chain t beside tanh + layer 3 of t - 1
@@ -772,24 +656,6 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc2[(NT - 1) & 1][j] = fast_tanh_prescaled(acc2[(NT - 1) & 1][j]);
             mlp3_layer3(W3t, NT - 1, half, acc2[(NT - 1) & 1], o);
-        } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { l1_chain(t); l1_finish(t); }
-        if (w2_pending) { __syncthreads(); w2_pending = false; }
-        MLP_STAMP(4 + 6 * stamp_tile);
-        // the NEXT tile's window is requested here: its 40 registers are free again (the window lives on as xsp until layer 1
-        // ends, the activations as bsp from here), and layer 2 + 3 give the loads ~10 k cycles to land
-        if (gtile + tile_stride < n_tiles) request_window(gtile + tile_stride);
-        MLP_STAMP(5 + 6 * stamp_tile);
-        // ---- layer 2 on the matrix cores, layer 3 on the vector lanes behind each finished output tile
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x16 acc2;
-            l2_chain(t, acc2);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc2[j] = fast_tanh_prescaled(acc2[j]);
-            mlp3_layer3(W3t, t, half, acc2, o);
-        }
         }
         mlp3_layer3_finish(o);
         MLP_STAMP(6 + 6 * stamp_tile);
@@ -809,10 +675,6 @@ __global__ __launch_bounds__(BLOCK) void k_mlp_v3(const MlpArgs a) {
         }
         MLP_STAMP(7 + 6 * stamp_tile);
         ++stamp_tile;
-    }
-    if (w2_pending) {   // a wave without a tile still takes part in the staging and its barrier
-        if (upper) copy_image(W2F, W3T - W2F, (int)threadIdx.x - BLOCK / 2, BLOCK / 2);
-        __syncthreads();
     }
     MLP_STAMP(15);
 }
@@ -1960,27 +1822,6 @@ template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream)
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL((k_dense_tail<H>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     return check_launch("k_dense_tail");
-}
-
-// ---- counter-based RNG: Philox4x32-10 (Salmon et al. 2011) --------------------------------------
-// One call = 4 x 32 random bits as a pure function of (key, counter): any env/step can be drawn
-// independently, so streams are identical whatever the sharding or launch order.
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
-    const float r = sqrtf(-2.0f * logf(u01(a)));
-    float sn, cs;
-    sincosf(6.283185307179586f * u01(b), &sn, &cs);
-    z0 = r * cs; z1 = r * sn;
 }
 
 // ActorCritic.act sampling (model.py:62-68): a = mean + std*eps, per-dimension Normal log-prob

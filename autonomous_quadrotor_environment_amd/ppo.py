@@ -649,6 +649,25 @@ class PolicyRollout:
         self.t += n_steps
         self.global_step += n_steps
 
+    def run_deterministic(self, n_steps):
+        """n_steps steps of the DETERMINISTIC policy (mean action, ppo_quad_eval.py:55) from slot self.t on in ONE library call
+        (qenv_policy_rollout): the buffers of n_steps step(deterministic=True) calls, bit for bit.  No auto-reset, no stored
+        observations, no critic (the evaluation loop)."""
+        n_steps = int(n_steps)
+        if n_steps <= 0:
+            return
+        t0 = self.t
+        if t0 + n_steps > self.horizon:
+            raise ValueError(f"run_deterministic({n_steps}) from slot {t0} exceeds the horizon {self.horizon}")
+        if self.auto_reset or self.obs is not None or (self.w.critic is not None and not self.batched_critic):
+            for _ in range(n_steps):
+                self.step(deterministic=True)
+            return
+        self.env.policy_rollout(self.w, n_steps, self.actions[t0:t0 + n_steps], self.rewards[t0:t0 + n_steps], self.done,
+                                self.masks[t0:t0 + n_steps])
+        self.t += n_steps
+        self.global_step += n_steps
+
     def critic_values(self, n=None):
         """values[:n] = critic(obs[:n]) in one launch over the stored observations (batched_critic)."""
         n = self.t if n is None else n

@@ -537,6 +537,27 @@ class BatchedQuad:
         self._bind()
         L.check(L.lib.qenv_ppo_step(self._h, C.byref(a)), "qenv_ppo_step")
 
+    def policy_rollout(self, weights, n_steps, actions, reward=None, done=None, mask=None):
+        """The evaluation loop of ppo_quad_eval.py:44-62 for n_steps steps in ONE library call (qenv_policy_rollout): per step
+        the deterministic policy (mlp_forward of the actor) and step(NO_AUX, push_window) on its action; the same buffers as
+        those 2 n_steps calls, bit for bit.  actions [n_steps, 4, N]; reward / mask [n_steps, N] optional; done [N] uint8
+        optional (the last step's).  For the reference's controller (hidden 128, T = 5, RK45) the whole loop is one launch."""
+        n_steps = int(n_steps)
+        W = weights.head("actor")
+        self._check_head(W, "actor", n_out=4)
+        want = {"actions": (actions, (n_steps, 4, self.n_envs)), "reward": (reward, (n_steps, self.n_envs)),
+                "mask": (mask, (n_steps, self.n_envs))}
+        for nm, (t, shape) in want.items():
+            if t is None and nm != "actions":
+                continue
+            if t is None or tuple(t.shape) != shape or t.dtype != self.dtype or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"{nm}: expected a contiguous {self.dtype} tensor of shape {shape} on {self.device}")
+        self._check_buf(done, 0, "done", torch.uint8)
+        self._ensure_prepared(weights, "actor")
+        self._bind()
+        L.check(L.lib.qenv_policy_rollout(self._h, int(W[0].shape[1]), int(W[0].shape[0]), *[L.ptr(t) for t in W], n_steps,
+                                          L.ptr(actions), L.ptr(reward), L.ptr(done), L.ptr(mask)), "qenv_policy_rollout")
+
     def ppo_flush(self):
         """Complete the warm-up a ppo_step left pending (no-op otherwise); call before reading the env's fields."""
         self._bind()

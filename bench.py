@@ -238,6 +238,11 @@ def load_policy(policy, dev):
     return w
 
 
+# qenv_ppo_rollout (in-band) / qenv_policy_rollout run policy + env step of a whole chunk as one launch (k_ppo_fused) unless
+# QENV_PPO_FUSED=0 (A/B: the two launches per step)
+FUSED_ROLLOUT = os.environ.get("QENV_PPO_FUSED", "1") != "0"
+
+
 def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_global, shards=1, make_env=None, n_local=0,
                     dev=None, policy="trained", inband=True):
     """config 4 / 5: the rollout collector of ppo.py:223-269 on the device."""
@@ -248,6 +253,11 @@ def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_globa
     w = load_policy(policy, dev)
     if controller == "ppo_actor":
         ro = PolicyRollout(env, ActorCriticWeights(w.actor, None, env.device), chunk)
+        if FUSED_ROLLOUT:   # the evaluation loop as ONE library call (qenv_policy_rollout: one launch of k_ppo_fused per chunk)
+            def fused_body():
+                ro.t = 0
+                ro.run_deterministic(chunk)
+            return fused_body, chunk, ro
 
         def body():
             ro.t = 0
@@ -414,7 +424,8 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
     # timed region is independent of W; the W warm-up steps run first through their own (same-kind) runner when W is not
     # a multiple of it
     cap = 128 if controller == "ppo_rollout" else 250
-    mult = 5 if (controller == "ppo_actor" and not no_graph) else 1  # a graph replay must bring the ring head back
+    fused_ppo = ppo and FUSED_ROLLOUT and integrator == "rk45"
+    mult = 5 if (controller == "ppo_actor" and not no_graph and not fused_ppo) else 1  # a graph replay must bring the ring head back
     chunk = chunk_arg or pick(steps, cap, mult)
     if not chunk:  # K has no multiple-of-5 divisor: eager launches instead of a graph replay
         no_graph, mult = True, 1
@@ -557,7 +568,8 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
     res = {"value": value, "ms_per_step": secs / steps * 1e3, "regions": len(regions),
            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3,
            "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,
-           "hip_graph": (launch == "step" and not no_graph and controller != "ppo_rollout"),
+           "hip_graph": (launch == "step" and not no_graph and controller != "ppo_rollout" and not fused_ppo),
+           "policy_env_fused": fused_ppo,
            "envs_per_gpu": hi - lo, "global_envs": n_global, "controller": controller, "desc": desc, "roofline": roofline,
            "all_gather_len": None if gathered is None else int(gathered.numel()), "all_gather_us": gather_us,
            "stream_shards": shards, "episode_steps": EPISODE_STEPS if episodic else None,

@@ -33,13 +33,15 @@
 extern "C" {
 #endif
 
-/* 5: qenv_ppo_step_args gains out_valid / inband / key_by_episode (in-band warm-up); qenv_gae_masked,
+/* 7: qenv_policy_rollout; qenv_ppo_rollout (in-band) and qenv_policy_rollout run as one launch where k_ppo_fused applies.
+ * 6: qenv_ppo_step_args gains obs_rows_from / obs_slices (the slice layout of stored observations); qenv_dense_tail_chunks_strided.
+ * 5: qenv_ppo_step_args gains out_valid / inband / key_by_episode (in-band warm-up); qenv_gae_masked,
  *    qenv_adv_normalize_masked, qenv_mlp_backward_ppo_masked (the `valid` rows of such a rollout); qenv_mlp_prepare /
  *    qenv_mlp_image_bytes; qenv_reward_function, qenv_mix.
  * 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
  * 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
-#define QENV_ABI_VERSION 6
+#define QENV_ABI_VERSION 7
 
 typedef struct qenv_s *qenv_t;
 
@@ -416,6 +418,18 @@ int qenv_ppo_flush(qenv_t q);
  * calls bit for bit; what it removes is the host's per-step work between the launches (a step is two ~25 us kernels at
  * 65 536 envs: a Python round trip per step leaves the GPU idle for about as long). */
 int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args *first, int n_steps);
+/* ABI 7.  The evaluation loop of ppo_quad_eval.py:44-62 for n_steps steps in one call: per step the DETERMINISTIC policy
+ * (action = tanh mean of the actor, model.py:27-33 -- qenv_mlp_forward with final_tanh = 1) and qenv_step(NO_AUX | PUSH_WINDOW)
+ * on that action; no sampling, no auto-reset (done is sticky, the envs keep stepping as the reference's loop would if it did
+ * not break).  out_actions [n_steps][4][N]; out_reward / out_mask [n_steps][N] nullable; out_done [N] nullable (the last
+ * step's), all in the handle's dtype.  Identical to the 2 n_steps separate calls bit for bit.
+ * Both this call and the in-band qenv_ppo_rollout run as ONE launch for the reference's controller (hidden 128, T = 5, RK45;
+ * no robust_control / sensor / outer loop): a wave keeps its 64-env blocks for the whole horizon, per step the policy forward
+ * of the block's two 32-env tiles and then the env step, the weights staged once per launch instead of once per step
+ * (k_ppo_fused; QENV_PPO_FUSED=0 keeps the separate launches). */
+int qenv_policy_rollout(qenv_t q, int k_in, int hidden, const float *W1, const float *b1, const float *W2, const float *b2,
+                        const float *W3, const float *b3, int n_steps, void *out_actions, void *out_reward,
+                        uint8_t *out_done, void *out_mask);
 
 /* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------
  * The reference hard-codes `self.robust_control = False` (:183) and a user flips the attribute; this is that

@@ -255,3 +255,50 @@ def test_slice_observation_store_equals_the_window_store(aq):
     # the small-batch kernel honours the same two fields: its windows are the slices it stored
     obs = res["small_slices"][0]
     assert torch.equal(obs[1:, :60], obs[:-1, 15:])
+
+
+HANDLES = {"lean": LEAN, "f32": dict(dtype=torch.float32), "mixed": dict(dtype=torch.float64, compute="f32"),
+           "f64": dict(dtype=torch.float64)}
+
+
+@pytest.mark.parametrize("handle", ["lean", "f32", "mixed", "f64"])
+def test_fused_rollout_launch_equals_the_separate_launches(aq, handle):
+    """k_ppo_fused (qenv_ppo_rollout in-band / qenv_policy_rollout as ONE launch: a wave keeps its 64-env blocks for the whole
+    horizon, policy forward of the block's two tiles then the env step, include/qenv.h ABI 7) against the per-step calls
+    (step(): k_mlp_v3 / k_mlp_small + k_step, two launches per step) on every handle type: all rollout buffers, the env's
+    state / window / counters / angles, bit for bit -- a ragged batch (the last block has one tile, the last tile 17 envs),
+    calls that start at a ring head != 0, episodes that end and restart inside the launch."""
+    w, _ = _weights(aq)
+    kw = HANDLES[handle]
+    n = 64 * 33 + 17
+    res = []
+    for mode in ("step", "run"):
+        env = aq.BatchedQuad(n, 0.01, 13, training=True, direct_control=1, T=5, **kw)
+        ro = aq.PolicyRollout(env, w, 40, store_obs=True, auto_reset=True, seed=21, env_offset=500, inband=True)
+        ro.start()
+        if mode == "run":
+            ro.run(17); ro.run(23)
+        else:
+            for _ in range(40):
+                ro.step()
+        ret, adv = ro.finish(ddof=0, group=False, deterministic=True)
+        res.append([x.clone() for x in (ro.actions, ro.logprobs, ro.rewards, ro.masks, ro.obs, ro.values, ret, adv, env.state,
+                                        env.last_return, env.episodes, env.window, env.i, ro.valid)])
+    for k, (x, y) in enumerate(zip(*res)):
+        assert torch.equal(x, y), ("in-band", k)
+    assert int(res[0][10].sum()) > n   # episodes did end and restart
+    res = []
+    for mode in ("step", "run"):
+        env = aq.BatchedQuad(n, 0.01, 500, training=True, direct_control=1, T=5, **kw)
+        ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None, env.device), 30)
+        ro.start()
+        if mode == "run":
+            ro.run_deterministic(11); ro.run_deterministic(19)
+        else:
+            for _ in range(30):
+                ro.step(deterministic=True)
+        res.append([x.clone() for x in (ro.actions, ro.rewards, ro.masks, ro.done, env.state, env.window, env.i, env.ang,
+                                        env.ang_vel, env.reward, env.episode_return)])
+    for k, (x, y) in enumerate(zip(*res)):
+        assert torch.equal(x, y), ("deterministic", k)
+    assert float(res[0][0].abs().max()) > 0.05 and bool(torch.isfinite(res[0][4]).all())

@@ -1,0 +1,38 @@
+"""GPU box: where a wave of k_ppo_fused spends a rollout step, from in-kernel s_memtime stamps (diagnostic build:
+tools/build_variant.sh fstamps "-DQENV_FUSED_STAMPS" qenv_env_lean.hip; run with QENV_LIB=build_variants/libqenv_fstamps.so).
+
+    QENV_LIB=build_variants/libqenv_fstamps.so python tests/tools/fused_stamps.py [envs] [sample 0/1]
+"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np
+import torch
+import autonomous_quadrotor_environment_amd as aq
+from autonomous_quadrotor_environment_amd import _lib as L
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+sample = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden", "g9_mlp_N128.npz"))
+w = aq.ActorCriticWeights.from_state_dict({k: g[k] for k in g.files if k.startswith(("actor", "critic"))})
+w.std = 0.1
+env = aq.BatchedQuad(N, 0.01, 500, training=True, direct_control=1, T=5, dtype=torch.float64, compute="lean")
+if sample:
+    ro = aq.PolicyRollout(env, w, 32, store_obs=True, auto_reset=True, seed=5, inband=True)
+else:
+    ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None, env.device), 32)
+ro.start()
+for _ in range(3):
+    ro.t = 0
+    ro.run(32) if sample else ro.run_deterministic(32)
+torch.cuda.synchronize()
+fn = L.lib.qenv_debug_fused_stamps
+fn.restype = C.c_int
+buf = (C.c_ulonglong * (1024 * 16))()
+assert fn(buf, 1024 * 16) == 0
+s = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16).astype(np.int64)
+s = s[s[:, 0] > 0]
+names = ["A: window load + split", "A: layers 1-3", "A: outputs", "B: window load + split", "B: layers 1-3", "B: outputs", "fences",
+         "env step", "fences"]
+rows = {nm: [float(np.percentile(s[:, k + 1] - s[:, k], q)) for q in (10, 50, 90)] for k, nm in enumerate(names)}
+print(json.dumps(dict(lib=os.environ.get("QENV_LIB", "default"), envs=N, sample=sample, waves=len(s),
+                      step_cycles_median=float(np.median(s[:, 9] - s[:, 0])), phases_p10_p50_p90=rows), indent=1))
