@@ -9,6 +9,27 @@
 #pragma once
 #include "qenv_host.hpp"
 #include "qenv_sensor.hpp"
+#include <hip/hip_runtime.h>
+namespace qenv {
+// Diagnostic build only (-DQENV_FUSED_STAMPS, tests/tools/fused_stamps.py): s_memtime stamps of a wave's phases in its last step.
+#if defined(QENV_FUSED_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
+__device__ unsigned long long g_fused_stamps[1024 * 16];
+#define FUSED_STAMP(slot)                                                                                      \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 1024)                             \
+            g_fused_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = t_;                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#else
+#define FUSED_STAMP(slot) do { } while (0)
+#endif
+
+}  // namespace qenv
+#if defined(QENV_FUSED_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
+#define MLP3_STAMP(slot) FUSED_STAMP(slot)
+#endif
 #include "qenv_mlp3.hpp"
 #include <type_traits>
 
@@ -461,21 +482,6 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
 // The ring offsets: k_mlp_v3's table holds the 80 row offsets of ONE ring head; here the head moves inside the launch, so the
 // table is that of head 0 and a load adds head * 15 rows and wraps (v_add, v_sub, v_min_u32: an offset beyond the ring comes
 // back as the smaller of (off, off - ring bytes), whichever did not wrap through 2^32).
-// Diagnostic build only (-DQENV_FUSED_STAMPS, tests/tools/fused_stamps.py): s_memtime stamps of a wave's phases in its last step.
-#if defined(QENV_FUSED_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
-__device__ unsigned long long g_fused_stamps[1024 * 16];
-#define FUSED_STAMP(slot)                                                                                      \
-    do {                                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 1024)                             \
-            g_fused_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = t_;                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-    } while (0)
-#else
-#define FUSED_STAMP(slot) do { } while (0)
-#endif
-
 template <typename T, typename S> struct FusedArgs {
     StepArgs<T, S> st;   // the step kernel's arguments of step 0
     MlpArgs ml;          // the policy forward's arguments of step 0
@@ -542,6 +548,8 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
                 if (blk * 64 + 32 * tl >= N) break;   // (wave-uniform: a ragged last block has one tile)
                 const bool valid = e < N;
                 const uint32_t e32 = (uint32_t)(valid ? e : N - 1);
+                // (requesting the second tile's window while the first tile computes was tried: the 40 live registers and the
+                //  loads landing in the middle of the matrix work cost the first tile more than the second one gained)
                 float xw[KS16][8];
                 {
                     const uint32_t hb = (uint32_t)head * 15u * N32 * 4u + (valid ? (uint32_t)e * 4u : 0x80000000u);

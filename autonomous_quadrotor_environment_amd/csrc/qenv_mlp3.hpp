@@ -152,6 +152,9 @@ __device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, co
 // NEXT step's three weight fragments (a step's MFMAs never wait for their own reads).
 // lds4: the image (mlp3 layout); xsp: the tile's window as bf16 terms; o: the four outputs before the final tanh, valid in the
 // lower lane half.
+#ifndef MLP3_STAMP
+#define MLP3_STAMP(slot) do { } while (0)   // (diagnostic builds of the including unit define it: s_memtime stamps)
+#endif
 __device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, int half, const bf16x8 (&xsp)[mlp3::KS16][3],
                                                   float (&o)[4]) {
     using namespace mlp3;
@@ -173,40 +176,107 @@ __device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, i
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = b[32 * t + acc_row(j, half)];
     };
-    auto mf6 = [&](f32x16& a, const Frag& f, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {   // smallest products first
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.m, bm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, bh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bl, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.m, bh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bh, a, 0, 0, 0);
+    // one 16-k step: the six products, smallest first, with work(slot) behind each of them -- every (MFMA, work) pair is its own
+    // scheduling region, so the vector work stands where it is written: in the 32-cycle shadow of the MFMA in front of it
+    auto step6 = [&](f32x16& a, const Frag& f, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl, auto&& work) {
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.m, bm, a, 0, 0, 0); work(0); __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.l, bh, a, 0, 0, 0); work(1); __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bl, a, 0, 0, 0); work(2); __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.m, bh, a, 0, 0, 0); work(3); __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bm, a, 0, 0, 0); work(4); __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.h, bh, a, 0, 0, 0); work(5); __builtin_amdgcn_sched_barrier(0);
     };
     f32x16 acc1[NT];
-    bf16x8 bsp[NT][2][3];
-    // the vector work behind layer-1 output tile t in four parts: tanh of registers 0-7, their split (layer 2's B operand of
-    // k-step 2 t), tanh of registers 8-15, their split
-    auto finish1 = [&](int t, int part) {
-        const int jh = part >> 1;
-        if ((part & 1) == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc1[t][8 * jh + i] = fast_tanh_prescaled(acc1[t][8 * jh + i]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned bspu[NT][2][3][4];   // layer 2's B operand: the tanh of layer 1 as bf16 terms (hi, mid, lo), [tile][k-step half][term][dword]
+    auto bsp = [&](int t, int jh, int k) {
+        const u32x4 u = {bspu[t][jh][k][0], bspu[t][jh][k][1], bspu[t][jh][k][2], bspu[t][jh][k][3]};
+        return __builtin_bit_cast(bf16x8, u);
+    };
+    // (every piece of vector work ends in an opaque use of what it computed: its results are not needed before layer 2 / the
+    // tile's end, and left alone the compiler SINKS the arithmetic out of the place it was written into, down to where the
+    // results are used -- the whole of layer 1's vector work then stood in one block in front of layer 2)
+    auto pin_f = [](float& x) { asm volatile("" : "+v"(x)); };
+    auto pin_u = [](unsigned& x) { asm volatile("" : "+v"(x)); };
+    auto cvt_pk = [](float lo, float hi) { unsigned d; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi)); return d; };
+    float th1[NT][16];       // tanh of layer 1's accumulators
+    float rs1[8][2];         // the split in flight: a pair's remainders after the hi term
+    unsigned mp1[8];         // ... and its mid terms
+    // The vector work behind layer-1 output tile t, by the slot S = 0, 1, 2 ... of the MFMA chain it rides on (tools/ubench/
+    // mfma_fill_kinds.hip: the shadow of one MFMA holds six plain VALU instructions, or two transcendental ones and two plain;
+    // v_pk_* and a third transcendental do not fit): slots 0-15 the tanh of register S (v_exp, v_add, v_rcp, v_fma); then the
+    // split of the eight register PAIRS into bf16 terms, half a pair per slot -- split3x8's arithmetic per element (hi = bf16(x),
+    // r = x - hi, mid = bf16(r), lo = bf16(r - mid)), spelled with v_cvt_pk_bf16_f32 on the pair so that a term's dword is
+    // born packed: (hi, r0, r1, mid) = 6 instructions, then (lo) = 5.  n_slots = 30: the last two slots take two halves each.
+    auto split_half = [&](int t, int unit) {
+        const int pr = unit >> 1, jh = pr >> 2, d = pr & 3;
+        if ((unit & 1) == 0) {
+            const float x0 = th1[t][2 * pr], x1 = th1[t][2 * pr + 1];
+            const unsigned h = cvt_pk(x0, x1);
+            rs1[pr][0] = x0 - __uint_as_float(h << 16); rs1[pr][1] = x1 - __uint_as_float(h & 0xffff0000u);
+            mp1[pr] = cvt_pk(rs1[pr][0], rs1[pr][1]);
+            bspu[t][jh][0][d] = h; bspu[t][jh][1][d] = mp1[pr];
+            pin_u(bspu[t][jh][0][d]); pin_u(bspu[t][jh][1][d]); pin_f(rs1[pr][0]); pin_f(rs1[pr][1]);
         } else {
-            float v8[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v8[i] = acc1[t][8 * jh + i];
-            split3x8(v8, bsp[t][jh][0], bsp[t][jh][1], bsp[t][jh][2]);
+            const float s0 = rs1[pr][0] - __uint_as_float(mp1[pr] << 16), s1 = rs1[pr][1] - __uint_as_float(mp1[pr] & 0xffff0000u);
+            bspu[t][jh][2][d] = cvt_pk(s0, s1);
+            pin_u(bspu[t][jh][2][d]);
         }
     };
-    // the vector work behind layer-2 output tile t in eight parts: tanh + layer 3 of registers 2 p, 2 p + 1 (mlp3_layer3's FMAs
-    // in its order)
-    auto finish2 = [&](int t, const f32x16& a2, int p) {
-#pragma unroll
-        for (int j = 2 * p; j < 2 * p + 2; ++j) {
-            const float h2 = fast_tanh_prescaled(a2[j]);
-            const float4 w = W3t[32 * t + acc_row(j, half)];
-            o[0] = fmaf(w.x, h2, o[0]); o[1] = fmaf(w.y, h2, o[1]);
-            o[2] = fmaf(w.z, h2, o[2]); o[3] = fmaf(w.w, h2, o[3]);
+    // tanh as a pipeline over the slots: v_exp, v_add, v_rcp, v_fma of ONE value are a dependent chain of ~50 cycles (two of them
+    // transcendental), which a lone wave cannot hide inside one MFMA shadow -- so slot S issues exp(S), add(S - 1), rcp(S - 2),
+    // fma(S - 3): four independent instructions, each a whole MFMA behind the one it depends on (fast_tanh_prescaled's
+    // arithmetic, stage by stage)
+    float tq[3];   // the pipeline registers: exp, exp + 1, rcp of the values in flight (one each)
+    auto tanh_stages = [&](const f32x16& a, float* th, int S) {
+        if (S >= 3 && S < 19) { th[S - 3] = 1.0f - 2.0f * tq[2]; pin_f(th[S - 3]); }
+        if (S >= 2 && S < 18) { tq[2] = __builtin_amdgcn_rcpf(tq[1]); pin_f(tq[2]); }
+        if (S >= 1 && S < 17) { tq[1] = tq[0] + 1.0f; pin_f(tq[1]); }
+        if (S < 16) { tq[0] = __builtin_amdgcn_exp2f(a[S]); pin_f(tq[0]); }
+    };
+    // slots 0-18 the tanh pipeline, then the 16 halves of the split, one per slot (n_slots = 30: the last four slots take two)
+    auto finish1 = [&](int t, int S, int n_slots) {
+        if (S < 19) tanh_stages(acc1[t], th1[t], S);
+        if (n_slots == 30) {
+            if (S == 18) split_half(t, 0);
+            else if (S >= 19 && S < 26) split_half(t, S - 18);
+            else if (S >= 26) { split_half(t, 2 * S - 44); split_half(t, 2 * S - 43); }
+        } else if (S >= 19 && S < 35) {
+            split_half(t, S - 19);
         }
+    };
+    // The vector work behind layer 2 (tanh + layer 3 of its 64 values V = 16 tile + register, in mlp3_layer3's order) as a
+    // pipeline over the slots of the chains 1-3, three slots per value: on the slot clock G = 48 chain + slot, value V issues exp
+    // at 48 + 3 V, add one slot later, rcp, fma (= tanh), and its four layer-3 FMAs at 52 + 3 V -- so a slot holds (exp, fma) or
+    // (add, 4 FMAs) or (rcp): within one MFMA shadow, every instruction a whole MFMA behind its producer.  Values 48-63 (the last
+    // tile) and the last two stages of value 47 have no chain left to sit beside: the tail.  The row of W3 a value needs is read
+    // a step EARLIER (a ds_read_b128 followed by its own wait is ~100 cycles that a lone wave cannot hide, 64 times per tile).
+    float q2[4];   // exp, exp + 1, rcp, tanh of the values in flight
+    float4 w3r[4]; // rows of W3, a ring by V & 3
+    auto w3row = [&](int V) { w3r[V & 3] = W3t[32 * (V >> 4) + acc_row(V & 15, half)]; };
+    auto l3 = [&](int V) {
+        const float4 w = w3r[V & 3];
+        o[0] = fmaf(w.x, q2[3], o[0]); o[1] = fmaf(w.y, q2[3], o[1]); o[2] = fmaf(w.z, q2[3], o[2]); o[3] = fmaf(w.w, q2[3], o[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pin_f(o[k]);
+    };
+    auto finish2 = [&](const f32x16 (&a2)[2], int G) {   // G >= 48
+        const int ph = (G - 48) % 3, V = (G - 48) / 3;
+        if (ph == 0) {
+            if (V >= 1 && V <= 48) { q2[3] = 1.0f - 2.0f * q2[2]; pin_f(q2[3]); }            // tanh of value V - 1
+            if (V < 48) { q2[0] = __builtin_amdgcn_exp2f(a2[(V >> 4) & 1][V & 15]); pin_f(q2[0]); }
+        } else if (ph == 1) {
+            if (V >= 1 && V <= 48) l3(V - 1);
+            if (V < 48) { q2[1] = q2[0] + 1.0f; pin_f(q2[1]); }
+        } else if (V < 48) {
+            q2[2] = __builtin_amdgcn_rcpf(q2[1]); pin_f(q2[2]);
+        }
+    };
+    // the rows of W3 whose FMAs (slot 52 + 3 V) fall into the step AFTER the one that starts at slot G0 (a step = 6 slots)
+    auto w3_prefetch = [&](int G0) {
+#pragma unroll
+        for (int V = 0; V < 48; ++V)
+            if (52 + 3 * V >= G0 + 6 && 52 + 3 * V < G0 + 12) w3row(V);
     };
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
@@ -219,40 +289,55 @@ __device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, i
 #pragma unroll
         for (int sk = 0; sk < KS16; ++sk) {
             const Frag nxt = ld(sk + 1 < KS16 ? f1(t, sk + 1) : (t + 1 < NT ? f1(t + 1, 0) : f2(0, 0)));
-            mf6(acc1[t], cur, xsp[sk][0], xsp[sk][1], xsp[sk][2]);
-            if (t > 0 && sk < 4) finish1(t - 1, sk);
-            if (sk == 3 && t + 1 < NT) bias(acc1[t + 1], b1s, t + 1);   // the next chain's start values, a region ahead
-            if (t > 0 && sk < 4) sgb_interleave<6, 7>();
+            if (sk == 3 && t + 1 < NT) bias(acc1[t + 1], b1s, t + 1);   // the next chain's start values, a step ahead
             __builtin_amdgcn_sched_barrier(0);
+            step6(acc1[t], cur, xsp[sk][0], xsp[sk][1], xsp[sk][2], [&](int slot) { if (t > 0) finish1(t - 1, 6 * sk + slot, 30); });
+            if (sk + 1 == KS16) asm volatile("" : "+v"(acc1[t]));   // (the chain in VGPRs: an accumulator in AGPRs costs a v_accvgpr_read
+                                                                    //  per value, 8 cycles each beside an MFMA)
             cur = nxt;
         }
     // ---- layer 2: chain 0 beside tanh + split of layer-1 tile 3 (its k-steps 6, 7 read that tile's terms: the four parts ride
-    // on k-steps 0-3); chain t beside tanh + layer 3 of tile t - 1; the start values of a chain are read a few regions early
-    // into `b2n` (its accumulator still holds the tile before last until the previous chain's last region)
+    // on k-steps 0-3); chain t beside tanh + layer 3 of tile t - 1; the start values of a chain are read a few steps early
+    // into `b2n` (its accumulator still holds the tile before last until the previous chain's last step)
     f32x16 acc2[2], b2n;
     bias(acc2[0], b2s, 0);
     __builtin_amdgcn_sched_barrier(0);
+    MLP3_STAMP(10);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t > 0) acc2[t & 1] = b2n;
+        if (t == 1) MLP3_STAMP(11);
 #pragma unroll
         for (int u = 0; u < 2 * NT; ++u) {
             const bool last = t + 1 == NT && u + 1 == 2 * NT;
             const Frag nxt = last ? cur : ld(u + 1 < 2 * NT ? f2(t, u + 1) : f2(t + 1, 0));
-            mf6(acc2[t & 1], cur, bsp[u >> 1][u & 1][0], bsp[u >> 1][u & 1][1], bsp[u >> 1][u & 1][2]);
-            if (t == 0) {
-                if (u < 4) { finish1(NT - 1, u); sgb_interleave<6, 7>(); }
-            } else {
-                finish2(t - 1, acc2[(t - 1) & 1], u);
-                sgb_interleave<6, 3>();
-            }
+            w3_prefetch(48 * t + 6 * u);
             if (u == 5 && t + 1 < NT) bias(b2n, b2s, t + 1);
             __builtin_amdgcn_sched_barrier(0);
+            step6(acc2[t & 1], cur, bsp(u >> 1, u & 1, 0), bsp(u >> 1, u & 1, 1), bsp(u >> 1, u & 1, 2), [&](int slot) {
+                if (t == 0) finish1(NT - 1, 6 * u + slot, 48);
+                else finish2(acc2, 48 * t + 6 * u + slot);
+            });
+            if (u + 1 == 2 * NT) asm volatile("" : "+v"(acc2[t & 1]));   // (see acc1)
             cur = nxt;
         }
     }
+    MLP3_STAMP(12);
+    {   // the tail: value 47's last two stages (its row of W3 was read beside the last step), then the last tile's sixteen values
+        // with nothing to sit beside -- their rows of W3 at once, tanh four at a time, then the FMAs in order
+        finish2(acc2, 192); finish2(acc2, 193);
+        float4 wt[16];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) finish2(NT - 1, acc2[(NT - 1) & 1], p);
+        for (int j = 0; j < 16; ++j) wt[j] = W3t[32 * (NT - 1) + acc_row(j, half)];
+        float h2[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h2[j] = fast_tanh_prescaled(acc2[(NT - 1) & 1][j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            o[0] = fmaf(wt[j].x, h2[j], o[0]); o[1] = fmaf(wt[j].y, h2[j], o[1]);
+            o[2] = fmaf(wt[j].z, h2[j], o[2]); o[3] = fmaf(wt[j].w, h2[j], o[3]);
+        }
+    }
     mlp3_layer3_finish(o);
 }
 

@@ -1666,6 +1666,7 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
         reinterpret_cast<float*>(lds4 + B2)[h] = a.b2[h] * TANH_PRESCALE;
     }
     if (threadIdx.x < 4) reinterpret_cast<float*>(lds4 + B3)[threadIdx.x] = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
+    __syncthreads();   // (the first tile's accumulators start from b1 right below, ahead of the chunk loop's first barrier)
     const float4* W3t = reinterpret_cast<const float4*>(lds4 + W3T);
     const float* b1s = reinterpret_cast<const float*>(lds4 + B1);
     const float* b2s = reinterpret_cast<const float*>(lds4 + B2);

@@ -34,5 +34,9 @@ s = s[s[:, 0] > 0]
 names = ["A: window load + split", "A: layers 1-3", "A: outputs", "B: window load + split", "B: layers 1-3", "B: outputs", "fences",
          "env step", "fences"]
 rows = {nm: [float(np.percentile(s[:, k + 1] - s[:, k], q)) for q in (10, 50, 90)] for k, nm in enumerate(names)}
+rows["B: layer 1 (20 steps)"] = [float(np.percentile(s[:, 10] - s[:, 4], q)) for q in (10, 50, 90)]
+rows["B: layer 2 chain 0"] = [float(np.percentile(s[:, 11] - s[:, 10], q)) for q in (10, 50, 90)]
+rows["B: layer 2 chains 1-3"] = [float(np.percentile(s[:, 12] - s[:, 11], q)) for q in (10, 50, 90)]
+rows["B: tail (tile 3's tanh + layer 3)"] = [float(np.percentile(s[:, 5] - s[:, 12], q)) for q in (10, 50, 90)]
 print(json.dumps(dict(lib=os.environ.get("QENV_LIB", "default"), envs=N, sample=sample, waves=len(s),
                       step_cycles_median=float(np.median(s[:, 9] - s[:, 0])), phases_p10_p50_p90=rows), indent=1))

@@ -12,7 +12,8 @@ python3 -c "import sys; sys.path.insert(0, '$ROOT'); import __graft_entry__ as g
 OBJS=""
 for u in qenv_env qenv_env_mix qenv_env_f64 qenv_env_lean qenv_ppo qenv_train; do
   if echo " $UNITS " | grep -q " $u.hip "; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=on -Wno-unused-function $FLAGS -c $CSRC/$u.hip -o $OUT/obj_$NAME/$u.o &
+    UF=""; case $u in qenv_env*) UF="-mllvm -amdgpu-mfma-vgpr-form";; esac   # (as __graft_entry__.UNIT_FLAGS)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=on -Wno-unused-function $UF $FLAGS -c $CSRC/$u.hip -o $OUT/obj_$NAME/$u.o &
     OBJS="$OBJS $OUT/obj_$NAME/$u.o"
   else
     OBJS="$OBJS $CSRC/_build/$u.o"
