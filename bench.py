@@ -540,16 +540,30 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
         heads = 2 if controller == "ppo_rollout" else 1
         e0, r0 = (env, ro) if shards == 1 else (ro.ros[0].env, ro.ros[0])   # one launch = one shard's envs
         n_l = e0.n_envs
-        mlp_us = kernel_launch_us(lambda: e0.mlp_forward(r0.w, "actor", out=r0.mean), 1, "fused")
+        if fused_ppo:   # ONE launch carries `chunk` steps of policy + env step for this shard's envs (k_ppo_fused)
+            def one_launch():
+                r0.t = 0
+                r0.run_deterministic(chunk) if controller == "ppo_actor" else r0.run(chunk)
+            mlp_us = kernel_launch_us(one_launch, 1, "fused")
+            if controller == "ppo_actor":   # (the timed launches moved the envs on: back to an episode start)
+                env.reset(x0_dev, return_history=False, push_window=True)
+                ep["n"] = 0
+            tiles = ((n_l + 31) // 32) * chunk
+        else:
+            mlp_us = kernel_launch_us(lambda: e0.mlp_forward(r0.w, "actor", out=r0.mean), 1, "fused")
+            tiles = (n_l + 31) // 32
         t_s = mlp_us * 1e-6
-        tiles = (n_l + 31) // 32
         cyc_tile = sum(n * c for n, c, _ in MLP_MFMA.values())
         flop_tile = sum(n * f for n, _, f in MLP_MFMA.values())
         busy = tiles * cyc_tile / (1024 * MAX_CLOCK_GHZ * 1e9 * t_s)
         executed = tiles * flop_tile / t_s / 1e12
-        tfl = MLP_FLOPS * n_l / t_s / 1e12
+        tfl = MLP_FLOPS * n_l * (chunk if fused_ppo else 1) / t_s / 1e12
         roofline = {"bound": "mfma", "achieved": executed, "peak": executed / busy, "unit": "TFLOP/s", "frac": busy,
-                    "traffic": None, "kernel": "k_mlp_v3 (actor forward 75-128-128-4)", "kernel_us": mlp_us,
+                    "traffic": None,
+                    "kernel": ("k_ppo_fused (per step and 64-env block: actor forward 75-128-128-4 of two 32-env tiles, then the env "
+                               "step; one launch per %d steps)" % chunk) if fused_ppo else "k_mlp_v3 (actor forward 75-128-128-4)",
+                    "kernel_us": mlp_us, "env_steps_per_launch": n_l * (chunk if fused_ppo else 1),
+                    "kernel_us_per_step": mlp_us / (chunk if fused_ppo else 1),
                     "envs_per_launch": n_l, "mlp_forwards_per_env_step": heads,
                     "achieved_is": "EXECUTED matrix-core flops per launch (the instruction mix below, padded tiles included) / "
                                    "launch time; `peak` = that same mix with the matrix pipe of all 1024 SIMDs busy every cycle "
