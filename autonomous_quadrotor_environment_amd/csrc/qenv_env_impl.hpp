@@ -510,23 +510,30 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
     } else {
         mlp3_build_image(lds4, fa.ml.W1, fa.ml.b1, fa.ml.W2, fa.ml.b2, fa.ml.W3, fa.ml.b3, fa.ml.n_out, (int)threadIdx.x, 256);
     }
-    uint32_t* rowtab = reinterpret_cast<uint32_t*>(lds4 + IMAGE_UINT4);   // [half][40]: byte offset of window element k at ring head 0
-    if (threadIdx.x < 80) {
-        const int hf = threadIdx.x / 40, slot = threadIdx.x % 40;
-        const int k = 16 * (slot >> 3) + 8 * hf + (slot & 7);
-        rowtab[threadIdx.x] = k < KW ? (uint32_t)k * N32 * 4u : 0x80000000u;
-    }
     __syncthreads();
-    const uint4* rowq = reinterpret_cast<const uint4*>(rowtab) + 10 * half;
-    const uint32_t ring_bytes = (uint32_t)KW * N32 * 4u;
-    const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc((void*)fa.ml.win, 0, (int)ring_bytes, 0x00020000);
     const int64_t n_blocks = (N + 63) / 64;
     const int64_t wave_stride = (int64_t)gridDim.x * 4;
 #pragma unroll 1
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blocks; blk += wave_stride) {
+        // ---- the block's 64 windows live in REGISTERS for the whole horizon: w[k] = element k (time order) of this lane's env.
+        // Read from the ring once; per step the newest slice (15 rows, just written by this wave's step) is read back and the
+        // window shifts by one slice.  (Reading the two tiles' windows from the ring every step was 80 loads of 256 B per wave
+        // and step on a CU path of ~12 B per clock: ~2.5 k cycles per tile in front of its first MFMA.)
+        const int64_t eb = blk * 64 + lane;
+        const bool ev = eb < N;
+        const int64_t ebc = ev ? eb : N - 1;
+        float w[KW];
+#pragma unroll
+        for (int sl = 0; sl < TW; ++sl) {
+            int slot = fa.ml.head + sl;
+            if (slot >= TW) slot -= TW;
+            const float* src = fa.ml.win + (int64_t)slot * 15 * N + ebc;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) w[15 * sl + r] = src[(int64_t)r * N];
+        }
 #pragma unroll 1
         for (int t = 0; t < fa.n_steps; ++t) {
-            asm volatile("" ::: "memory");   // (the weights and the table in LDS are loop-invariant: nothing of them is to be hoisted)
+            asm volatile("" ::: "memory");   // (the weights in LDS are loop-invariant: nothing of them is to be hoisted)
             const int head = (fa.ml.head + t) % TW;   // wave-uniform
             // ---- this step's view of the per-step arrays
             MlpArgs m = fa.ml;
@@ -540,52 +547,37 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
             }
             if (m.obs_store) m.obs_store = (float*)((char*)fa.ml.obs_store + fa.adv_obs * t);
             if (fa.obs_slices && t > 0) m.obs_rows_from = 15 * (TW - 1);
+            // ---- the observation copy: rows >= obs_rows_from of the window, from the env layout (one 256-byte row store per element)
+            if (m.obs_store && ev) {
+                float* __restrict__ obs_c = m.obs_store + eb;
+#pragma unroll
+                for (int k = 0; k < KW; ++k)
+                    if (k >= m.obs_rows_from) obs_c[(int64_t)k * N] = w[k];
+            }
             // ---- the policy on the block's two 32-env tiles
             FUSED_STAMP(0);
+            // the MFMA's B operand wants element 16 sk + 8 half + i of env col in lane (col, half): v_permlane32_swap of
+            // (w[16 sk + i], w[16 sk + 8 + i]) leaves tile 0's operand in the first register (lanes 32-63 receive the second
+            // register's lower half: envs 0-31, elements + 8) and tile 1's in the second (lanes 0-31 receive the first register's
+            // upper half: envs 32-63)
 #pragma unroll 1
             for (int tl = 0; tl < 2; ++tl) {
                 const int64_t e = blk * 64 + 32 * tl + col;
                 if (blk * 64 + 32 * tl >= N) break;   // (wave-uniform: a ragged last block has one tile)
+                float xw[KS16][8];   // (built per tile: both tiles' operands at once would be 40 more live registers)
+#pragma unroll
+                for (int sk = 0; sk < KS16; ++sk)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float a0 = 16 * sk + i < KW ? w[16 * sk + i < KW ? 16 * sk + i : 0] : 0.f;
+                        const float a1 = 16 * sk + 8 + i < KW ? w[16 * sk + 8 + i < KW ? 16 * sk + 8 + i : 0] : 0.f;
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+                        xw[sk][i] = __uint_as_float(tl ? r[1] : r[0]);
+                    }
                 const bool valid = e < N;
-                const uint32_t e32 = (uint32_t)(valid ? e : N - 1);
-                // (requesting the second tile's window while the first tile computes was tried: the 40 live registers and the
-                //  loads landing in the middle of the matrix work cost the first tile more than the second one gained)
-                float xw[KS16][8];
-                {
-                    const uint32_t hb = (uint32_t)head * 15u * N32 * 4u + (valid ? (uint32_t)e * 4u : 0x80000000u);
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) {
-                        const uint4 r = rowq[q];
-                        const uint32_t t0[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const uint32_t off = t0[c] + hb, offw = off - ring_bytes;
-                            xw[(4 * q + c) >> 3][(4 * q + c) & 7] =
-                                __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ring, off < offw ? off : offw, 0, 0));
-                        }
-                    }
-                }
-                bf16x8 xsp[KS16][3];
-                {
-                    uint32_t n32 = N32;
-                    uint32_t kh = 8u * (uint32_t)half;
-                    asm volatile("" : "+s"(n32), "+v"(kh));
-                    float* __restrict__ obs_c = m.obs_store;
-#pragma unroll
-                    for (int sk = 0; sk < KS16; ++sk) {
-                        if (obs_c && valid) {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const uint32_t k = (uint32_t)(16 * sk + i) + kh;
-                                if (k < (uint32_t)KW && k >= (uint32_t)m.obs_rows_from) obs_c[k * n32 + e32] = xw[sk][i];
-                            }
-                        }
-                        split3x8(xw[sk], xsp[sk][0], xsp[sk][1], xsp[sk][2]);
-                    }
-                }
                 FUSED_STAMP(1 + 3 * tl);
                 float o[4];
-                mlp3_tile_forward(lds4, lane, half, xsp, o);
+                mlp3_tile_forward(lds4, lane, half, xw, o);
                 FUSED_STAMP(2 + 3 * tl);
                 float outv[4];
 #pragma unroll
@@ -620,6 +612,16 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
             }
             FUSED_STAMP(8);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            {   // the slice this step pushed into ring slot `head` becomes the window's newest; the window shifts by one slice
+                const float* src = fa.ml.win + (int64_t)head * 15 * N + ebc;
+                float nw[15];
+#pragma unroll
+                for (int r = 0; r < 15; ++r) nw[r] = src[(int64_t)r * N];
+#pragma unroll
+                for (int k = 0; k < KW - 15; ++k) w[k] = w[k + 15];
+#pragma unroll
+                for (int r = 0; r < 15; ++r) w[KW - 15 + r] = nw[r];
+            }
             FUSED_STAMP(9);
         }
     }

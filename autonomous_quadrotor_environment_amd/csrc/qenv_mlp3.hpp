@@ -150,12 +150,13 @@ __device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, co
 // MFMAs it issued the chain as a burst and the vector work as a block: 20.5 k cycles per tile, the sum of the two).  So every
 // 16-k step is its own region here: six MFMAs, a sixth .. an eighth of the previous tile's vector work, and the LDS reads of the
 // NEXT step's three weight fragments (a step's MFMAs never wait for their own reads).
-// lds4: the image (mlp3 layout); xsp: the tile's window as bf16 terms; o: the four outputs before the final tanh, valid in the
-// lower lane half.
+// lds4: the image (mlp3 layout); xw: the tile's window, element (sk, i) of a lane = window[16 sk + 8 half + i] of its env (fp32;
+// split into bf16 terms here: k-step 0's up front, k-step sk + 1's in the shadows of chain 0's step sk); o: the four outputs
+// before the final tanh, valid in the lower lane half.
 #ifndef MLP3_STAMP
 #define MLP3_STAMP(slot) do { } while (0)   // (diagnostic builds of the including unit define it: s_memtime stamps)
 #endif
-__device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, int half, const bf16x8 (&xsp)[mlp3::KS16][3],
+__device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, int half, const float (&xw)[mlp3::KS16][8],
                                                   float (&o)[4]) {
     using namespace mlp3;
     const uint4* W1f = lds4 + W1F;
@@ -199,6 +200,20 @@ __device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, i
     auto pin_f = [](float& x) { asm volatile("" : "+v"(x)); };
     auto pin_u = [](unsigned& x) { asm volatile("" : "+v"(x)); };
     auto cvt_pk = [](float lo, float hi) { unsigned d; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi)); return d; };
+    unsigned xspu[KS16][3][4];   // the window as bf16 terms (hi, mid, lo), [k-step][term][dword]
+    auto xsp = [&](int sk, int k) {
+        const u32x4 u = {xspu[sk][k][0], xspu[sk][k][1], xspu[sk][k][2], xspu[sk][k][3]};
+        return __builtin_bit_cast(bf16x8, u);
+    };
+    auto split_x_pair = [&](int sk, int d) {   // split3x8's arithmetic on elements 2 d, 2 d + 1 of k-step sk
+        const float x0 = xw[sk][2 * d], x1 = xw[sk][2 * d + 1];
+        const unsigned h = cvt_pk(x0, x1);
+        const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = cvt_pk(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+        xspu[sk][0][d] = h; xspu[sk][1][d] = m; xspu[sk][2][d] = cvt_pk(s0, s1);
+        pin_u(xspu[sk][0][d]); pin_u(xspu[sk][1][d]); pin_u(xspu[sk][2][d]);
+    };
     float th1[NT][16];       // tanh of layer 1's accumulators
     float rs1[8][2];         // the split in flight: a pair's remainders after the hi term
     unsigned mp1[8];         // ... and its mid terms
@@ -282,16 +297,25 @@ __device__ __forceinline__ void mlp3_tile_forward(const uint4* lds4, int lane, i
     for (int k = 0; k < 4; ++k) o[k] = half ? 0.f : b3s[k];
     Frag cur = ld(f1(0, 0));
     bias(acc1[0], b1s, 0);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) split_x_pair(0, d);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- layer 1: chain t beside tanh + split of tile t - 1
+    // ---- layer 1: chain 0 beside the split of the window's k-steps 1-4 (a pair of elements in slots 0, 1, 3, 4 of step sk for
+    // k-step sk + 1); chain t beside tanh + split of tile t - 1
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int sk = 0; sk < KS16; ++sk) {
+            if (sk == 0 && t == 1) MLP3_STAMP(13);
+            if (sk == 0 && t == 2) MLP3_STAMP(14);
+            if (sk == 3 && t == 2) MLP3_STAMP(15);
             const Frag nxt = ld(sk + 1 < KS16 ? f1(t, sk + 1) : (t + 1 < NT ? f1(t + 1, 0) : f2(0, 0)));
             if (sk == 3 && t + 1 < NT) bias(acc1[t + 1], b1s, t + 1);   // the next chain's start values, a step ahead
             __builtin_amdgcn_sched_barrier(0);
-            step6(acc1[t], cur, xsp[sk][0], xsp[sk][1], xsp[sk][2], [&](int slot) { if (t > 0) finish1(t - 1, 6 * sk + slot, 30); });
+            step6(acc1[t], cur, xsp(sk, 0), xsp(sk, 1), xsp(sk, 2), [&](int slot) {
+                if (t > 0) finish1(t - 1, 6 * sk + slot, 30);
+                else if (sk + 1 < KS16 && slot != 2 && slot != 5) split_x_pair(sk + 1, slot - (slot > 2));
+            });
             if (sk + 1 == KS16) asm volatile("" : "+v"(acc1[t]));   // (the chain in VGPRs: an accumulator in AGPRs costs a v_accvgpr_read
                                                                     //  per value, 8 cycles each beside an MFMA)
             cur = nxt;

@@ -38,5 +38,8 @@ rows["B: layer 1 (20 steps)"] = [float(np.percentile(s[:, 10] - s[:, 4], q)) for
 rows["B: layer 2 chain 0"] = [float(np.percentile(s[:, 11] - s[:, 10], q)) for q in (10, 50, 90)]
 rows["B: layer 2 chains 1-3"] = [float(np.percentile(s[:, 12] - s[:, 11], q)) for q in (10, 50, 90)]
 rows["B: tail (tile 3's tanh + layer 3)"] = [float(np.percentile(s[:, 5] - s[:, 12], q)) for q in (10, 50, 90)]
+rows["B: L1 chain 0 (bare)"] = [float(np.percentile(s[:, 13] - s[:, 4], q)) for q in (10, 50, 90)]
+rows["B: L1 chain 1"] = [float(np.percentile(s[:, 14] - s[:, 13], q)) for q in (10, 50, 90)]
+rows["B: L1 chain 2 steps 0-2 (tanh slots)"] = [float(np.percentile(s[:, 15] - s[:, 14], q)) for q in (10, 50, 90)]
 print(json.dumps(dict(lib=os.environ.get("QENV_LIB", "default"), envs=N, sample=sample, waves=len(s),
                       step_cycles_median=float(np.median(s[:, 9] - s[:, 0])), phases_p10_p50_p90=rows), indent=1))
