@@ -554,15 +554,26 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
                 for (int k = 0; k < KW; ++k)
                     if (k >= m.obs_rows_from) obs_c[(int64_t)k * N] = w[k];
             }
+            // ---- the env step's own inputs (state and bookkeeping rows: they do not depend on the policy) are requested now and
+            // land behind the policy tiles; the action reaches the step in registers (below)
+            StepArgs<T, S> s = fa.st;
+            s.actions = nullptr;
+            if (s.out_reward) s.out_reward = (S*)((char*)fa.st.out_reward + fa.adv_row * t);
+            if (s.out_mask) s.out_mask = (S*)((char*)fa.st.out_mask + fa.adv_row * t);
+            if (s.out_valid) s.out_valid = (S*)((char*)fa.st.out_valid + fa.adv_row * t);
+            s.win_slot = head;
+            s.ar_episode = fa.st.ar_episode + (uint64_t)t;
+            StepIn<T, S> in;
+            step_load(s, eb, in);
             // ---- the policy on the block's two 32-env tiles
             FUSED_STAMP(0);
             // the MFMA's B operand wants element 16 sk + 8 half + i of env col in lane (col, half): v_permlane32_swap of
             // (w[16 sk + i], w[16 sk + 8 + i]) leaves tile 0's operand in the first register (lanes 32-63 receive the second
             // register's lower half: envs 0-31, elements + 8) and tile 1's in the second (lanes 0-31 receive the first register's
             // upper half: envs 32-63)
+            float o0[4], o1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int tl = 0; tl < 2; ++tl) {
-                const int64_t e = blk * 64 + 32 * tl + col;
                 if (blk * 64 + 32 * tl >= N) break;   // (wave-uniform: a ragged last block has one tile)
                 float xw[KS16][8];   // (built per tile: both tiles' operands at once would be 40 more live registers)
 #pragma unroll
@@ -574,40 +585,46 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
                         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
                         xw[sk][i] = __uint_as_float(tl ? r[1] : r[0]);
                     }
-                const bool valid = e < N;
                 FUSED_STAMP(1 + 3 * tl);
                 float o[4];
                 mlp3_tile_forward(lds4, lane, half, xw, o);
                 FUSED_STAMP(2 + 3 * tl);
-                float outv[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v = o[k];
-                    if (m.final_tanh) v = tanhf(v);
-                    outv[k] = v;
-                    if (valid && half == 0 && k < m.n_out && m.out) {
-                        if (m.out_f64) ((double*)m.out)[(int64_t)k * N + e] = (double)v;
-                        else ((float*)m.out)[(int64_t)k * N + e] = v;
-                    }
-                }
-                if constexpr (SAMPLE) {
-                    if (valid && half == 0) sample_store(m, e, outv);
-                }
+                for (int k = 0; k < 4; ++k) { if (tl == 0) o0[k] = o[k]; else o1[k] = o[k]; }
                 FUSED_STAMP(3 + 3 * tl);
             }
-            // ---- the env step of the block's 64 envs on the actions just written
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            FUSED_STAMP(7);
+            // ---- the outputs of both tiles at once, in the env layout (lane = env of the block): tile 0's are valid in lanes 0-31
+            // of o0, tile 1's in lanes 0-31 of o1 -- v_permlane32_swap puts the latter into lanes 32-63.  One pass of the exact
+            // tanh, of the stores and of ActorCritic.act's sampling on 64 lanes instead of two passes on 32 (k_mlp_v3's arithmetic
+            // per env: the same values)
             {
-                StepArgs<T, S> s = fa.st;
-                s.actions = (const S*)(SAMPLE ? m.out_action : m.out);
-                if (s.out_reward) s.out_reward = (S*)((char*)fa.st.out_reward + fa.adv_row * t);
-                if (s.out_mask) s.out_mask = (S*)((char*)fa.st.out_mask + fa.adv_row * t);
-                if (s.out_valid) s.out_valid = (S*)((char*)fa.st.out_valid + fa.adv_row * t);
-                s.win_slot = head;
-                s.ar_episode = fa.st.ar_episode + (uint64_t)t;
-                StepIn<T, S> in;
-                step_load(s, blk * 64 + lane, in);
+                float outv[4];
+                S act[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o0[k]), __float_as_uint(o1[k]), false, false);
+                    float v = __uint_as_float(r[0]);
+                    if (m.final_tanh) v = tanhf(v);
+                    outv[k] = v;
+                    act[k] = (S)v;
+                    if (ev && k < m.n_out && m.out) ((S*)m.out)[(int64_t)k * N + eb] = (S)v;
+                }
+                if constexpr (SAMPLE) {
+                    S logp[4];
+                    if (ev) {
+                        sample_compute<S>(m, eb, outv, act, logp);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            ((S*)m.out_action)[(int64_t)k * N + eb] = act[k];
+                            if (m.out_logprob) ((S*)m.out_logprob)[(int64_t)k * N + eb] = logp[k];
+                        }
+                    }
+                }
+                // ---- the env step of the block's 64 envs on the actions just computed (what qenv_step would read back from
+                // the action buffer: the stored value, converted to the arithmetic type)
+                FUSED_STAMP(7);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) in.raw[k] = (T)act[k];
                 if (in.active) step_one<T, S, INTEG, false, LEAN>(s, in);
             }
             FUSED_STAMP(8);

@@ -90,6 +90,35 @@ __device__ __forceinline__ void sample_store(const MlpArgs& a, int64_t e, const 
     }
 }
 
+// sample_store's arithmetic with the results handed back instead of stored (k_ppo_fused: the action goes straight into the env step):
+// act / logp in the handle's storage type S (double iff a.out_f64)
+template <typename S>
+__device__ __forceinline__ void sample_compute(const MlpArgs& a, int64_t e, const float mean[4], S act[4], S logp[4]) {
+    float z[4];
+    if (a.noise) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = (float)((const S*)a.noise)[(int64_t)k * a.N + e];
+    } else {
+        const uint64_t g = (uint64_t)(a.env_offset + e);
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)a.step, (uint32_t)(a.step >> 32)};
+        philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32) ^ 0xAC710Du);
+        box_muller(c[0], c[1], z[0], z[1]);
+        box_muller(c[2], c[3], z[2], z[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if constexpr (sizeof(S) == 8) {
+            const double eps = (double)z[k];
+            act[k] = (double)mean[k] + a.std * eps;
+            logp[k] = -0.5 * eps * eps + a.log_norm;
+        } else {
+            const float eps = z[k];
+            act[k] = mean[k] + (float)a.std * eps;
+            logp[k] = -0.5f * eps * eps + (float)a.log_norm;
+        }
+    }
+}
+
 // the image from the fp32 torch-layout weights, written by `nthr` threads (a workgroup into LDS, or a small grid into
 // global memory: qenv_mlp_prepare).  Fragment layouts: see k_mlp.
 __device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, const float* b1, const float* W2, const float* b2,
