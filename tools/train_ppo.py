@@ -57,11 +57,9 @@ for u in range(1, a.updates + 1):
     if a.eval_every and (u % a.eval_every == 0 or u == 1):
         ev = aq.BatchedQuad(a.eval_envs, 0.01, 1000, training=False, direct_control=1, T=5, integrator=a.integrator, **HKW)
         ev.robust_control = a.eval_robust
-        er = aq.PolicyRollout(ev, aq.ActorCriticWeights(w.actor, None), 1, seed=a.seed + 77)
+        er = aq.PolicyRollout(ev, aq.ActorCriticWeights(w.actor, None), 500, seed=a.seed + 77)
         er.start(ev.sample_init_states(a.seed + 1000, u))
-        for _ in range(500):
-            er.t = 0
-            er.step(deterministic=True)
+        er.run_deterministic(500)   # the evaluation episode as one library call (qenv_policy_rollout)
         v = torch.linalg.norm(ev.state[1:6:2], dim=0)
         rec.update(eval_solved=float(ev.solved.float().mean()), eval_v_lt_0p05=float((v < 0.05).float().mean()),
                    eval_broken=float(ev.done.float().mean()), eval_return=float(ev.episode_return.mean()))
