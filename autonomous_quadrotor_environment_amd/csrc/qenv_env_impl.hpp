@@ -479,9 +479,10 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
 // only the wave's own memory ordering between the phases: its stores of one phase are the loads of the next, on the same CU --
 // a WORKGROUP-scope fence (a wait for the stores; the CU's vector L1 is coherent with the CU's own writes).  An agent-scope
 // fence writes back / invalidates the XCD's L2 every time (measured: the window loads that follow took 25 k cycles).
-// The ring offsets: k_mlp_v3's table holds the 80 row offsets of ONE ring head; here the head moves inside the launch, so the
-// table is that of head 0 and a load adds head * 15 rows and wraps (v_add, v_sub, v_min_u32: an offset beyond the ring comes
-// back as the smaller of (off, off - ring bytes), whichever did not wrap through 2^32).
+// The block's 64 observation windows stay in registers for the whole horizon (75 floats per lane, env layout): the MFMA operands
+// of the two tiles come out of v_permlane32_swap, the observation copy is stored from the env layout, and per step only the slice
+// the env step has just pushed into the ring is read back.  Both tiles' outputs are finished in one 64-lane pass (exact tanh,
+// stores, sampling); the action reaches the env step in registers; the step's state rows are requested ahead of the tiles.
 template <typename T, typename S> struct FusedArgs {
     StepArgs<T, S> st;   // the step kernel's arguments of step 0
     MlpArgs ml;          // the policy forward's arguments of step 0
