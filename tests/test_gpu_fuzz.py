@@ -24,6 +24,7 @@ TOOLS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
     ("fuzz_mlp.py", ["101", "50"]),                 # every MLP forward path vs torch fp64 (ring phases, T, hidden, K, N)
     ("fuzz_gae.py", ["101", "60"]),                 # GAE + normalisation, atomic and ordered moments
     ("fuzz_learner.py", ["101", "30"]),             # learner gradients vs torch autograd (fp64), random batch shapes
+    ("fuzz_fused_rollout.py", ["101", "16"]),       # the fused rollout launch vs the per-step launches, bit for bit
 ]] + [
     # the parity-qualified lean handle (fp64 rows, lean fp64 arithmetic) through the same fp64 fuzzers and tolerances
     ("fuzz_parity.py", ["102", "100"], "lean"),
