@@ -25,6 +25,21 @@ __device__ unsigned long long g_fused_stamps[1024 * 16];
 #else
 #define FUSED_STAMP(slot) do { } while (0)
 #endif
+// Diagnostic build only (-DQENV_ROLLOUT_STAMPS, tests/tools/rollout_stamps.py): where a k_rollout launch spends its time, per wave
+// (s_memtime = shader cycles for the phases, s_memrealtime = the 100 MHz wall clock for entry / exit across the waves).
+#if defined(QENV_ROLLOUT_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
+__device__ unsigned long long g_rollout_stamps[1024 * 8];
+#define ROLLOUT_STAMP(slot, real)                                                                              \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        const unsigned long long t_ = (real) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+        const unsigned wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                              \
+        if ((threadIdx.x & 63) == 0 && wv_ < 1024) g_rollout_stamps[wv_ * 8 + (slot)] = t_;                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#else
+#define ROLLOUT_STAMP(slot, real) do { } while (0)
+#endif
 
 }  // namespace qenv
 #if defined(QENV_FUSED_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
@@ -649,6 +664,7 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
 template <typename T, typename S, int INTEG, int CTRL, bool ROBUST, bool LEAN = false>
 __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutArgs<T, S> a) {
     using M = typename MathSel<T, LEAN>::type;
+    ROLLOUT_STAMP(0, true); ROLLOUT_STAMP(1, false);
     const int wpb = blockDim.x >> 6;  // waves per workgroup (env_block())
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.lane_shift < 6) {
@@ -792,18 +808,26 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         }
     } else {
         for (int s = 0; s < a.n_steps; ++s) {
+            if (s == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ROLLOUT_STAMP(2, false); }
+            if (s == 1) ROLLOUT_STAMP(3, false);
+            if (s == 2) ROLLOUT_STAMP(4, false);
             begin_step(s);
             // (a robust plant has no FSAL across steps: the wind changes from step to step)
             if constexpr (ROBUST) begin_step_wind(pl, bk.i + 1);
             integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !ROBUST && s > 0);
             end_step(s);
         }
+        ROLLOUT_STAMP(5, false);
     }
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         if (MIXED) st(a.ws, ROW_STATE + k, N, e, ys[k]);
         else st(a.ws, ROW_STATE + k, N, e, y[k]);
     }
+#if defined(QENV_ROLLOUT_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ROLLOUT_STAMP(6, false); ROLLOUT_STAMP(7, true);
+#endif
     if (dyn_only) return;
     if constexpr (ROBUST) store_gust(a.ws, a.wsi, N, e, pl);
     store_book(a.ws, a.wsi, N, e, bk, true);

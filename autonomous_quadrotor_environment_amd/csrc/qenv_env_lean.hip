@@ -11,3 +11,9 @@ extern "C" int qenv_debug_fused_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qenv::g_fused_stamps), sizeof(unsigned long long) * (size_t)n);
 }
 #endif
+
+#ifdef QENV_ROLLOUT_STAMPS
+extern "C" int qenv_debug_rollout_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qenv::g_rollout_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
