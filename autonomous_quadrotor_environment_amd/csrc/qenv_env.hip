@@ -234,7 +234,7 @@ static int ar_warmup(qenv_s* q, int parity) {
 static bool ppo_fused_ok(const qenv_s* q, int k_in, int hidden) {
     static const int on = getenv("QENV_PPO_FUSED") ? atoi(getenv("QENV_PPO_FUSED")) : 1;
     return on && hidden == 128 && k_in == 75 && q->cfg.T == 5 && q->cfg.integrator == QENV_RK45 && q->cfg.direct_control && !q->robust &&
-           !q->sens.ws && q->outer.kind == QENV_OUTER_NONE && (int64_t)300 * q->N <= ((int64_t)1 << 30);
+           !q->sens.ws && q->outer.kind == QENV_OUTER_NONE;
 }
 static const void* fused_image(const qenv_s* q, const float* W1) {
     for (int h = 0; h < 2; ++h)

@@ -511,9 +511,8 @@ template <typename T, typename S, int INTEG, bool LEAN, bool SAMPLE>
 __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
     using namespace mlp3;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
     const int64_t N = fa.ml.N;
-    const uint32_t N32 = (uint32_t)N;
     // ---- the weights, once per launch
     if (fa.ml.image) {
         for (int base = threadIdx.x; base < IMAGE_UINT4; base += 8 * 256) {
@@ -1446,7 +1445,7 @@ template <typename T, typename S, bool LEAN = false> int do_ppo_fused(qenv_s* q,
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     int64_t blocks = (n_blocks + 3) / 4;
     if (blocks > cus) blocks = cus;   // one resident workgroup per CU (its LDS holds the weights); a wave walks its blocks
-    const size_t lds = sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4 + 80 * sizeof(uint32_t);
+    const size_t lds = sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4;
     hipError_t e;
     if (deterministic) {
         auto fn = k_ppo_fused<T, S, INT_RK45, LEAN, false>;
