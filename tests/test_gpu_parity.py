@@ -724,6 +724,15 @@ def test_c_host_drives_the_library_without_python(tmp_path):
     for args, tag in (([], "handle=lean"), (["f32"], "handle=f32")):   # the parity-qualified handle first
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "finite=1" in r.stdout and tag in r.stdout, (r.stdout, r.stderr[-500:])
+    # examples/host_policy_rollout.c: the policy-in-the-loop path (qenv_reset_sampled, qenv_mlp_prepare, qenv_policy_rollout: the
+    # evaluation loop as one launch per 25 steps) from plain C
+    exe2 = str(tmp_path / "host_policy_rollout")
+    r = subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                        os.path.join(ROOT, "examples", "host_policy_rollout.c"), "-L", libdir, "-lqenv", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        "-lm", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe2], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    r = subprocess.run([exe2], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "finite=1" in r.stdout and "G env-steps/s" in r.stdout, (r.stdout, r.stderr[-500:])
 
 
 def test_sharded_quad_slices_reproduce_the_global_batch(aq):
