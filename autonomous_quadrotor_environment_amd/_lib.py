@@ -97,6 +97,7 @@ SYMBOLS = {
     "qenv_outer_pospi": (_i, [_vp, _vp, C.c_double, C.c_double, C.c_double]),
     "qenv_outer_reset": (_i, [_vp, _vp]),
     "qenv_set_robust": (_i, [_vp, _i]),
+    "qenv_set_ppo_fused": (_i, [_vp, _i]),
     "qenv_robust_params": (_i, [_vp, _vp, C.c_uint64, _i64, _vp]),
     "qenv_robust_gusts": (_i, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, _i64]),
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

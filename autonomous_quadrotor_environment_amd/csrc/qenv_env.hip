@@ -59,6 +59,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->env_flags[0] = (uint8_t*)workspace + L.flag_off; q->env_flags[1] = q->env_flags[0] + L.flag_stride;
     q->ar_pending = 0; q->ar_parity = 0; q->zero_on_act = nullptr;
     q->prep[0] = {nullptr, nullptr, 0}; q->prep[1] = {nullptr, nullptr, 0};
+    q->ppo_fused = getenv("QENV_PPO_FUSED") ? (atoi(getenv("QENV_PPO_FUSED")) != 0) : 1;
     q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
@@ -150,6 +151,12 @@ int qenv_outer_reset(qenv_t q, const uint8_t* mask) {
     return check_launch("k_outer_reset");
 }
 
+int qenv_set_ppo_fused(qenv_t q, int enabled) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_set_ppo_fused: null handle");
+    q->ppo_fused = enabled ? 1 : 0;
+    return QENV_OK;
+}
+
 int qenv_set_robust(qenv_t q, int enabled) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_set_robust: null handle");
     if (enabled && q->cfg.variant != QENV_MAIN)
@@ -230,10 +237,9 @@ static int ar_warmup(qenv_s* q, int parity) {
 
 // k_ppo_fused (policy + env step of a whole rollout in one launch, qenv_env_impl.hpp) covers the reference's controller
 // (75-128-128-4, T = 5) on the scipy-exact integrator, without the per-env extras the separate calls support.
-// QENV_PPO_FUSED=0 keeps the two launches per step (A/B runs, and what the fused launch is tested against).
+// qenv_set_ppo_fused(q, 0) / QENV_PPO_FUSED=0 keep the two launches per step (A/B runs, and what the fused launch is tested against).
 static bool ppo_fused_ok(const qenv_s* q, int k_in, int hidden) {
-    static const int on = getenv("QENV_PPO_FUSED") ? atoi(getenv("QENV_PPO_FUSED")) : 1;
-    return on && hidden == 128 && k_in == 75 && q->cfg.T == 5 && q->cfg.integrator == QENV_RK45 && q->cfg.direct_control && !q->robust &&
+    return q->ppo_fused && hidden == 128 && k_in == 75 && q->cfg.T == 5 && q->cfg.integrator == QENV_RK45 && q->cfg.direct_control && !q->robust &&
            !q->sens.ws && q->outer.kind == QENV_OUTER_NONE;
 }
 static const void* fused_image(const qenv_s* q, const float* W1) {
@@ -271,6 +277,8 @@ int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
     if (p->inband) {
         // in-band warm-up: policy + step, the restart in the step kernel's epilogue, the warm-up steps ride the next T steps
         if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+        // (k_ppo_fused with ONE step was measured for this call: 60 us against 53 for the two launches at 65 536 envs -- the
+        //  159 KiB of weights per workgroup and the 75 window rows are staged for a single step; it starts at qenv_ppo_rollout)
         StepExtra exi{};
         exi.ar_on = 2; exi.ar_seed = p->seed; exi.ar_episode = p->step; exi.ar_env_offset = p->env_offset;
         exi.ar_key_episode = p->key_by_episode; exi.out_valid = p->out_valid;

@@ -119,6 +119,9 @@ struct qenv_s {
     // qenv_mlp_prepare: per head (0 actor, 1 critic) the caller-owned image of the weights in k_mlp_v3's LDS layout, used by
     // the forward calls whose W1 pointer and n_out match
     struct { const float* W1; const void* image; int32_t n_out; } prep[2];
+    // qenv_ppo_rollout (in-band) / qenv_policy_rollout as ONE launch where k_ppo_fused applies
+    // (qenv_set_ppo_fused; initial value: QENV_PPO_FUSED, default 1)
+    int32_t ppo_fused;
 };
 
 namespace qenv {

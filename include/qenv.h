@@ -426,10 +426,14 @@ int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args *first, int n_steps);
  * Both this call and the in-band qenv_ppo_rollout run as ONE launch for the reference's controller (hidden 128, T = 5, RK45;
  * no robust_control / sensor / outer loop): a wave keeps its 64-env blocks for the whole horizon, per step the policy forward
  * of the block's two 32-env tiles and then the env step, the weights staged once per launch instead of once per step
- * (k_ppo_fused; QENV_PPO_FUSED=0 keeps the separate launches). */
+ * (k_ppo_fused; qenv_set_ppo_fused(q, 0) keeps the separate launches). */
 int qenv_policy_rollout(qenv_t q, int k_in, int hidden, const float *W1, const float *b1, const float *W2, const float *b2,
                         const float *W3, const float *b3, int n_steps, void *out_actions, void *out_reward,
                         uint8_t *out_done, void *out_mask);
+/* ABI 7.  Whether this handle's in-band qenv_ppo_rollout and qenv_policy_rollout run as the
+ * one fused launch where it applies (1, the default; the environment variable QENV_PPO_FUSED sets the initial value) or as the
+ * separate policy / env-step launches (0).  Results are bit-identical either way. */
+int qenv_set_ppo_fused(qenv_t q, int enabled);
 
 /* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------
  * The reference hard-codes `self.robust_control = False` (:183) and a user flips the attribute; this is that

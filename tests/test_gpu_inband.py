@@ -201,6 +201,8 @@ def test_ppo_rollout_call_equals_the_step_calls(aq, inband):
     outs = []
     for use_run in (False, True):
         env = aq.BatchedQuad(n, 0.01, 13, training=True, direct_control=1, T=5, **LEAN)
+        if not use_run:
+            env.set_ppo_fused(False)   # the step calls as the separate policy / env-step launches
         ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=21, env_offset=500, inband=inband)
         ro.start()
         snap = []
@@ -233,6 +235,8 @@ def test_slice_observation_store_equals_the_window_store(aq):
         w, _ = _weights(aq)            # a fresh copy per mode: the learner below updates it
         n_envs = 96 if mode == "small_slices" else n
         env = aq.BatchedQuad(n_envs, 0.01, n_max, training=True, direct_control=1, T=5, **LEAN)
+        if mode in ("dense", "small_slices"):
+            env.set_ppo_fused(False)   # (the references as separate launches)
         ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=5, inband=True, key_by_episode=True,
                               slice_obs=(mode != "dense"))
         assert ro.slice_obs == (mode != "dense")
@@ -272,24 +276,30 @@ def test_fused_rollout_launch_equals_the_separate_launches(aq, handle):
     kw = HANDLES[handle]
     n = 64 * 33 + 17
     res = []
-    for mode in ("step", "run"):
+    for mode in ("step", "run", "run1"):   # run1: every step its own fused launch (run(1))
         env = aq.BatchedQuad(n, 0.01, 13, training=True, direct_control=1, T=5, **kw)
+        env.set_ppo_fused(mode != "step")
         ro = aq.PolicyRollout(env, w, 40, store_obs=True, auto_reset=True, seed=21, env_offset=500, inband=True)
         ro.start()
         if mode == "run":
             ro.run(17); ro.run(23)
+        elif mode == "run1":
+            for _ in range(40):
+                ro.run(1)
         else:
             for _ in range(40):
                 ro.step()
         ret, adv = ro.finish(ddof=0, group=False, deterministic=True)
         res.append([x.clone() for x in (ro.actions, ro.logprobs, ro.rewards, ro.masks, ro.obs, ro.values, ret, adv, env.state,
                                         env.last_return, env.episodes, env.window, env.i, ro.valid)])
-    for k, (x, y) in enumerate(zip(*res)):
-        assert torch.equal(x, y), ("in-band", k)
+    for other in (1, 2):
+        for k, (x, y) in enumerate(zip(res[0], res[other])):
+            assert torch.equal(x, y), ("in-band", ("run", "run1")[other - 1], k)
     assert int(res[0][10].sum()) > n   # episodes did end and restart
     res = []
     for mode in ("step", "run"):
         env = aq.BatchedQuad(n, 0.01, 500, training=True, direct_control=1, T=5, **kw)
+        env.set_ppo_fused(mode != "step")
         ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None, env.device), 30)
         ro.start()
         if mode == "run":

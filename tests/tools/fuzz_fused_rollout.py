@@ -35,6 +35,7 @@ for case in range(n_cases):
     res = []
     for mode in ("step", "run"):
         env = aq.BatchedQuad(n, 0.01, n_max, training=bool(case & 1), direct_control=1, T=5, **kw)
+        env.set_ppo_fused(mode != "step")
         if sampling:
             ww = w if store else aq.ActorCriticWeights(w.actor, None, env.device)   # (no stored observations: no batched critic)
             ww.std = w.std

@@ -52,6 +52,11 @@ def main():
         ro5.t = 0
         ro5.run(128)
     out["config5_rollout_us_per_step"] = timed(c5, 5) / 128 * 1e6
+    def c5s():   # the same horizon as 128 step() calls (qenv_ppo_step: with the fused path each its own launch)
+        ro5.t = 0
+        for _ in range(128):
+            ro5.step()
+    out["config5_step_api_us_per_step"] = timed(c5s, 3) / 128 * 1e6
     def c5f():
         ro5.t = 0
         ro5.run(128)
@@ -65,6 +70,7 @@ def main():
             res = []
             for mode in ("step", "run"):
                 e = aq.BatchedQuad(n, 0.01, 13, training=True, direct_control=1, T=5, device=dev, **lean)
+                e.set_ppo_fused(mode != "step")
                 r = aq.PolicyRollout(e, w, 40, store_obs=True, auto_reset=True, seed=21, env_offset=500, inband=True)
                 r.start()
                 if mode == "run":
@@ -80,6 +86,7 @@ def main():
             res = []
             for mode in ("step", "run"):
                 e = aq.BatchedQuad(n, 0.01, 500, training=True, direct_control=1, T=5, device=dev, **lean)
+                e.set_ppo_fused(mode != "step")
                 r = aq.PolicyRollout(e, aq.ActorCriticWeights(w.actor, None, dev), 30)
                 r.start()
                 if mode == "run":
