@@ -297,18 +297,34 @@ def test_fused_rollout_launch_equals_the_separate_launches(aq, handle):
             assert torch.equal(x, y), ("in-band", ("run", "run1")[other - 1], k)
     assert int(res[0][10].sum()) > n   # episodes did end and restart
     res = []
-    for mode in ("step", "run"):
+    for mode in ("step", "run", "run_unfused"):   # run_unfused: qenv_policy_rollout's loop of the separate calls
         env = aq.BatchedQuad(n, 0.01, 500, training=True, direct_control=1, T=5, **kw)
-        env.set_ppo_fused(mode != "step")
+        env.set_ppo_fused(mode == "run")
         ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None, env.device), 30)
         ro.start()
-        if mode == "run":
+        if mode != "step":
             ro.run_deterministic(11); ro.run_deterministic(19)
         else:
             for _ in range(30):
                 ro.step(deterministic=True)
         res.append([x.clone() for x in (ro.actions, ro.rewards, ro.masks, ro.done, env.state, env.window, env.i, env.ang,
                                         env.ang_vel, env.reward, env.episode_return)])
-    for k, (x, y) in enumerate(zip(*res)):
-        assert torch.equal(x, y), ("deterministic", k)
+    for other in (1, 2):
+        for k, (x, y) in enumerate(zip(res[0], res[other])):
+            assert torch.equal(x, y), ("deterministic", ("run", "run_unfused")[other - 1], k)
     assert float(res[0][0].abs().max()) > 0.05 and bool(torch.isfinite(res[0][4]).all())
+    if handle == "lean":   # a policy the fused launch does not cover (hidden 64): the library call falls back to the separate launches
+        w64 = aq.ActorCriticWeights.random(64, 75, 4, seed=3)
+        res = []
+        for mode in ("step", "run"):
+            env = aq.BatchedQuad(300, 0.01, 500, training=True, direct_control=1, T=5, **kw)
+            ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w64.actor, None, env.device), 12)
+            ro.start()
+            if mode == "run":
+                ro.run_deterministic(12)
+            else:
+                for _ in range(12):
+                    ro.step(deterministic=True)
+            res.append([x.clone() for x in (ro.actions, ro.rewards, ro.masks, env.state, env.window)])
+        for k, (x, y) in enumerate(zip(*res)):
+            assert torch.equal(x, y), ("hidden 64", k)
