@@ -578,6 +578,7 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
             if (s.out_valid) s.out_valid = (S*)((char*)fa.st.out_valid + fa.adv_row * t);
             s.win_slot = head;
             s.ar_episode = fa.st.ar_episode + (uint64_t)t;
+            if (t > 0) s.ang_ok = 1;   // (as the host sets it after an unmasked full step: every prev_ang row is current from here on)
             StepIn<T, S> in;
             step_load(s, eb, in);
             // ---- the policy on the block's two 32-env tiles
