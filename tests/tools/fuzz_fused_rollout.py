@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 import autonomous_quadrotor_environment_amd as aq
+from autonomous_quadrotor_environment_amd import _lib as L
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -32,6 +33,7 @@ for case in range(n_cases):
     store = bool(rng.randint(2)) if sampling else False
     slices = bool(rng.randint(2)) if store else None
     inject = sampling and bool(rng.randint(2))
+    dyn_first = bool(rng.randint(4) == 0)   # a dynamics-only step in front: the launch starts with stale prev_ang rows (ang_ok = 0)
     res = []
     for mode in ("step", "run"):
         env = aq.BatchedQuad(n, 0.01, n_max, training=bool(case & 1), direct_control=1, T=5, **kw)
@@ -44,6 +46,8 @@ for case in range(n_cases):
         else:
             ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None, env.device), H)
         ro.start(None if sampling else env.sample_init_states(seed, 0, off))
+        if dyn_first:
+            env.step(None, flags=L.STEP_DYNAMICS_ONLY)
         noise = None
         if inject:
             g = torch.Generator(device="cpu"); g.manual_seed(seed)
@@ -67,6 +71,6 @@ for case in range(n_cases):
     ok = not diff
     bad += 0 if ok else 1
     print(json.dumps(dict(case=case, handle=handle, n=n, H=H, cuts=cuts, n_max=n_max, sampling=sampling, std=w.std, store=store,
-                          slices=slices, inject=inject, restarts=int(res[0][-3].sum()), mismatching_buffers=diff, ok=ok)), flush=True)
+                          slices=slices, inject=inject, dyn_first=dyn_first, restarts=int(res[0][-3].sum()), mismatching_buffers=diff, ok=ok)), flush=True)
 print(json.dumps(dict(cases=n_cases, mismatching=bad)))
 sys.exit(1 if bad else 0)
