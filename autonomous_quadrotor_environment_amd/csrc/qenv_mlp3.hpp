@@ -177,8 +177,9 @@ __device__ __forceinline__ void mlp3_build_image(uint4* img, const float* W1, co
 // operand, or tanh + layer 3) has to sit BETWEEN the MFMAs of this one.  k_mlp_v3 asks for that with one scheduling region per
 // chain (sched_group_barrier); with 512 registers to play with hipcc honours it only in small regions (in a region of 30-48
 // MFMAs it issued the chain as a burst and the vector work as a block: 20.5 k cycles per tile, the sum of the two).  So every
-// 16-k step is its own region here: six MFMAs, a sixth .. an eighth of the previous tile's vector work, and the LDS reads of the
-// NEXT step's three weight fragments (a step's MFMAs never wait for their own reads).
+// (MFMA, vector work) pair is its own region here, the work of a pair sized by what tools/ubench/mfma_fill_kinds.hip measured
+// to fit one MFMA's shadow (see finish1 / finish2 below), and the LDS reads of the NEXT 16-k step's three weight fragments are
+// issued a step ahead (a step's MFMAs never wait for their own reads).  20.5 k -> 14.7 k cycles per tile.
 // lds4: the image (mlp3 layout); xw: the tile's window, element (sk, i) of a lane = window[16 sk + 8 half + i] of its env (fp32;
 // split into bf16 terms here: k-step 0's up front, k-step sk + 1's in the shadows of chain 0's step sk); o: the four outputs
 // before the final tanh, valid in the lower lane half.
