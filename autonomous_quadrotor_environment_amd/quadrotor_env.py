@@ -23,6 +23,9 @@ J = np.array([[16.83e-3, 0, 0], [0, 16.83e-3, 0], [0, 0, 28.34e-3]])
 BB_POS, BB_VEL, BB_ANG = 5, 10, np.pi / 2
 
 
+_CTRL = {"const": L.CTRL_CONST, "lqr": L.CTRL_LQR, "pid": L.CTRL_PID, "pidpos": L.CTRL_PIDPOS}
+
+
 def _raw_stream(device):
     """The caller's current HIP stream on `device` as an integer handle."""
     try:
@@ -344,13 +347,15 @@ class BatchedQuad:
     def rollout(self, controller="const", n_steps=1, action=None, pid_first_action=False, flags=L.STEP_FULL):
         """n_steps fused env steps in one launch with an on-device controller
         ('const' | 'lqr' | 'pid'); state stays in registers between steps."""
-        ctrl = {"const": L.CTRL_CONST, "lqr": L.CTRL_LQR, "pid": L.CTRL_PID, "pidpos": L.CTRL_PIDPOS}[controller]
+        ctrl = _CTRL[controller]
         ca = None
         if action is not None:  # CONST: the 4-vector action; PIDPOS: the 7-vector target
             vals = [float(a) for a in np.asarray(action).ravel()]
             ca = (C.c_double * len(vals))(*vals)
         self._bind()
-        L.check(L.lib.qenv_rollout(self._h, ctrl, int(n_steps), ca, int(bool(pid_first_action)), flags), "qenv_rollout")
+        rc = L.lib.qenv_rollout(self._h, ctrl, n_steps, ca, 1 if pid_first_action else 0, flags)
+        if rc:
+            L.check(rc, "qenv_rollout")
 
     def track(self, targets, flags=L.STEP_FULL):
         """Position-PD trajectory tracking in one launch (PID_control.py:245-263): targets [n_steps, 7] =
