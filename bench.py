@@ -579,6 +579,14 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
                                             "fraction of anything: layers 1-2 run as 6 bf16 products of 3-way split fp32 "
                                             "operands (fp32-accurate), i.e. ~6x the algorithmic flops on a 16x faster pipe"},
                     "hbm_algorithmic_GBps_whole_step": bytes_per_step * value / world / 1e9}
+        st = recorded("r03_fused_stamps_sampling.json" if controller == "ppo_rollout" else "r03_fused_stamps_deterministic.json")
+        if fused_ppo and st:   # in-kernel s_memtime stamps of the same launch (tests/tools/fused_stamps.py), recorded
+            ph = st["phases_p10_p50_p90"]
+            tile = ph["A: layers 1-3"][1]
+            roofline["policy_tile"] = {"cycles_median": tile, "mfma_cycles": cyc_tile, "matrix_pipe_busy_in_tile": cyc_tile / tile,
+                                       "block_step_cycles_median": st["step_cycles_median"], "env_step_cycles_median": ph["env step"][1],
+                                       "source": "recorded: profiles/r03_fused_stamps_*.json (a 32-env tile of layers 1-3 on its lone "
+                                                 "wave; a block-step = two tiles + the env step of 64 envs)"}
     res = {"value": value, "ms_per_step": secs / steps * 1e3, "regions": len(regions),
            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3,
            "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,
