@@ -153,7 +153,7 @@ int qenv_outer_reset(qenv_t q, const uint8_t* mask) {
 
 int qenv_set_ppo_fused(qenv_t q, int enabled) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_set_ppo_fused: null handle");
-    q->ppo_fused = enabled ? 1 : 0;
+    q->ppo_fused = (enabled == 5 || enabled == 6) ? enabled : (enabled ? 1 : 0);
     return QENV_OK;
 }
 

@@ -503,6 +503,8 @@ template <typename T, typename S> struct FusedArgs {
     MlpArgs ml;          // the policy forward's arguments of step 0
     int32_t n_steps;
     int32_t obs_slices;  // stored observations as slices: step t > 0 stores its newest slice only (see qenv.h)
+    int32_t block_shift; // 6: a wave owns 64-env blocks (two policy tiles + one full-wave env step per step); 5: 32-env blocks (one
+                         // tile, the env step on half the lanes) -- small batches spread over twice the waves (do_ppo_fused)
     // bytes by which the per-step arrays advance from one step to the next (0: the array is scratch / not per step)
     int64_t adv_act, adv_logp, adv_noise, adv_obs, adv_row;
 };
@@ -526,7 +528,8 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
         mlp3_build_image(lds4, fa.ml.W1, fa.ml.b1, fa.ml.W2, fa.ml.b2, fa.ml.W3, fa.ml.b3, fa.ml.n_out, (int)threadIdx.x, 256);
     }
     __syncthreads();
-    const int64_t n_blocks = (N + 63) / 64;
+    const int bsh = fa.block_shift, benvs = 1 << bsh;
+    const int64_t n_blocks = (N + benvs - 1) >> bsh;
     const int64_t wave_stride = (int64_t)gridDim.x * 4;
 #pragma unroll 1
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blocks; blk += wave_stride) {
@@ -534,8 +537,8 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
         // Read from the ring once; per step the newest slice (15 rows, just written by this wave's step) is read back and the
         // window shifts by one slice.  (Reading the two tiles' windows from the ring every step was 80 loads of 256 B per wave
         // and step on a CU path of ~12 B per clock: ~2.5 k cycles per tile in front of its first MFMA.)
-        const int64_t eb = blk * 64 + lane;
-        const bool ev = eb < N;
+        const int64_t eb = (blk << bsh) + lane;
+        const bool ev = eb < N && lane < benvs;
         const int64_t ebc = ev ? eb : N - 1;
         float w[KW];
 #pragma unroll
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
             s.ar_episode = fa.st.ar_episode + (uint64_t)t;
             if (t > 0) s.ang_ok = 1;   // (as the host sets it after an unmasked full step: every prev_ang row is current from here on)
             StepIn<T, S> in;
-            step_load(s, eb, in);
+            step_load(s, ev ? eb : N, in);   // (lanes beyond the block or the batch: inactive)
             // ---- the policy on the block's two 32-env tiles
             FUSED_STAMP(0);
             // the MFMA's B operand wants element 16 sk + 8 half + i of env col in lane (col, half): v_permlane32_swap of
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
             float o0[4], o1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int tl = 0; tl < 2; ++tl) {
-                if (blk * 64 + 32 * tl >= N) break;   // (wave-uniform: a ragged last block has one tile)
+                if ((blk << bsh) + 32 * tl >= N || 32 * tl >= benvs) break;   // (wave-uniform: a ragged last block / a 32-env block has one tile)
                 float xw[KS16][8];   // (built per tile: both tiles' operands at once would be 40 more live registers)
 #pragma unroll
                 for (int sk = 0; sk < KS16; ++sk)
@@ -1441,9 +1444,15 @@ template <typename T, typename S, bool LEAN = false> int do_ppo_fused(qenv_s* q,
     fa.adv_act = (int64_t)(4 * N * esz); fa.adv_logp = (int64_t)(4 * N * esz); fa.adv_noise = (int64_t)(4 * N * esz);
     fa.adv_obs = (int64_t)((p->obs_slices ? (size_t)15 : (size_t)15 * q->cfg.T) * N * sizeof(float));
     fa.adv_row = (int64_t)(N * esz);
-    const int64_t n_blocks = ((int64_t)N + 63) / 64;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    // a batch that leaves half of the chip's waves without a 64-env block runs as 32-env blocks: one policy tile and an env step on
+    // half the lanes per wave and step -- 36 k instead of 55 k cycles per step, on twice the waves (QENV_FUSED_BLOCK=5/6 forces)
+    static const int force_shift = getenv("QENV_FUSED_BLOCK") ? atoi(getenv("QENV_FUSED_BLOCK")) : 0;
+    fa.block_shift = (q->ppo_fused == 5 || q->ppo_fused == 6) ? q->ppo_fused      // qenv_set_ppo_fused(q, 5 / 6): forced (tests)
+                     : (force_shift == 5 || force_shift == 6) ? force_shift
+                     : (((int64_t)N + 31) / 32 <= (int64_t)cus * 4 ? 5 : 6);
+    const int64_t n_blocks = ((int64_t)N + (1 << fa.block_shift) - 1) >> fa.block_shift;
     int64_t blocks = (n_blocks + 3) / 4;
     if (blocks > cus) blocks = cus;   // one resident workgroup per CU (its LDS holds the weights); a wave walks its blocks
     const size_t lds = sizeof(uint4) * (size_t)mlp3::IMAGE_UINT4;

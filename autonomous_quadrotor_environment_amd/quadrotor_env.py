@@ -586,11 +586,14 @@ class BatchedQuad:
         L.check(L.lib.qenv_policy_rollout(self._h, int(W[0].shape[1]), int(W[0].shape[0]), *[L.ptr(t) for t in W], n_steps,
                                           L.ptr(actions), L.ptr(reward), L.ptr(done), L.ptr(mask)), "qenv_policy_rollout")
 
-    def set_ppo_fused(self, on=True):
+    def set_ppo_fused(self, on=True, block=None):
         """Whether PolicyRollout.run (in-band) and policy_rollout use the ONE fused launch (policy + env step of the whole
-        call, k_ppo_fused; the default) where it applies, or the separate policy / env-step launches.  Bit-identical results."""
+        call, k_ppo_fused; the default) where it applies, or the separate policy / env-step launches.  Bit-identical results.
+        block: force 32- or 64-env blocks per wavefront (default: 32 for batches that would leave half the wavefronts idle)."""
         self._bind()
-        L.check(L.lib.qenv_set_ppo_fused(self._h, int(bool(on))), "qenv_set_ppo_fused")
+        if block not in (None, 32, 64):
+            raise ValueError("block: None (chosen by the batch size), 32 or 64 envs per wavefront")
+        L.check(L.lib.qenv_set_ppo_fused(self._h, ({32: 5, 64: 6}[block] if (on and block) else int(bool(on)))), "qenv_set_ppo_fused")
 
     def ppo_flush(self):
         """Complete the warm-up a ppo_step left pending (no-op otherwise); call before reading the env's fields."""

@@ -432,7 +432,9 @@ int qenv_policy_rollout(qenv_t q, int k_in, int hidden, const float *W1, const f
                         uint8_t *out_done, void *out_mask);
 /* ABI 7.  Whether this handle's in-band qenv_ppo_rollout and qenv_policy_rollout run as the
  * one fused launch where it applies (1, the default; the environment variable QENV_PPO_FUSED sets the initial value) or as the
- * separate policy / env-step launches (0).  Results are bit-identical either way. */
+ * separate policy / env-step launches (0).  Results are bit-identical either way.  5 / 6: on, with the launch's env blocks forced
+ * to 32 / 64 envs per wavefront (by default a batch that leaves half the chip's wavefronts without a 64-env block runs as 32-env
+ * blocks: one policy tile and a half-wave env step per wavefront and step; the tests force both). */
 int qenv_set_ppo_fused(qenv_t q, int enabled);
 
 /* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------

@@ -276,9 +276,9 @@ def test_fused_rollout_launch_equals_the_separate_launches(aq, handle):
     kw = HANDLES[handle]
     n = 64 * 33 + 17
     res = []
-    for mode in ("step", "run", "run1"):   # run1: every step its own fused launch (run(1))
+    for mode in ("step", "run", "run1"):   # run: 64-env blocks per wavefront; run1: every step its own fused launch (run(1)), 32-env blocks
         env = aq.BatchedQuad(n, 0.01, 13, training=True, direct_control=1, T=5, **kw)
-        env.set_ppo_fused(mode != "step")
+        env.set_ppo_fused(mode != "step", block={"run": 64, "run1": 32}.get(mode))
         ro = aq.PolicyRollout(env, w, 40, store_obs=True, auto_reset=True, seed=21, env_offset=500, inband=True)
         ro.start()
         if mode == "run":
@@ -299,7 +299,7 @@ def test_fused_rollout_launch_equals_the_separate_launches(aq, handle):
     res = []
     for mode in ("step", "run", "run_unfused"):   # run_unfused: qenv_policy_rollout's loop of the separate calls
         env = aq.BatchedQuad(n, 0.01, 500, training=True, direct_control=1, T=5, **kw)
-        env.set_ppo_fused(mode == "run")
+        env.set_ppo_fused(mode == "run", block=64 if handle in ("lean", "mixed") else 32)
         ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None, env.device), 30)
         ro.start()
         if mode != "step":

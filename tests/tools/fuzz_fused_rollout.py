@@ -33,11 +33,12 @@ for case in range(n_cases):
     store = bool(rng.randint(2)) if sampling else False
     slices = bool(rng.randint(2)) if store else None
     inject = sampling and bool(rng.randint(2))
+    block = [None, 32, 64][rng.randint(3)]   # env block per wavefront of the fused launch: chosen by the batch size / forced
     dyn_first = bool(rng.randint(4) == 0)   # a dynamics-only step in front: the launch starts with stale prev_ang rows (ang_ok = 0)
     res = []
     for mode in ("step", "run"):
         env = aq.BatchedQuad(n, 0.01, n_max, training=bool(case & 1), direct_control=1, T=5, **kw)
-        env.set_ppo_fused(mode != "step")
+        env.set_ppo_fused(mode != "step", block=block)
         if sampling:
             ww = w if store else aq.ActorCriticWeights(w.actor, None, env.device)   # (no stored observations: no batched critic)
             ww.std = w.std
@@ -71,6 +72,6 @@ for case in range(n_cases):
     ok = not diff
     bad += 0 if ok else 1
     print(json.dumps(dict(case=case, handle=handle, n=n, H=H, cuts=cuts, n_max=n_max, sampling=sampling, std=w.std, store=store,
-                          slices=slices, inject=inject, dyn_first=dyn_first, restarts=int(res[0][-3].sum()), mismatching_buffers=diff, ok=ok)), flush=True)
+                          slices=slices, inject=inject, dyn_first=dyn_first, block=block, restarts=int(res[0][-3].sum()), mismatching_buffers=diff, ok=ok)), flush=True)
 print(json.dumps(dict(cases=n_cases, mismatching=bad)))
 sys.exit(1 if bad else 0)
