@@ -724,6 +724,11 @@ class StreamShardedRollout:
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 self.ros.append(PolicyRollout(make_env(lo, hi), weights, horizon, seed=seed, env_offset=env_offset + lo, **kw))
+        if self.shards > 1:
+            # the shards' fused rollout launches are meant to run side by side: 64-env blocks keep a shard to its share of the
+            # chip (with the 32-env blocks a small shard would pick by itself every launch fills the chip and they serialise)
+            for ro in self.ros:
+                ro.env.set_ppo_fused(True, block=64)
         self.w = weights
         self._stats = torch.zeros(3, dtype=torch.float64, device=dev)
         self._fast = None   # built at the first sampling step (see _fast_args)

@@ -26,8 +26,9 @@ with the contract fields plus `roofline`, `cpu_baseline`, `sustained` and (defau
 `configs`: short per-GPU slices of BASELINE configs[2..4].  A rank's clock for a region stops when its own GPU
 has finished (torch.cuda.synchronize); the MAX all-reduce over the ranks closes the bracket afterwards.
 
---workload config5 collects the rank's env range as `--stream-shards` (default 2) shards on their own HIP streams
-(StreamShardedRollout: bit-identical to one batch, +12 %).  --policy trained|random: the actor (and critic) of configs 4 / 5
+--workload config5 can collect the rank's env range as `--stream-shards` S shards on their own HIP streams (default 1: since
+the rollout is ONE fused launch per horizon the shards gain nothing)
+(StreamShardedRollout: bit-identical to one batch; +12 % with round 2's list schedule).  --policy trained|random: the actor (and critic) of configs 4 / 5
 are the reference's checked-in N = 128 weights (solved/nn_old_solved_128_*.pth re-exported as arrays) or
 nn.Linear-style random-init weights (the reset-heavy variant: that policy drives envs out of the box within tens of steps).  --no-sustained / --no-extras / --no-subconfigs /
 --no-cpu-baseline trim the line for profiling runs (tools/profile_round.sh).
@@ -101,7 +102,7 @@ def parse(argv=None):
     p.add_argument("--chunk", type=int, default=0, help="env steps per graph replay / fused launch "
                    "(0 = the largest divisor of --steps up to 250)")
     p.add_argument("--no-graph", action="store_true", help="launch=step: eager launches instead of hipGraph replay")
-    p.add_argument("--stream-shards", type=int, default=2,
+    p.add_argument("--stream-shards", type=int, default=1,
                    help="config5: the rank's env range as this many shards on their own HIP streams (1 = one batch)")
     p.add_argument("--policy", default="trained", choices=["trained", "random"],
                    help="configs 4 / 5: the reference's checked-in N=128 weights (default, SURVEY.md 8d) or random-init weights")
