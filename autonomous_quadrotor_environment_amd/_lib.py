@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 7
+QENV_ABI_VERSION = 8
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -98,6 +98,8 @@ SYMBOLS = {
     "qenv_outer_reset": (_i, [_vp, _vp]),
     "qenv_set_robust": (_i, [_vp, _i]),
     "qenv_set_ppo_fused": (_i, [_vp, _i]),
+    "qenv_set_ppo_fused_block": (_i, [_vp, _i]),
+    "qenv_get_ppo_fused": (_i, [_vp]),
     "qenv_robust_params": (_i, [_vp, _vp, C.c_uint64, _i64, _vp]),
     "qenv_robust_gusts": (_i, [_vp, _vp, C.c_int32, C.c_int32, C.c_uint64, _i64]),
     "qenv_gae": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

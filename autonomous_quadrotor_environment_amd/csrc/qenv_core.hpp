@@ -150,6 +150,7 @@ constexpr double U_MAX = F_MAX_ROTOR / K_F;          // max squared rotor speed
 template <typename T> struct Cfg {
     T t_step;
     T cm_xy, cm_z;   // drag-moment coefficients of the selected variant
+    T cmj_xy, cmj_z; // ... divided by the nominal body inertia (J_xx = J_yy, J_zz): the nominal right-hand side works in angular accelerations
     T bb[9];         // done box: |v|(3), |ang|(3), |omega|(3)
     T zero_control0; // zero_control = [zc0,0,0,0] (indirect) or [zc0]*4 (direct, zc0=0)
     int32_t n_max;   // n + T
@@ -162,7 +163,20 @@ template <typename T> struct Cfg {
 // recomputes f2F (4 sqrt) in every RHS evaluation although the action is constant.
 template <typename T> struct Act {
     T F, Mx, My, Mz, omr;  // omr = (-w1+w2-w3+w4)*I_R
+    // nominal plant: the moments and the gyroscopic factor divided by the body inertia, once per env step (act_finish) instead
+    // of one multiplication per axis in every right-hand-side evaluation
+    T Mxj, Myj, Mzj, omrj;
 };
+static_assert(phys::JX == phys::JY, "act_finish / rhs use one gyroscopic factor omr / J_xx for the x and y axes");
+// two envs per lane (k_rollout2): the actuation of env 0 / env 1 in the two halves of the packed type
+template <typename T2, typename T1> __device__ __forceinline__ void pack_act(const Act<T1>& a, const Act<T1>& b, Act<T2>& u) {
+    u.F = T2{a.F, b.F}; u.Mx = T2{a.Mx, b.Mx}; u.My = T2{a.My, b.My}; u.Mz = T2{a.Mz, b.Mz}; u.omr = T2{a.omr, b.omr};
+    u.Mxj = T2{a.Mxj, b.Mxj}; u.Myj = T2{a.Myj, b.Myj}; u.Mzj = T2{a.Mzj, b.Mzj}; u.omrj = T2{a.omrj, b.omrj};
+}
+template <typename T> __device__ __forceinline__ void act_finish(Act<T>& u) {
+    u.Mxj = u.Mx * T(1.0 / phys::JX); u.Myj = u.My * T(1.0 / phys::JY); u.Mzj = u.Mz * T(1.0 / phys::JZ);
+    u.omrj = u.omr * T(1.0 / phys::JX);
+}
 
 // The plant the RHS integrates.  Nominal: the constants above plus the variant's drag-moment coefficients.
 // Robust (robust_control, quadrotor_env.py:84-109, flag :183): the episode's perturbed thrust coefficients, mass,
@@ -171,7 +185,7 @@ template <typename T, bool ROBUST, bool LEAN = false> struct Plant;
 template <typename T, bool LEAN> struct Plant<T, false, LEAN> {
     static constexpr bool robust = false;
     using math = typename MathSel<T, LEAN>::type;
-    T cm_xy, cm_z;
+    T cmj_xy, cmj_z;   // drag-moment coefficients / body inertia
 };
 constexpr int GUST_PERIOD = 500;  // robust_control.gust_period (:94)
 template <typename T, bool LEAN> struct Plant<T, true, LEAN> {
@@ -192,6 +206,15 @@ template <typename T, bool LEAN> struct Plant<T, true, LEAN> {
     int64_t N, e;      // row stride and this lane's env
     uint32_t key0, key1, ctr0, ctr1, episode;
 };
+
+// the plant's wave-uniform coefficients from the configuration (nominal: already divided by the body inertia; robust: the
+// episode's own inertia divides the moments, so the plain coefficients)
+template <typename T, bool LEAN> __device__ __forceinline__ void set_plant(Plant<T, false, LEAN>& pl, const Cfg<T>& cfg) {
+    pl.cmj_xy = cfg.cmj_xy; pl.cmj_z = cfg.cmj_z;
+}
+template <typename T, bool LEAN> __device__ __forceinline__ void set_plant(Plant<T, true, LEAN>& pl, const Cfg<T>& cfg) {
+    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
+}
 
 // Philox4x32-10 (Salmon et al. 2011), the same generator qenv_ppo.hip uses for actions and initial states.
 __device__ __forceinline__ void philox_core(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -335,7 +358,7 @@ __device__ __forceinline__ void mix_direct(const T a[4], const P& pl, T w[4], Ac
     u.My = (f[1] - f[3]) * T(phys::D);
     u.Mz = ((f[1] - f[0]) + (f[3] - f[2])) * T(phys::K_M / phys::K_F);
     if constexpr (P::robust) u.omr = ((w[1] * pl.ir[1] - w[0] * pl.ir[0]) + (w[3] * pl.ir[3] - w[2] * pl.ir[2]));
-    else u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
+    else { u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R); act_finish(u); }
 }
 
 // f2w, quadrotor_env.py:197-245 / quadrotor_env_opt.py:144-176 (indirect mode), with the
@@ -365,7 +388,7 @@ __device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool 
     u.My = T(phys::D * phys::K_F) * (s[1] - s[3]);
     u.Mz = T(phys::K_M) * ((s[1] - s[0]) + (s[3] - s[2]));
     if constexpr (P::robust) u.omr = ((w[1] * pl.ir[1] - w[0] * pl.ir[0]) + (w[3] * pl.ir[3] - w[2] * pl.ir[2]));
-    else u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R);
+    else { u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R); act_finish(u); }
     cl[0] = u.F; cl[1] = u.Mx; cl[2] = u.My; cl[3] = u.Mz;
 }
 
@@ -375,16 +398,22 @@ __device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool 
 template <typename T, typename P>
 __device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, P& pl, T dy[13]) {
     using m = typename P::math;
-    const T cm_xy = pl.cm_xy, cm_z = pl.cm_z;
     const T vx = y[1], vy = y[3], vz = y[5];
     const T wx = y[10], wy = y[11], wz = y[12];
     const T inv = m::rsqrt(y[6] * y[6] + y[7] * y[7] + y[8] * y[8] + y[9] * y[9]);
     const T a = y[6] * inv, b = y[7] * inv, c = y[8] * inv, d = y[9] * inv;
-    const T aa = a * a, bb = b * b, cc = c * c, dd = d * d;
-    const T ab = a * b, ac = a * c, ad = a * d, bc = b * c, bd = b * d, cd = c * d;
-    const T r00 = (aa + bb) - (cc + dd), r01 = T(2) * (bc - ad), r02 = T(2) * (bd + ac);
-    const T r10 = T(2) * (bc + ad), r11 = (aa - bb) + (cc - dd), r12 = T(2) * (cd - ab);
-    const T r20 = T(2) * (bd - ac), r21 = T(2) * (cd + ab), r22 = (aa - bb) - (cc - dd);
+    // quat_rot_mat of the UNIT quaternion (quaternion_euler_utility.py:77-79): with a^2 + b^2 + c^2 + d^2 = 1 the diagonal
+    // a^2 + b^2 - c^2 - d^2 is 1 - 2 (c^2 + d^2), and with the doubled components every entry is one or two multiply-adds:
+    // 17 instructions where squares, products, sums and doublings take 31 (the integrator evaluates this seven times per
+    // attempted sub-step; the kernels are bound by the number of vector instructions they issue).  An exact hover
+    // (q = 1, 0, 0, 0) still gives R = I exactly.
+    const T b2 = b + b, c2 = c + c, d2 = d + d;
+    const T ub = T(1) - b2 * b, ud = T(1) - d2 * d;
+    const T r00 = ud - c2 * c, r11 = ub - d2 * d, r22 = ub - c2 * c;
+    const T ad = d2 * a, ac = c2 * a, ab = b2 * a;
+    const T r01 = b2 * c - ad, r10 = b2 * c + ad;
+    const T r02 = b2 * d + ac, r20 = b2 * d - ac;
+    const T r12 = c2 * d - ab, r21 = c2 * d + ab;
     // body velocity and aerodynamic drag (robust: air-relative velocity = v + wind, :317-320)
     T vax = vx, vay = vy, vaz = vz;
     if constexpr (P::robust) {
@@ -406,22 +435,25 @@ __device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, P& pl, T dy[
     // (f_z - M G)/M instead of f_z/M - G: the same number, but the weight cancels before the
     // scaling, so an exact hover (f_z == fl(M G)) has az == 0 exactly in fp32 as well
     const T az = ((r20 * fbx + r21 * fby + r22 * fbz) - mg) * inv_m;
-    // moments: action + gyro (sic: x uses -wx, y uses +wy, :347-349) + drag - w x (J w)
-    const T mx = u.Mx - wx * u.omr - cm_xy * (m::abs(wx) * wx) - wy * wz * T(phys::JZ - phys::JY);
-    const T my = u.My + wy * u.omr - cm_xy * (m::abs(wy) * wy) - wz * wx * T(phys::JX - phys::JZ);
-    const T mz = u.Mz - cm_z * (m::abs(wz) * wz) - wx * wy * T(phys::JY - phys::JX);
     dy[0] = vx; dy[1] = ax; dy[2] = vy; dy[3] = ay; dy[4] = vz; dy[5] = az;
-    // deriv_quat with the normalised quaternion (quaternion_euler_utility.py:58-69)
-    dy[6] = T(0.5) * (-wx * b - wy * c - wz * d);
-    dy[7] = T(0.5) * (wx * a + wz * c - wy * d);
-    dy[8] = T(0.5) * (wy * a - wz * b + wx * d);
-    dy[9] = T(0.5) * (wz * a + wy * b - wx * c);
+    // deriv_quat with the normalised quaternion (quaternion_euler_utility.py:58-69), the 1/2 taken into the body rates
+    const T hx = T(0.5) * wx, hy = T(0.5) * wy, hz = T(0.5) * wz;
+    dy[6] = -(hx * b) - hy * c - hz * d;
+    dy[7] = hx * a + hz * c - hy * d;
+    dy[8] = hy * a - hz * b + hx * d;
+    dy[9] = hz * a + hy * b - hx * c;
+    // moments: action + gyro (sic: x uses -wx, y uses +wy, :347-349) + drag - w x (J w)
+    const T gx = m::abs(wx) * wx, gy = m::abs(wy) * wy, gz = m::abs(wz) * wz;
     if constexpr (P::robust) {
+        const T mx = u.Mx - wx * u.omr - pl.cm_xy * gx - wy * wz * T(phys::JZ - phys::JY);
+        const T my = u.My + wy * u.omr - pl.cm_xy * gy - wz * wx * T(phys::JX - phys::JZ);
+        const T mz = u.Mz - pl.cm_z * gz - wx * wy * T(phys::JY - phys::JX);
         dy[10] = mx * pl.ij[0]; dy[11] = my * pl.ij[1]; dy[12] = mz * pl.ij[2];
     } else {
-        dy[10] = mx * T(1.0 / phys::JX);
-        dy[11] = my * T(1.0 / phys::JY);
-        dy[12] = mz * T(1.0 / phys::JZ);
+        // nominal plant: every term already divided by the body inertia (act_finish, Cfg::cmj_*): five multiply-adds per axis
+        dy[10] = u.Mxj - wx * u.omrj - pl.cmj_xy * gx - (wy * wz) * T((phys::JZ - phys::JY) / phys::JX);
+        dy[11] = u.Myj + wy * u.omrj - pl.cmj_xy * gy - (wz * wx) * T((phys::JX - phys::JZ) / phys::JY);
+        dy[12] = u.Mzj - pl.cmj_z * gz - (wx * wy) * T((phys::JY - phys::JX) / phys::JZ);
     }
 }
 
@@ -445,23 +477,28 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
                                       T yn[13], T k7[13], T inc[13]) {
     using m = typename P::math;
     T k2[13], k3[13], k4[13], k5[13], k6[13], ys[13];
+    // the step size goes into the tableau's coefficients once (15 products per attempt) instead of into every component's
+    // stage sum (5 x 13): a stage value is then a chain of multiply-adds on y
+    const T a21 = h * T(dp::A21);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A21) * k1[i]);
+    for (int i = 0; i < 13; ++i) ys[i] = y[i] + a21 * k1[i];
     rhs(ys, u, pl, k2);
+    const T a31 = h * T(dp::A31), a32 = h * T(dp::A32);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A31) * k1[i] + T(dp::A32) * k2[i]);
+    for (int i = 0; i < 13; ++i) ys[i] = (y[i] + a31 * k1[i]) + a32 * k2[i];
     rhs(ys, u, pl, k3);
+    const T a41 = h * T(dp::A41), a42 = h * T(dp::A42), a43 = h * T(dp::A43);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) ys[i] = y[i] + h * (T(dp::A41) * k1[i] + T(dp::A42) * k2[i] + T(dp::A43) * k3[i]);
+    for (int i = 0; i < 13; ++i) ys[i] = ((y[i] + a41 * k1[i]) + a42 * k2[i]) + a43 * k3[i];
     rhs(ys, u, pl, k4);
+    const T a51 = h * T(dp::A51), a52 = h * T(dp::A52), a53 = h * T(dp::A53), a54 = h * T(dp::A54);
 #pragma unroll
-    for (int i = 0; i < 13; ++i)
-        ys[i] = y[i] + h * (T(dp::A51) * k1[i] + T(dp::A52) * k2[i] + T(dp::A53) * k3[i] + T(dp::A54) * k4[i]);
+    for (int i = 0; i < 13; ++i) ys[i] = (((y[i] + a51 * k1[i]) + a52 * k2[i]) + a53 * k3[i]) + a54 * k4[i];
     rhs(ys, u, pl, k5);
+    const T a61 = h * T(dp::A61), a62 = h * T(dp::A62), a63 = h * T(dp::A63), a64 = h * T(dp::A64), a65 = h * T(dp::A65);
 #pragma unroll
     for (int i = 0; i < 13; ++i)
-        ys[i] = y[i] + h * (T(dp::A61) * k1[i] + T(dp::A62) * k2[i] + T(dp::A63) * k3[i] + T(dp::A64) * k4[i] +
-                            T(dp::A65) * k5[i]);
+        ys[i] = ((((y[i] + a61 * k1[i]) + a62 * k2[i]) + a63 * k3[i]) + a64 * k4[i]) + a65 * k5[i];
     rhs(ys, u, pl, k6);
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
@@ -472,14 +509,16 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
     rhs(yn, u, pl, k7);
     T err2 = T(0);
     if (WITH_ERR) {
+        // 13 error_norm^2 = h^2 sum_i ((E . K)_i / scale_i)^2: the step size leaves the sum (one product instead of 13)
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
-            const T e = h * (T(dp::E1) * k1[i] + T(dp::E3) * k3[i] + T(dp::E4) * k4[i] + T(dp::E5) * k5[i] +
-                             T(dp::E6) * k6[i] + T(dp::E7) * k7[i]);
+            const T e = T(dp::E1) * k1[i] + T(dp::E3) * k3[i] + T(dp::E4) * k4[i] + T(dp::E5) * k5[i] +
+                        T(dp::E6) * k6[i] + T(dp::E7) * k7[i];
             const T sc = T(1e-6) + m::max(m::abs(y[i]), m::abs(yn[i])) * T(1e-3);
             const T r = e * m::rcp_ctl(sc);
             err2 += r * r;
         }
+        err2 = err2 * (h * h);
         if constexpr (m::lean) {
             // the hardware reciprocal is good to 2^-23: whenever the fast norm cannot decide err < 1 with a wide margin,
             // form it again with full-precision quotients (rare: the branch is taken by ~1e-5 of the attempts)

@@ -60,6 +60,7 @@ int qenv_create(const qenv_config* cfg, void* workspace, size_t bytes, void* str
     q->ar_pending = 0; q->ar_parity = 0; q->zero_on_act = nullptr;
     q->prep[0] = {nullptr, nullptr, 0}; q->prep[1] = {nullptr, nullptr, 0};
     q->ppo_fused = getenv("QENV_PPO_FUSED") ? (atoi(getenv("QENV_PPO_FUSED")) != 0) : 1;
+    q->ppo_fused_block = 0;
     q->outer = qenv_outer{QENV_OUTER_NONE, nullptr, 0, {0, 0, 0}};
     q->gust = qenv_gust_src{nullptr, cfg->dtype == QENV_F64, 1, 1, 0x0B57u, 0x6057u, 0};
     hipError_t e = hipMemsetAsync(workspace, 0, L.total, q->stream);
@@ -153,14 +154,31 @@ int qenv_outer_reset(qenv_t q, const uint8_t* mask) {
 
 int qenv_set_ppo_fused(qenv_t q, int enabled) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_set_ppo_fused: null handle");
-    q->ppo_fused = (enabled == 5 || enabled == 6) ? enabled : (enabled ? 1 : 0);
+    q->ppo_fused = enabled ? 1 : 0;
+    q->ppo_fused_block = (enabled == 5 || enabled == 6) ? enabled : 0;
     return QENV_OK;
+}
+
+int qenv_set_ppo_fused_block(qenv_t q, int block_envs) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_set_ppo_fused_block: null handle");
+    if (block_envs != 0 && block_envs != 32 && block_envs != 64)
+        return fail(QENV_ERR_ARG, "qenv_set_ppo_fused_block: 0 (chosen by the batch size), 32 or 64 envs per wavefront");
+    q->ppo_fused_block = block_envs == 32 ? 5 : block_envs == 64 ? 6 : 0;   // on / off stays as it is
+    return QENV_OK;
+}
+
+int qenv_get_ppo_fused(qenv_t q) {
+    if (!q) return fail(QENV_ERR_ARG, "qenv_get_ppo_fused: null handle");
+    return (q->ppo_fused ? 1 : 0) | ((q->ppo_fused_block ? (1 << q->ppo_fused_block) : 0) << 8);
 }
 
 int qenv_set_robust(qenv_t q, int enabled) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_set_robust: null handle");
     if (enabled && q->cfg.variant != QENV_MAIN)
         return fail(QENV_ERR_ARG, "qenv_set_robust: only the main variant has robust_control (quadrotor_env.py:84-109)");
+    if (enabled && q->cfg.compute == QENV_COMPUTE_LEAN)
+        return fail(QENV_ERR_ARG, "qenv_set_robust: the lean fp64 handle has no robust_control kernels; create the handle as f32, "
+                                  "mix (fp64 rows, QENV_COMPUTE_F32) or IEEE f64 (compute default)");
     q->robust = enabled ? 1 : 0;
     return QENV_OK;
 }
@@ -248,6 +266,22 @@ static const void* fused_image(const qenv_s* q, const float* W1) {
     return nullptr;
 }
 
+// The argument and state checks of a policy-in-the-loop step: ONE list for qenv_ppo_step (every schedule) and for the fused
+// launch behind qenv_ppo_rollout, so the two cannot drift apart as checks are added.
+static int ppo_args_check(const qenv_s* q, const qenv_ppo_step_args* p) {
+    if (!p->W1 || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->out_action) return fail(QENV_ERR_ARG, "qenv_ppo_step: null argument");
+    if (!q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_ppo_step: the policy commands the four rotors (direct_control=1)");
+    if (q->robust) return fail(QENV_ERR_STATE, "qenv_ppo_step: robust_control episodes redraw their plant at reset; use the separate calls");
+    if (q->sens.ws) return fail(QENV_ERR_STATE, "qenv_ppo_step: a sensor is attached (qenv_attach_sensor); the fused call neither evaluates nor resets it -- use the separate calls");
+    if (q->outer.kind != QENV_OUTER_NONE) return fail(QENV_ERR_STATE, "qenv_ppo_step: an outer position loop is active; its state is not reset with the episode here -- use the separate calls");
+    if ((p->obs_rows_from != 0 || p->obs_slices != 0) && !p->inband)
+        return fail(QENV_ERR_ARG, "qenv_ppo_step: the slice layout of stored observations needs the in-band schedule (one window slice per env and step)");
+    if (p->obs_rows_from < 0 || p->obs_rows_from >= 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_ppo_step: obs_rows_from must be in [0, 15*T)");
+    if (!(p->std > 0)) return fail(QENV_ERR_ARG, "qenv_policy_act: std must be positive");
+    if (p->k_in != 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_policy_act: k_in (row length of W1) must be 15*T of the handle");
+    return QENV_OK;
+}
+
 int qenv::ppo_flush(qenv_s* q) {
     if (!q->ar_pending) return QENV_OK;
     q->ar_pending = 0;
@@ -262,18 +296,13 @@ int qenv_ppo_flush(qenv_t q) {
 }
 
 int qenv_ppo_step(qenv_t q, const qenv_ppo_step_args* p) {
-    if (!q || !p || !p->W1 || !p->out_action) return fail(QENV_ERR_ARG, "qenv_ppo_step: null argument");
-    if (!q->cfg.direct_control) return fail(QENV_ERR_STATE, "qenv_ppo_step: the policy commands the four rotors (direct_control=1)");
-    if (q->robust) return fail(QENV_ERR_STATE, "qenv_ppo_step: robust_control episodes redraw their plant at reset; use the separate calls");
-    if (q->sens.ws) return fail(QENV_ERR_STATE, "qenv_ppo_step: a sensor is attached (qenv_attach_sensor); the fused call neither evaluates nor resets it -- use the separate calls");
-    if (q->outer.kind != QENV_OUTER_NONE) return fail(QENV_ERR_STATE, "qenv_ppo_step: an outer position loop is active; its state is not reset with the episode here -- use the separate calls");
+    if (!q || !p) return fail(QENV_ERR_ARG, "qenv_ppo_step: null argument");
+    if (const int crc = ppo_args_check(q, p)) return crc;
     // the side-stream schedule is opt-in: measured on config 5 (65 536 envs, random-init policy: 1.8 % of the envs finish
     // per step) it is SLOWER than the plain sequence, 234 vs 162 us per step -- the warm-up wavefronts run 1.5x longer when
     // they share their SIMDs with the policy forward, the gathered forward of the reset envs costs 65 us and the two
     // streams meet twice per step; with few resets per step (episodes that run their 500 steps) the side chain is shorter
     // than the main one and it pays (tests/tools/ab_ppo_overlap.py measures both and checks bit-identity)
-    if ((p->obs_rows_from != 0 || p->obs_slices != 0) && !p->inband)
-        return fail(QENV_ERR_ARG, "qenv_ppo_step: the slice layout of stored observations needs the in-band schedule (one window slice per env and step)");
     if (p->inband) {
         // in-band warm-up: policy + step, the restart in the step kernel's epilogue, the warm-up steps ride the next T steps
         if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
@@ -379,12 +408,12 @@ int qenv_mix(qenv_t q, int64_t n, const void* action, void* out_w, void* out_fm,
 int qenv_ppo_rollout(qenv_t q, const qenv_ppo_step_args* first, int n_steps) {
     if (!q || !first) return fail(QENV_ERR_ARG, "qenv_ppo_rollout: null argument");
     if (n_steps < 0) return fail(QENV_ERR_ARG, "qenv_ppo_rollout: negative n_steps");
-    if (n_steps > 0 && first->inband && first->W1 && first->out_action && ppo_fused_ok(q, first->k_in, first->hidden)) {
-        // the whole horizon as ONE launch (k_ppo_fused): the argument checks of qenv_ppo_step / qenv_policy_act, then the launch
-        if (!(first->std > 0)) return fail(QENV_ERR_ARG, "qenv_policy_act: std must be positive");
-        if (first->obs_rows_from < 0 || first->obs_rows_from >= 15 * q->cfg.T) return fail(QENV_ERR_ARG, "qenv_ppo_step: obs_rows_from must be in [0, 15*T)");
-        if (!first->b1 || !first->W2 || !first->b2 || !first->W3 || !first->b3) return fail(QENV_ERR_ARG, "qenv_policy_act: null argument");
+    if (n_steps == 0) return QENV_OK;
+    if (const int crc = ppo_args_check(q, first)) return crc;   // up front, whichever path runs: the per-step calls would say the same at step 0
+    if (first->inband && ppo_fused_ok(q, first->k_in, first->hidden)) {
+        // the whole horizon as ONE launch (k_ppo_fused)
         if (q->ar_pending) { const int frc = ppo_flush(q); if (frc != QENV_OK) return frc; }
+        q->zero_on_act = nullptr;   // (the word a list-schedule step asks its policy launch to clear: no list in the in-band schedule)
         return QENV_DISPATCH(q, do_ppo_fused, q, first, n_steps, 0, fused_image(q, first->W1));
     }
     const size_t esz = q->cfg.dtype == QENV_F64 ? 8 : 4;

@@ -298,7 +298,7 @@ __device__ __forceinline__ void step_one(const StepArgs<T, S>& a, const StepIn<T
     const T q_old[4] = {y[6], y[7], y[8], y[9]};
     Act<T> u;
     Plant<T, ROBUST, LEAN> pl;
-    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
+    set_plant(pl, cfg);
     if constexpr (ROBUST) {
         load_plant<T>(a.ws, a.wsi, N, e, a.gust, pl);
         begin_step_wind(pl, a.wsi[IROW_I * N + e] + 1);  // self.i += 1 comes first in step (:467)
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
     T w[4], effort[4], cl[4], act[4], kq[13], raw[4], dy[13];
     Act<T> u;
     Plant<T, ROBUST, LEAN> pl;
-    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
+    set_plant(pl, cfg);
     if constexpr (ROBUST) load_plant<T>(a.ws, a.wsi, N, e, a.gust, pl);  // the host refuses dynamics-only robust rollouts
     if (CTRL == QENV_CTRL_CONST) {  // constant action: mix once for the whole rollout
         prepare_action(a.const_action, cfg, pl, w, effort, cl, act, u);
@@ -884,9 +884,9 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
         }
     }
     Plant<F2, false> pl2;
-    pl2.cm_xy = F2{cfg.cm_xy, cfg.cm_xy}; pl2.cm_z = F2{cfg.cm_z, cfg.cm_z};
+    pl2.cmj_xy = F2{cfg.cmj_xy, cfg.cmj_xy}; pl2.cmj_z = F2{cfg.cmj_z, cfg.cmj_z};
     Plant<float, false> pl1;
-    pl1.cm_xy = cfg.cm_xy; pl1.cm_z = cfg.cm_z;
+    set_plant(pl1, cfg);
     float w[2][4], effort[2][4], cl[2][4], act[2][4], raw[4];
     Act<float> us[2];
     Act<F2> u;
@@ -894,8 +894,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
         prepare_action(a.const_action, cfg, pl1, w[0], effort[0], cl[0], act[0], us[0]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { w[1][k] = w[0][k]; effort[1][k] = effort[0][k]; cl[1][k] = cl[0][k]; act[1][k] = act[0][k]; }
-        u.F = F2{us[0].F, us[0].F}; u.Mx = F2{us[0].Mx, us[0].Mx}; u.My = F2{us[0].My, us[0].My};
-        u.Mz = F2{us[0].Mz, us[0].Mz}; u.omr = F2{us[0].omr, us[0].omr};
+        pack_act(us[0], us[0], u);
     }
     bool ang_ok = a.ang_ok != 0;
     F2 kq[13], dy[13];
@@ -913,8 +912,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout2(const RolloutA
                 } else pidpos_law(yc, bk[c], ps[c], a.target_table ? a.target_table + s * 7 : a.pid_target, cfg.t_step, raw);
                 prepare_action(raw, cfg, pl1, w[c], effort[c], cl[c], act[c], us[c]);
             }
-            u.F = F2{us[0].F, us[1].F}; u.Mx = F2{us[0].Mx, us[1].Mx}; u.My = F2{us[0].My, us[1].My};
-            u.Mz = F2{us[0].Mz, us[1].Mz}; u.omr = F2{us[0].omr, us[1].omr};
+            pack_act(us[0], us[1], u);
         }
         const F2 q_old[4] = {y[6], y[7], y[8], y[9]};
         integrate2<INTEG>(y, u, pl2, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && s > 0);
@@ -1088,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_mix(int64_t n, Cfg<T> cfg, const S* act
     for (int k = 0; k < 4; ++k) raw[k] = (T)action[(int64_t)k * n + e];
     Act<T> u;
     Plant<T, false, LEAN> pl;
-    pl.cm_xy = cfg.cm_xy; pl.cm_z = cfg.cm_z;
+    set_plant(pl, cfg);
     prepare_action(raw, cfg, pl, w, effort, cl, act, u);
     const T fm[4] = {u.F, u.Mx, u.My, u.Mz};
 #pragma unroll
@@ -1216,6 +1214,8 @@ template <typename T> static Cfg<T> make_cfg(const qenv_s* q) {
     c.t_step = (T)f.t_step;
     c.cm_xy = (T)(phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3));
     c.cm_z = (T)(2.0 * phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3));
+    c.cmj_xy = (T)(phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3) / phys::JX);   // (J_xx = J_yy)
+    c.cmj_z = (T)(2.0 * phys::CM0 * (opt ? phys::SUM_XX2 : phys::SUM_XX3) / phys::JZ);
     double bb[9];
     if (opt) {
         const double b[9] = {10, 10, 10, phys::BB_ANG, phys::BB_ANG, 4, 30, 30, 30};
@@ -1444,12 +1444,11 @@ template <typename T, typename S, bool LEAN = false> int do_ppo_fused(qenv_s* q,
     fa.adv_act = (int64_t)(4 * N * esz); fa.adv_logp = (int64_t)(4 * N * esz); fa.adv_noise = (int64_t)(4 * N * esz);
     fa.adv_obs = (int64_t)((p->obs_slices ? (size_t)15 : (size_t)15 * q->cfg.T) * N * sizeof(float));
     fa.adv_row = (int64_t)(N * esz);
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int cus = device_cu_count();
     // a batch that leaves half of the chip's waves without a 64-env block runs as 32-env blocks: one policy tile and an env step on
     // half the lanes per wave and step -- 36 k instead of 55 k cycles per step, on twice the waves (QENV_FUSED_BLOCK=5/6 forces)
     static const int force_shift = getenv("QENV_FUSED_BLOCK") ? atoi(getenv("QENV_FUSED_BLOCK")) : 0;
-    fa.block_shift = (q->ppo_fused == 5 || q->ppo_fused == 6) ? q->ppo_fused      // qenv_set_ppo_fused(q, 5 / 6): forced (tests)
+    fa.block_shift = (q->ppo_fused_block == 5 || q->ppo_fused_block == 6) ? q->ppo_fused_block   // qenv_set_ppo_fused_block: forced
                      : (force_shift == 5 || force_shift == 6) ? force_shift
                      : (((int64_t)N + 31) / 32 <= (int64_t)cus * 4 ? 5 : 6);
     const int64_t n_blocks = ((int64_t)N + (1 << fa.block_shift) - 1) >> fa.block_shift;

@@ -75,15 +75,15 @@ template <typename HW> QENV_FM double div(double a, double b) {
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
+// 1/sqrt(x) from the 2^-23 seed in ONE third-order step: with e = 1 - x r^2 (|e| <= 2^-22), 1/sqrt(x) = r (1 - e)^(-1/2) =
+// r (1 + e/2 + 3 e^2/8 + O(e^3)), and the dropped 5 e^3 / 16 is below 2^-67 -- five multiply-adds after the seed where two
+// Newton steps take eight (the quaternion normalisation of every right-hand-side evaluation goes through here).
 template <typename HW> QENV_FM double rsqrt(double x) {
-    double r = HW::rsq_seed(x);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const double t = x * r;
-        const double e = fma(-t, r, 1.0);
-        r = fma(0.5 * r, e, r);
-    }
-    return r;
+    const double r = HW::rsq_seed(x);
+    const double t = x * r;
+    const double e = fma(-t, r, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    return fma(r * e, p, r);
 }
 template <typename HW> QENV_FM double sqrt(double x) {  // 0 -> 0, negative -> NaN (as ::sqrt)
     const double xs = x == 0.0 ? 1.0 : x;

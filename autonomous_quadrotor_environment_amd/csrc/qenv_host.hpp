@@ -122,6 +122,7 @@ struct qenv_s {
     // qenv_ppo_rollout (in-band) / qenv_policy_rollout as ONE launch where k_ppo_fused applies
     // (qenv_set_ppo_fused; initial value: QENV_PPO_FUSED, default 1)
     int32_t ppo_fused;
+    int32_t ppo_fused_block;   // 0: chosen by the batch size; 5 / 6: 32- / 64-env blocks forced (qenv_set_ppo_fused_block)
 };
 
 namespace qenv {
@@ -148,6 +149,17 @@ static inline hipError_t allow_dynamic_lds(const void* fn, size_t bytes) {
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess && dev >= 0 && n < 128) cache[n++] = Slot{fn, dev, bytes};
     return e;
+}
+
+// compute units of the current device, asked once per device and thread (launch sizing of the persistent kernels)
+static inline int device_cu_count() {
+    static thread_local int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && cached[dev] > 0) return cached[dev];
+    int cus = 0;
+    if (dev < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 256;
+    return cached[dev] = cus;
 }
 
 static inline int fail(int code, const char* msg) {

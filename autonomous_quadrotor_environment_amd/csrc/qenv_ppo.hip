@@ -783,7 +783,10 @@ __global__ __launch_bounds__((H < 32 ? 32 : H) * 2) void k_mlp_small(const MlpAr
         const float* __restrict__ winc = a.win + chunk * (a.win_chunk_stride ? a.win_chunk_stride : (int64_t)K1 * a.N);
         const int64_t j_list = tile * 32 + col;
         const int64_t e = a.list_idx ? (j_list < n_list ? (int64_t)a.list_idx[j_list] : a.N) : j_list;
-        const bool valid = e < a.N;
+        // an env left to the side stream (env_skip: the overlapped PPO step) rides along in its tile, but nothing of it is stored --
+        // like k_mlp / k_mlp_v3.  (Round 4: this kernel stored it; the side stream's launch writes the same action / observation
+        // rows from the env's warmed-up window, and whichever store landed last stayed: a rare mismatch of the stored rows.)
+        const bool valid = e < a.N && !(a.env_skip && a.env_skip[e < a.N ? e : 0]);
         const int64_t ec = valid ? e : a.N - 1;
         f32x16 acc;
         if constexpr (BF16L1) {

@@ -98,6 +98,15 @@ class GradBucket:
             self.flat.div_(world)
         return self.flat
 
+    def all_reduce_sum_(self, group=None):
+        """Sum over the ranks: for gradients that every rank already normalised by the GLOBAL sample count (shards with
+        different numbers of valid rows -- an in-band rollout's masks).  No-op without a process group or with one rank."""
+        if group is False or not (dist.is_available() and dist.is_initialized()):
+            return self.flat
+        if dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, group=group)
+        return self.flat
+
 
 class ShardedQuad:
     """This rank's slice of a global batch of `n_global` envs."""

@@ -9,6 +9,7 @@ Reference (relative to /root/reference):
   visual_landing/rl_reward_fuction.py:3-102      visual_reward
 """
 import ctypes as C
+import itertools
 
 import numpy as np
 import torch
@@ -26,6 +27,24 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# One version cell per weight STORAGE (keyed by the first layer's device pointer), shared by every ActorCriticWeights that
+# wraps the same tensors: `ActorCriticWeights(w.actor, None)` is such an alias (dev() hands fp32 device tensors back as they
+# are), and an env that holds the alias must see the learner's touch() of the object it trains.  Version numbers come from
+# one process-wide counter, so a number is never handed out twice (a fresh storage at a recycled address cannot collide
+# with an image built from the old one).
+_VERSION_CELLS = {}
+_NEXT_VERSION = itertools.count(1)
+
+
+def _version_cell(t_in, t_dev):
+    p = t_dev.data_ptr()
+    alias = isinstance(t_in, torch.Tensor) and t_in.device == t_dev.device and t_in.data_ptr() == p
+    cell = _VERSION_CELLS.get(p) if alias else None
+    if cell is None:   # our own copy of the caller's numbers (or a storage nobody registered): a new cell
+        cell = _VERSION_CELLS[p] = [next(_NEXT_VERSION)]
+    return cell
+
+
 class ActorCriticWeights:
     """float32 device copies of model.py's actor / critic Linear layers, torch layout
     ([out, in] row-major), read directly by the MFMA kernel."""
@@ -41,12 +60,34 @@ class ActorCriticWeights:
         self.hidden = self.actor[0].shape[0]
         self.state_dim = self.actor[0].shape[1]
         # bumped whenever the weight VALUES change in place (PpoLearner does; call touch() after writing into the tensors
-        # yourself): an env re-builds its prepared image of the weights (qenv_mlp_prepare) when it sees a new version
-        self.version = 0
+        # yourself): an env re-builds its prepared image of the weights (qenv_mlp_prepare) when it sees a new version.  The
+        # cells belong to the storage, not to this wrapper (see _version_cell): aliases of the same tensors share them.
+        self._cells = {"actor": _version_cell(actor[0], self.actor[0])}
+        if self.critic is not None:
+            self._cells["critic"] = _version_cell(critic[0], self.critic[0])
+
+    def version_of(self, head):
+        """The version of `head`'s storage, looked up by where its first layer lives NOW (PpoLearner re-homes the tensors
+        into its flat parameter buffer: the cell follows them)."""
+        t = self.head(head)[0]
+        cell = _VERSION_CELLS.get(t.data_ptr())
+        if cell is None:
+            cell = _VERSION_CELLS[t.data_ptr()] = self._cells.get(head) or [next(_NEXT_VERSION)]
+        self._cells[head] = cell
+        return cell[0]
+
+    @property
+    def version(self):
+        return self.version_of("actor")
 
     def touch(self):
-        """Tell the envs that the weight values changed in place (their prepared images are rebuilt at the next forward)."""
-        self.version += 1
+        """Tell the envs that the weight values changed in place (their prepared images are rebuilt at the next forward);
+        every wrapper of the same tensors sees it."""
+        for head in ("actor", "critic"):
+            if head == "critic" and self.critic is None:
+                continue
+            self.version_of(head)   # (binds the cell to the tensors' current home)
+            self._cells[head][0] = next(_NEXT_VERSION)
 
     @classmethod
     def from_state_dict(cls, sd, device="cuda"):
@@ -73,6 +114,14 @@ class ActorCriticWeights:
             W1, b1 = lin(hidden, state_dim); W2, b2 = lin(hidden, hidden); W3, b3 = lin(out, hidden)
             return [W1, b1, W2, b2, W3, b3]
         return cls(mlp(action_dim), mlp(1), device)
+
+    def actor_only(self):
+        """A wrapper of the SAME actor tensors without the critic (what an evaluation env needs).  It shares the actor's
+        version cell, so an env holding it rebuilds its prepared image after the learner's touch().  Make it AFTER
+        constructing a PpoLearner on these weights: the learner re-homes the tensors into its flat parameter buffer, and a
+        wrapper of the tensors from before that move keeps the old, no longer trained, copies."""
+        w = ActorCriticWeights(self.actor, None, self.device, self.std)
+        return w
 
     def head(self, name):
         if name == "actor":
@@ -257,6 +306,7 @@ class PpoLearner:
         for (h, k), p in zip(keys, params):
             weights.head(h)[k] = self.flat_p[off:off + p.numel()].view_as(p)
             off += p.numel()
+        weights.touch()   # the tensors moved into the flat buffer: the version cells follow them to their new home
         if self.learn_std and not self.fused_loss:
             raise ValueError("learn_std needs the fused-loss backward (hidden 16, 32, 64 or 128)")
         self.std_param = self.flat_p[-1:] if self.learn_std else None
@@ -278,11 +328,31 @@ class PpoLearner:
             self._buf = (key, dict(h1=mk(H), h2=mk(H), dz2=mk(H), dz1=mk(H), dz3=mk(4), mean=mk(4), value=mk(1)))
         return self._buf[1]
 
-    def gradients(self, obs, actions, old_logprob, adv, returns, valid=None, n_valid=None):
+    def _world(self):
+        """Ranks that share this learner's gradients (1: no group, group=False, or no initialised process group)."""
+        import torch.distributed as dist
+        if self.group is False or not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
+
+    def _global_count(self, n_local, dev):
+        """Sum of a per-rank sample count over the learner's group (the denominator of a loss that is a mean over ALL the
+        ranks' valid samples)."""
+        if self._world() == 1:
+            return int(n_local)
+        import torch.distributed as dist
+        t = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def gradients(self, obs, actions, old_logprob, adv, returns, valid=None, n_valid=None, n_valid_global=None):
         """One forward + loss + backward over the batch; fills the .grad buffers.  obs [n, 75, N] float32,
         actions / old_logprob [n, 4, N], adv / returns [n, N].  Returns the loss dict of `ppo_loss`.
         valid [n, N] (in-band warm-up rollouts): rows of weight 0 take no part in the loss; n_valid = their count on THIS
-        learner (computed here with one device-to-host read if not given)."""
+        learner (computed here with one device-to-host read if not given).  Data-parallel learners hold DIFFERENT numbers
+        of valid rows, so the loss is normalised by n_valid_global (their sum over the group: one 8-byte all-reduce if not
+        given) and the gradients are SUMMED over the ranks -- the single learner's sum / count, not a mean of per-rank
+        means."""
         n, K, N = obs.shape
         dev, w = obs.device, self.w
         H = w.hidden
@@ -297,8 +367,10 @@ class PpoLearner:
             valid = f32(valid)
             if n_valid is None:
                 n_valid = int(valid.sum().item())
+            if n_valid_global is None:
+                n_valid_global = self._global_count(n_valid, dev)
         if self.fused_loss:
-            return self._gradients_fused(obs, actions, old_logprob, adv, returns, b, valid, n_valid)
+            return self._gradients_fused(obs, actions, old_logprob, adv, returns, b, valid, n_valid, n_valid_global)
         # forward of both heads on the stored observations (the dense kernel takes feature-major chunks)
         for head, out, ft in (("actor", b["mean"], True), ("critic", b["value"], False)):
             W = w.head(head)  # all n stored steps in one launch
@@ -337,7 +409,7 @@ class PpoLearner:
         L.check(L.lib.qenv_weight_grad_deterministic(N, n, rows_a, rows_b, L.ptr(A), L.ptr(Bm), L.ptr(gw), L.ptr(gb),
                                                      L.ptr(self._wg_ws[key]), stream), "qenv_weight_grad_deterministic")
 
-    def _gradients_fused(self, obs, actions, old_logprob, adv, returns, b, valid=None, n_valid=None):
+    def _gradients_fused(self, obs, actions, old_logprob, adv, returns, b, valid=None, n_valid=None, n_valid_global=None):
         """The same update with the loss inside the backward kernel: per head one backward launch (which recomputes
         the forward anyway and derives d loss / d output from it) + three weight-gradient launches; no forward launch,
         no loss launch, no [n, r, N] <-> [r, n N] copies."""
@@ -350,7 +422,7 @@ class PpoLearner:
             n_out = W[4].shape[0]
             L.check(L.lib.qenv_mlp_backward_ppo_masked(N, n, K, H, hid, L.ptr(obs), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
                                                        L.ptr(returns), L.ptr(valid), std, float(self.eps_clip), float(self.c_value),
-                                                       n * N if valid is None else max(1, int(n_valid)),
+                                                       n * N if valid is None else max(1, int(n_valid_global)),
                                                        L.ptr(sums), *[L.ptr(x) for x in W], L.ptr(b["h1"]), L.ptr(b["h2"]),
                                                        L.ptr(b["dz2"]), L.ptr(b["dz1"]), L.ptr(b["dz3"]), stream),
                     "qenv_mlp_backward_ppo")
@@ -359,10 +431,19 @@ class PpoLearner:
             for A, rows_a, Bm, rows_b, gw, gb in ((dz3, n_out, b["h2"], H, g[4], g[5]), (b["dz2"], H, b["h1"], H, g[2], g[3]),
                                                  (b["dz1"], H, obs, K, g[0], g[1])):
                 self._weight_grad(N, n, rows_a, rows_b, A, Bm, gw, gb, stream)
-        B = float(n * N) if valid is None else float(max(1, int(n_valid)))
-        if self.learn_std:  # before the all-reduce: the std's gradient travels in the same bucket
-            self.bucket.flat[-1] = (sums[4] / B - self.c_entropy * 4.0 / std).to(torch.float32)
-        self.bucket.all_reduce_mean_(self.group)
+        if valid is None:   # equal shards: every rank's loss is a mean over its own n N samples, the ranks are averaged
+            B = float(n * N)
+            if self.learn_std:  # before the all-reduce: the std's gradient travels in the same bucket
+                self.bucket.flat[-1] = (sums[4] / B - self.c_entropy * 4.0 / std).to(torch.float32)
+            self.bucket.all_reduce_mean_(self.group)
+        else:               # valid rows: normalised by the GLOBAL count above, so the ranks' contributions add up
+            B, world = float(max(1, int(n_valid_global))), self._world()
+            if self.learn_std:  # (the entropy term is not a sum over samples: a 1 / world share per rank)
+                self.bucket.flat[-1] = (sums[4] / B - self.c_entropy * 4.0 / std / world).to(torch.float32)
+            self.bucket.all_reduce_sum_(self.group)
+            if world > 1:       # the reported loss terms as the single learner would see them
+                import torch.distributed as dist
+                dist.all_reduce(sums, group=self.group)
         actor = sums[1] / B
         critic = self.c_value * sums[2] / B
         entropy = torch.full((), -self.c_entropy * 4.0 * (0.5 + 0.9189385332046727 + float(np.log(std))), dtype=torch.float64,
@@ -435,12 +516,13 @@ class PpoLearner:
                 raise ValueError("minibatch epochs over an in-band rollout are not implemented (full-batch epochs are)")
             v32 = valid[:n].to(torch.float32).contiguous()
             n_valid = int(v32.sum().item())
+            n_valid_global = self._global_count(n_valid, v32.device)   # once per update: the mask is the same every epoch
             obs = rollout.obs[:n]
             if not obs.is_contiguous():   # observations stored as slices (PolicyRollout.slice_obs): ONE dense copy for all epochs
                 obs = obs.contiguous()
             for _ in range(self.K_epochs):
                 out.append(self.gradients(obs, rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n],
-                                          valid=v32, n_valid=n_valid))
+                                          valid=v32, n_valid=n_valid, n_valid_global=n_valid_global))
                 self.adam_step()
             return out
         if graph and minibatch is None and not self.learn_std and self.fused_loss and not (
@@ -727,8 +809,9 @@ class StreamShardedRollout:
         if self.shards > 1:
             # the shards' fused rollout launches are meant to run side by side: 64-env blocks keep a shard to its share of the
             # chip (with the 32-env blocks a small shard would pick by itself every launch fills the chip and they serialise)
+            # (the block size only: a handle switched to the separate launches -- QENV_PPO_FUSED=0, set_ppo_fused(False) -- stays so)
             for ro in self.ros:
-                ro.env.set_ppo_fused(True, block=64)
+                ro.env.set_ppo_fused_block(64)
         self.w = weights
         self._stats = torch.zeros(3, dtype=torch.float64, device=dev)
         self._fast = None   # built at the first sampling step (see _fast_args)

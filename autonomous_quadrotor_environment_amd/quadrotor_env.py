@@ -138,7 +138,8 @@ class BatchedQuad:
         every BASELINE config's horizon and is what bench.py measures.  Opt-in alternatives:
         dtype=torch.float64 (compute None / "native"): IEEE fp64 arithmetic; dtype=torch.float64, compute="f32": the
         mixed handle (fp64 rows, fp32 arithmetic); dtype=torch.float32: fp32 rows and arithmetic -- the fastest, but
-        NOT parity-qualified (1e-4 off after 100 open-loop steps)."""
+        NOT parity-qualified (1e-4 off after 100 open-loop steps).  robust_control (domain randomisation) has kernels on
+        the f32, mixed and IEEE fp64 handles only: `env.robust_control = True` on the lean default raises at once."""
         if dtype is None:
             dtype = torch.float64
             if compute is None:
@@ -472,13 +473,21 @@ class BatchedQuad:
             raise ValueError(f"{name}: expected a contiguous {dtype} tensor of shape {shp} on {self.device}, got "
                              f"{tuple(t.shape)} {t.dtype} on {t.device}")
 
+    @staticmethod
+    def _prep_key(weights, head, W):
+        """What a prepared image was built from: where the first layer lives and the version of THAT STORAGE
+        (ActorCriticWeights.version_of: shared by every wrapper of the same tensors, so an alias held by this env sees the
+        learner's touch()); a weights object without versions is keyed by its identity."""
+        ver = weights.version_of(head) if hasattr(weights, "version_of") else (id(weights), getattr(weights, "version", 0))
+        return (W[0].data_ptr(), ver)
+
     def _prepared_is_current(self, weights, head):
         """True if nothing would be launched by _ensure_prepared (no prepared form for this shape, or the image is current)."""
         W = weights.head(head)
         if self.T != 5 or L.lib.qenv_mlp_image_bytes(int(W[0].shape[1]), int(W[0].shape[0])) == 0:
             return True
         cur = self.__dict__.get("_prep", {}).get(0 if head == "actor" else 1)
-        return cur is not None and cur[0] == (id(weights), getattr(weights, "version", 0), W[0].data_ptr())
+        return cur is not None and cur[0] == self._prep_key(weights, head, W)
 
     def _ensure_prepared(self, weights, head):
         """Build / refresh this handle's prepared image of `weights.head(head)` (qenv_mlp_prepare: the weights in the
@@ -490,7 +499,7 @@ class BatchedQuad:
             return
         slot = 0 if head == "actor" else 1
         prep = self.__dict__.setdefault("_prep", {})
-        key = (id(weights), getattr(weights, "version", 0), W[0].data_ptr())
+        key = self._prep_key(weights, head, W)
         cur = prep.get(slot)
         if cur is not None and cur[0] == key:
             return
@@ -595,6 +604,19 @@ class BatchedQuad:
             raise ValueError("block: None (chosen by the batch size), 32 or 64 envs per wavefront")
         L.check(L.lib.qenv_set_ppo_fused(self._h, ({32: 5, 64: 6}[block] if (on and block) else int(bool(on)))), "qenv_set_ppo_fused")
 
+    @property
+    def ppo_fused(self):
+        """(on, block): whether the fused rollout launch is enabled on this handle and the forced env block (None: by size)."""
+        v = int(L.lib.qenv_get_ppo_fused(self._h))
+        return bool(v & 1), ((v >> 8) or None)
+
+    def set_ppo_fused_block(self, block=None):
+        """Only the env block of the fused launch (None = chosen by the batch size, 32 or 64 envs per wavefront); whether the
+        fused launch is used at all stays as set_ppo_fused / QENV_PPO_FUSED left it.  No stream is bound here."""
+        if block not in (None, 32, 64):
+            raise ValueError("block: None (chosen by the batch size), 32 or 64 envs per wavefront")
+        L.check(L.lib.qenv_set_ppo_fused_block(self._h, int(block or 0)), "qenv_set_ppo_fused_block")
+
     def ppo_flush(self):
         """Complete the warm-up a ppo_step left pending (no-op otherwise); call before reading the env's fields."""
         self._bind()
@@ -650,6 +672,9 @@ class BatchedQuad:
 
     @robust_control.setter
     def robust_control(self, on):
+        if on and self.handle == "lean":   # (qenv_set_robust says the same; here with the Python spelling of the remedy)
+            raise ValueError("robust_control: the lean fp64 handle (BatchedQuad's default) has no robust kernels -- create the "
+                             "env with dtype=torch.float32, dtype=torch.float64 (IEEE) or dtype=torch.float64, compute='f32'")
         L.check(L.lib.qenv_set_robust(self._h, int(bool(on))), "qenv_set_robust")
         self._robust = bool(on)
 

@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-/* 7: qenv_policy_rollout; qenv_ppo_rollout (in-band) and qenv_policy_rollout run as one launch where k_ppo_fused applies.
+/* 8: qenv_set_ppo_fused_block, qenv_get_ppo_fused; qenv_set_robust refuses the lean fp64 handle (it has no robust kernels) instead of failing at
+ *    the first step; qenv_ppo_rollout validates its arguments up front on every path.
+ * 7: qenv_policy_rollout; qenv_ppo_rollout (in-band) and qenv_policy_rollout run as one launch where k_ppo_fused applies.
  * 6: qenv_ppo_step_args gains obs_rows_from / obs_slices (the slice layout of stored observations); qenv_dense_tail_chunks_strided.
  * 5: qenv_ppo_step_args gains out_valid / inband / key_by_episode (in-band warm-up); qenv_gae_masked,
  *    qenv_adv_normalize_masked, qenv_mlp_backward_ppo_masked (the `valid` rows of such a rollout); qenv_mlp_prepare /
@@ -41,7 +43,7 @@ extern "C" {
  * 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
  * 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
-#define QENV_ABI_VERSION 7
+#define QENV_ABI_VERSION 8
 
 typedef struct qenv_s *qenv_t;
 
@@ -436,13 +438,21 @@ int qenv_policy_rollout(qenv_t q, int k_in, int hidden, const float *W1, const f
  * to 32 / 64 envs per wavefront (by default a batch that leaves half the chip's wavefronts without a 64-env block runs as 32-env
  * blocks: one policy tile and a half-wave env step per wavefront and step; the tests force both). */
 int qenv_set_ppo_fused(qenv_t q, int enabled);
+/* ABI 8.  Only the env block of the fused launch -- 0 (chosen by the batch size), 32 or 64 envs per wavefront -- leaving the
+ * on / off state of qenv_set_ppo_fused (and of QENV_PPO_FUSED) as it is: what a caller that runs several handles side by side
+ * on their own streams wants (64-env blocks keep a launch to its share of the chip) without overriding an A/B switch. */
+int qenv_set_ppo_fused_block(qenv_t q, int block_envs);
+/* ABI 8.  The two settings as the handle holds them: bit 0 = fused launch on, bits 8.. = forced block in envs (0, 32 or 64);
+ * negative on a null handle. */
+int qenv_get_ppo_fused(qenv_t q);
 
 /* ---- robust_control: per-episode plant perturbation + gusts (environment/quadrotor_env.py:84-109) ----------
  * The reference hard-codes `self.robust_control = False` (:183) and a user flips the attribute; this is that
  * switch.  Main variant only (quadrotor_env_opt.py has no such mode).  With it on, every step / rollout of the
  * handle runs the perturbed plant: thrust loss u -= u*episode_kf after w (:235,:265), wind added to the
  * air-relative velocity (:317-320), per-rotor inertia (:341-343), mass (:360-361), body inertia (:381-382).
- * Dynamics-only steps are refused (the gusts follow the step counter i). */
+ * Dynamics-only steps are refused (the gusts follow the step counter i).  Handles: f32, mix and IEEE f64; the lean fp64 handle
+ * (QENV_COMPUTE_LEAN) has no robust kernels and is refused here with QENV_ERR_ARG (ABI 8; before, at the first step). */
 int qenv_set_robust(qenv_t q, int enabled);
 
 /* robust_control.reset (:97-101): the 12 episode draws of the envs with mask != 0 (mask nullable).

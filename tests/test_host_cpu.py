@@ -201,3 +201,31 @@ def test_lean_fastmath_accuracy(tmp_path):
     assert r["edges"] is True
     assert r["atan2_abs"] < 1e-15 and r["asin_abs"] < 1e-15 and r["sin_abs"] < 5e-16 and r["cos_abs"] < 5e-16
     assert r["tan_rel"] < 1e-15 and r["div_rel"] < 3e-16 and r["sqrt_rel"] < 3e-16 and r["rsqrt_rel"] < 5e-16
+
+
+def test_weight_versions_belong_to_the_storage_not_the_wrapper():
+    """ActorCriticWeights.version_of keys an env's prepared weight image: every wrapper of the same tensors shares one
+    cell (an alias held by an evaluation env sees the learner's touch()), a wrapper that copies gets its own, and the
+    cells follow the tensors into the learner's flat parameter buffer.  Host logic only (CPU tensors, no launch)."""
+    import torch
+    from autonomous_quadrotor_environment_amd.ppo import ActorCriticWeights, PpoLearner
+    rng = np.random.RandomState(0)
+    mk = lambda o: [rng.randn(16, 75), rng.randn(16), rng.randn(16, 16), rng.randn(16), rng.randn(o, 16), rng.randn(o)]
+    w = ActorCriticWeights(mk(4), mk(1), device="cpu")
+    alias = ActorCriticWeights(w.actor, None, device="cpu")
+    assert alias.actor[0].data_ptr() == w.actor[0].data_ptr()
+    v0 = w.version_of("actor")
+    assert alias.version_of("actor") == v0 and w.version_of("critic") != v0
+    w.touch()
+    assert alias.version_of("actor") == w.version_of("actor") != v0
+    alias.touch()   # either wrapper may announce a change
+    assert alias.version_of("actor") == w.version_of("actor")
+    copy = ActorCriticWeights([t.double() for t in w.actor], None, device="cpu")
+    assert copy.actor[0].data_ptr() != w.actor[0].data_ptr() and copy.version_of("actor") != w.version_of("actor")
+    before = w.version_of("actor")
+    learner = PpoLearner(w, K_epochs=1)   # re-homes the tensors into one flat buffer
+    assert w.actor[0].data_ptr() == learner.flat_p.data_ptr() and w.version_of("actor") != before
+    late = w.actor_only()
+    assert late.version_of("actor") == w.version_of("actor")
+    w.touch()
+    assert late.version_of("actor") == w.version_of("actor")

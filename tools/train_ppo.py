@@ -28,6 +28,8 @@ p.add_argument("--learn-std", action="store_true", help="train the action std to
 p.add_argument("--inband", action="store_true", help="the in-band warm-up schedule (a restart's warm-up steps ride the next T steps; rows flagged "
                                                       "invalid) with the observations stored as slices: a rollout step is policy + env step")
 a = p.parse_args()
+if (a.robust or a.eval_robust) and a.handle == "lean":
+    p.error("--robust / --eval-robust need --handle f32 or f64: the lean handle has no robust_control kernels")
 
 w = aq.ActorCriticWeights.random(a.hidden, 75, 4, seed=a.seed)
 w.std = 0.1
@@ -57,7 +59,7 @@ for u in range(1, a.updates + 1):
     if a.eval_every and (u % a.eval_every == 0 or u == 1):
         ev = aq.BatchedQuad(a.eval_envs, 0.01, 1000, training=False, direct_control=1, T=5, integrator=a.integrator, **HKW)
         ev.robust_control = a.eval_robust
-        er = aq.PolicyRollout(ev, aq.ActorCriticWeights(w.actor, None), 500, seed=a.seed + 77)
+        er = aq.PolicyRollout(ev, w.actor_only(), 500, seed=a.seed + 77)
         er.start(ev.sample_init_states(a.seed + 1000, u))
         er.run_deterministic(500)   # the evaluation episode as one library call (qenv_policy_rollout)
         v = torch.linalg.norm(ev.state[1:6:2], dim=0)
