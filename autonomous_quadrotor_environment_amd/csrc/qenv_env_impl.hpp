@@ -498,6 +498,110 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
 // of the two tiles come out of v_permlane32_swap, the observation copy is stored from the env layout, and per step only the slice
 // the env step has just pushed into the ring is read back.  Both tiles' outputs are finished in one 64-lane pass (exact tanh,
 // stores, sampling); the action reaches the env step in registers; the step's state rows are requested ahead of the tiles.
+// ---- the env step of k_ppo_fused: state and bookkeeping of the block's envs stay in REGISTERS for the whole horizon ---------
+// step_one's arithmetic, call for call (prepare_action, integrate, euler_update, done_reward on the same values: every buffer
+// the fused launch writes is compared bit for bit with the per-step launches), without its memory round trip: per step only what
+// the rollout keeps is stored (reward / done / mask / valid rows); the 13 state rows, the bookkeeping rows, V_q and the ring are
+// written once, by the launch's last step.  (With the rows going through memory every step a wave issued 25 row loads and ~47
+// row stores of 512 B per step on a CU path of ~12 B per clock, plus the 64-bit address arithmetic of each.)
+template <typename T, typename S> struct EnvRegs {
+    S ys[13];      // state rows (storage type)
+    Book<T> bk;    // prev_ang, ang, prev_shaping, abs_sum, ep_return, reward, i, flags
+};
+
+// reset_env_sampled on registers (the in-band restart in the step's epilogue): the same draws, the same IEEE angle functions of the
+// storage type, the same cleared counters; the banked return and the episode count go to memory (a rare event)
+template <typename T, typename S>
+__device__ __forceinline__ void reset_env_regs(S* ws, int32_t* wsi, int64_t N, int64_t e, uint64_t seed, uint64_t episode,
+                                               int64_t env_offset, bool key_episode, EnvRegs<T, S>& r) {
+    using m = Mth<S>;
+    st(ws, ROW_LAST_RETURN, N, e, (S)r.bk.ep_return);   // (what the memory version reads back from the row store_book has just written)
+    const int32_t n_ep = wsi[IROW_EPISODES * N + e] + 1;
+    wsi[IROW_EPISODES * N + e] = n_ep;
+    if (key_episode) episode = (uint64_t)n_ep;
+    float xf[13];
+    sample_init_state(seed, episode, (uint64_t)(env_offset + e), xf);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) r.ys[k] = (S)xf[k];
+    const S* q = r.ys + 6;
+    r.bk.ang[0] = (T)m::atan2(S(2) * (q[0] * q[1] + q[2] * q[3]), S(1) - S(2) * (q[1] * q[1] + q[2] * q[2]));
+    r.bk.ang[1] = (T)m::asin(S(2) * (q[0] * q[2] - q[3] * q[1]));
+    r.bk.ang[2] = (T)m::atan2(S(2) * (q[0] * q[3] + q[1] * q[2]), S(1) - S(2) * (q[2] * q[2] + q[3] * q[3]));
+    r.bk.prev_shaping = T(0); r.bk.abs_sum = T(0); r.bk.ep_return = T(0); r.bk.reward = T(0);
+    r.bk.i = 0; r.bk.flags = 0;
+}
+
+// one env step of lane env e on the registers `r` with the raw action `raw_in`; slice[15] = the observation slice this step pushes
+// (dl_in_gen.dl_input's row, as floats); `last`: the launch's final step writes the rows back
+template <typename T, typename S, int INTEG, bool LEAN>
+__device__ __forceinline__ void fused_env_step(const StepArgs<T, S>& a, int64_t e, EnvRegs<T, S>& r, const T raw_in[4], bool last,
+                                               float slice[15]) {
+    using M = typename MathSel<T, LEAN>::type;
+    const int64_t N = a.N;
+    const Cfg<T>& cfg = a.cfg;
+    constexpr bool MIXED = !std::is_same<T, S>::value;
+    T y[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) y[k] = (T)r.ys[k];
+    T raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[k] = raw_in[k];
+    T w[4], effort[4], cl[4], act[4], kq[13], dy[13];
+    const T q_old[4] = {y[6], y[7], y[8], y[9]};
+    Act<T> u;
+    Plant<T, false, LEAN> pl;
+    set_plant(pl, cfg);
+    Book<T>& bk = r.bk;
+    bool warming = false;
+    if (a.ar_on == 2) {  // in-band warm-up: steps 1..T after a reset apply zero_control (:448-451)
+        warming = bk.i < cfg.warmup;
+        if (warming) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) raw[k] = (cfg.direct || k == 0) ? cfg.zero_control0 : T(0);
+        }
+    }
+    prepare_action(raw, cfg, pl, w, effort, cl, act, u);
+    integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        if (MIXED) { r.ys[k] += (S)dy[k]; y[k] = (T)r.ys[k]; }
+        else r.ys[k] = (S)y[k];
+    }
+    bk.i += 1;
+    euler_update<T, M>(q_old, y, dy, a.ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
+    done_reward<T, M>(y, act, effort, cfg, bk);
+    if (a.out_reward) a.out_reward[e] = (S)bk.reward;
+    if (a.out_done) a.out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
+    if (a.out_mask) a.out_mask[e] = (bk.flags & FLAG_DONE) ? S(0) : S(1);
+    if (a.out_valid) a.out_valid[e] = warming ? S(0) : S(1);
+    // dl_in_gen.dl_input: [raw action(4), vel(3), q(4), q_dot(4)] (dl_auxiliary.py:27-31), as k_step pushes it into the ring
+#pragma unroll
+    for (int k = 0; k < 4; ++k) slice[k] = (float)raw[k];
+    slice[4] = (float)(y[1] - T(0)); slice[5] = (float)(y[3] - T(0)); slice[6] = (float)(y[5] - T(0));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { slice[7 + k] = (float)y[6 + k]; slice[11 + k] = (float)kq[6 + k]; }
+    if (last) {   // (wave-uniform) what the per-step launches leave in the workspace after this step, before a restart
+#pragma unroll
+        for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, r.ys[k]);
+        store_book(a.ws, a.wsi, N, e, bk, false);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st(a.ws, ROW_VQ + k, N, e, kq[6 + k]);
+    }
+    if (a.ar_on == 2 && (bk.flags & FLAG_DONE) != 0 && !warming) {
+        // in-band: an episode that ends in a POLICY step restarts here (see k_step's epilogue)
+        reset_env_regs<T, S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, a.ar_key_episode != 0, r);
+        if (last) {   // the rows reset_env_sampled overwrites
+#pragma unroll
+            for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, r.ys[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) st(a.ws, ROW_ANG + k, N, e, bk.ang[k]);
+            st(a.ws, ROW_PREV_SHAPING, N, e, S(0)); st(a.ws, ROW_ABS_SUM, N, e, S(0));
+            st(a.ws, ROW_EP_RETURN, N, e, S(0)); st(a.ws, ROW_REWARD, N, e, S(0));
+            a.wsi[IROW_I * N + e] = 0; a.wsi[IROW_FLAGS * N + e] = 0;
+        }
+    }
+}
+
 template <typename T, typename S> struct FusedArgs {
     StepArgs<T, S> st;   // the step kernel's arguments of step 0
     MlpArgs ml;          // the policy forward's arguments of step 0
@@ -549,6 +653,13 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
 #pragma unroll
             for (int r = 0; r < 15; ++r) w[15 * sl + r] = src[(int64_t)r * N];
         }
+        // ---- the block's env state and bookkeeping: read once, carried in registers (fused_env_step), written back by the last step
+        EnvRegs<T, S> er;
+        if (ev) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) er.ys[k] = ld(fa.st.ws, ROW_STATE + k, N, eb);
+            load_book(fa.st.ws, fa.st.wsi, N, eb, fa.st.cfg.variant != 0, er.bk);
+        }
 #pragma unroll 1
         for (int t = 0; t < fa.n_steps; ++t) {
             asm volatile("" ::: "memory");   // (the weights in LDS are loop-invariant: nothing of them is to be hoisted)
@@ -572,8 +683,7 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
                 for (int k = 0; k < KW; ++k)
                     if (k >= m.obs_rows_from) obs_c[(int64_t)k * N] = w[k];
             }
-            // ---- the env step's own inputs (state and bookkeeping rows: they do not depend on the policy) are requested now and
-            // land behind the policy tiles; the action reaches the step in registers (below)
+            // ---- this step's view of the step arguments (the action reaches the step in registers, below)
             StepArgs<T, S> s = fa.st;
             s.actions = nullptr;
             if (s.out_reward) s.out_reward = (S*)((char*)fa.st.out_reward + fa.adv_row * t);
@@ -582,8 +692,6 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
             s.win_slot = head;
             s.ar_episode = fa.st.ar_episode + (uint64_t)t;
             if (t > 0) s.ang_ok = 1;   // (as the host sets it after an unmasked full step: every prev_ang row is current from here on)
-            StepIn<T, S> in;
-            step_load(s, ev ? eb : N, in);   // (lanes beyond the block or the batch: inactive)
             // ---- the policy on the block's two 32-env tiles
             FUSED_STAMP(0);
             // the MFMA's B operand wants element 16 sk + 8 half + i of env col in lane (col, half): v_permlane32_swap of
@@ -642,23 +750,34 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
                 // ---- the env step of the block's 64 envs on the actions just computed (what qenv_step would read back from
                 // the action buffer: the stored value, converted to the arithmetic type)
                 FUSED_STAMP(7);
+                T rawT[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) in.raw[k] = (T)act[k];
-                if (in.active) step_one<T, S, INTEG, false, LEAN>(s, in);
-            }
-            FUSED_STAMP(8);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            {   // the slice this step pushed into ring slot `head` becomes the window's newest; the window shifts by one slice
-                const float* src = fa.ml.win + (int64_t)head * 15 * N + ebc;
+                for (int k = 0; k < 4; ++k) rawT[k] = (T)act[k];
                 float nw[15];
 #pragma unroll
-                for (int r = 0; r < 15; ++r) nw[r] = src[(int64_t)r * N];
+                for (int r = 0; r < 15; ++r) nw[r] = 0.f;
+                if (ev) fused_env_step<T, S, INTEG, LEAN>(s, eb, er, rawT, t + 1 == fa.n_steps, nw);
+                FUSED_STAMP(8);
+                // the slice this step pushes becomes the window's newest; the window shifts by one slice (registers only: the
+                // ring in memory is brought up to date after the last step)
 #pragma unroll
                 for (int k = 0; k < KW - 15; ++k) w[k] = w[k + 15];
 #pragma unroll
                 for (int r = 0; r < 15; ++r) w[KW - 15 + r] = nw[r];
             }
             FUSED_STAMP(9);
+        }
+        // ---- the ring as the per-step launches leave it: time position j of the window lives in slot (head + n_steps + j) mod T
+        if (ev) {
+            const int head_end = (fa.ml.head + fa.n_steps) % TW;   // the slot of the oldest slice after n_steps pushes
+#pragma unroll
+            for (int sl = 0; sl < TW; ++sl) {
+                int slot = head_end + sl;
+                if (slot >= TW) slot -= TW;
+                float* dst = const_cast<float*>(fa.ml.win) + (int64_t)slot * 15 * N + eb;
+#pragma unroll
+                for (int r = 0; r < 15; ++r) dst[(int64_t)r * N] = w[15 * sl + r];
+            }
         }
     }
 }
