@@ -43,7 +43,14 @@ __device__ unsigned long long g_rollout_stamps[1024 * 8];
 
 }  // namespace qenv
 #if defined(QENV_FUSED_STAMPS) && defined(QENV_ENV_UNIT_LEAN)
+#if defined(QENV_ENVSTEP_STAMPS)   // slots 10-15 inside the env step instead of inside the policy tile
+#define ENVSTEP_STAMP(slot) FUSED_STAMP(slot)
+#else
 #define MLP3_STAMP(slot) FUSED_STAMP(slot)
+#endif
+#endif
+#ifndef ENVSTEP_STAMP
+#define ENVSTEP_STAMP(slot) do { } while (0)
 #endif
 #include "qenv_mlp3.hpp"
 #include <type_traits>
@@ -561,7 +568,9 @@ __device__ __forceinline__ void fused_env_step(const StepArgs<T, S>& a, int64_t 
         }
     }
     prepare_action(raw, cfg, pl, w, effort, cl, act, u);
+    ENVSTEP_STAMP(10);
     integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy);
+    ENVSTEP_STAMP(11);
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         if (MIXED) { r.ys[k] += (S)dy[k]; y[k] = (T)r.ys[k]; }
@@ -569,7 +578,9 @@ __device__ __forceinline__ void fused_env_step(const StepArgs<T, S>& a, int64_t 
     }
     bk.i += 1;
     euler_update<T, M>(q_old, y, dy, a.ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
+    ENVSTEP_STAMP(12);
     done_reward<T, M>(y, act, effort, cfg, bk);
+    ENVSTEP_STAMP(13);
     if (a.out_reward) a.out_reward[e] = (S)bk.reward;
     if (a.out_done) a.out_done[e] = (bk.flags & FLAG_DONE) ? 1 : 0;
     if (a.out_mask) a.out_mask[e] = (bk.flags & FLAG_DONE) ? S(0) : S(1);
