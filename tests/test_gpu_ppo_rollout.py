@@ -886,3 +886,27 @@ def test_ppo_rollout_validates_up_front_on_every_path(aq):
         assert L.lib.qenv_ppo_rollout(env._h, C.byref(args()), 4) == 0
         torch.cuda.synchronize()
         assert not torch.equal(env.state, state0)
+
+
+def test_rccl_itself_runs_the_paths_collectives_on_one_rank():
+    """The N > 1 path's collectives through RCCL (backend "nccl") on the one GPU of this box: a one-rank communicator loads
+    librccl, is created on the device and runs the all-gather of the episode returns, the MAX / SUM all-reduces and the barrier as
+    device operations (tests/tools/rccl_one_rank.py, its own process: the process group is global state).  The multi-rank logic is
+    covered under gloo (tests/test_distributed_gloo.py, the --gpus 2 bench tests); this shows the RCCL half of the path is usable
+    on the image and the hardware."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "rccl_one_rank.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["backend"] == "nccl" and d["world"] == 1 and d["all_gather_512KB_us"] > 0
