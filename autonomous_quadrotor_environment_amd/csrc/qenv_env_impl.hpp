@@ -846,6 +846,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
     Act<T> u;
     Plant<T, ROBUST, LEAN> pl;
     set_plant(pl, cfg);
+    if constexpr (!ROBUST) pl.skip_probe = CTRL == QENV_CTRL_CONST;   // (see Plant: pays in the constant-action rollouts)
     if constexpr (ROBUST) load_plant<T>(a.ws, a.wsi, N, e, a.gust, pl);  // the host refuses dynamics-only robust rollouts
     if (CTRL == QENV_CTRL_CONST) {  // constant action: mix once for the whole rollout
         prepare_action(a.const_action, cfg, pl, w, effort, cl, act, u);

@@ -229,3 +229,80 @@ def test_weight_versions_belong_to_the_storage_not_the_wrapper():
     assert late.version_of("actor") == w.version_of("actor")
     w.touch()
     assert late.version_of("actor") == w.version_of("actor")
+
+
+def test_probe_bound_is_conservative(tmp_path, oracle):
+    """csrc/qenv_probe_bound.hpp proves, from y, f0 and h0 alone, that scipy's select_initial_step would get h1 >= t_bound, and
+    the kernels then skip the evaluation f(y + h0 f0) that only feeds d2.  The proof is a Lipschitz bound on d2: here the header
+    is built for the host and its bound is compared with the ACTUAL d2 from the oracle's drone_eq over wide random states
+    (hover-like to far outside the done box, both control modes, both variants' drag moments): bound >= d2 always, and the
+    proof succeeds on most of them (so the skip is what usually runs)."""
+    import ctypes as C
+    import subprocess
+    so = str(tmp_path / "probe_bound.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tests", "tools", "probe_bound_host.cpp")])
+    pb = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    pb.pb_sum.restype = C.c_double
+    pb.pb_sum.argtypes = [dp, dp, dp, dp, C.c_double]
+    pb.pb_skippable.restype = C.c_int
+    pb.pb_skippable.argtypes = [dp, dp, dp, dp, C.c_double, C.c_double, C.c_double]
+    P = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+    M, G, KF, IR, D = 1.03, 9.82, 1.435e-5, 5e-5, 0.26
+    J = np.array([16.83e-3, 16.83e-3, 28.34e-3])
+    RHO, CD, BEAM = 1.2041, 1.1, 0.05
+    KDZ = 0.5 * RHO * CD * 4 * BEAM * D
+    CM0 = RHO * CD * BEAM * D / 10
+    rng = np.random.RandomState(7)
+    tb, thr = 0.01, 0.01 / 0.01 ** 5
+    rms = lambda x: float(np.sqrt(np.mean(x * x)))
+    worst, n_proven, n = np.inf, 0, 0
+    for variant, sxx in (("main", D ** 3 * 2025 / 729), ("opt", D * D * 285 / 81)):
+        for direct in (1, 0):
+            env = oracle.OracleQuad(tb, 1000, training=False, direct_control=direct, T=1, variant=variant)
+            for k in range(700):
+                scale = 10.0 ** rng.uniform(-3, 0.3)          # hover-like ... twice the done box
+                y = np.zeros(13)
+                y[0:5:2] = rng.normal(0, 2, 3) * (rng.rand() < 0.8)
+                y[1:6:2] = rng.normal(0, 5, 3) * scale
+                q = rng.normal(0, 1, 4) if k % 3 else np.array([1.0, 0, 0, 0]) + rng.normal(0, 0.3 * scale, 4)
+                y[6:10] = q / np.linalg.norm(q) * (1 + rng.normal(0, 1e-3))
+                y[10:13] = rng.normal(0, 10, 3) * scale
+                if direct:
+                    a = np.clip(rng.normal(0, 0.6, 4), -1, 1) if k % 4 else np.zeros(4)
+                    f = (a + 1) * 2 * M * G / 8
+                    w = np.sqrt(f / KF)
+                    F = f.sum()
+                else:
+                    F = M * G * (1 + rng.normal(0, 0.3)); a = np.array([F, *rng.normal(0, 0.05, 3)])
+                    w = np.sqrt(np.clip(F / 4 / KF + rng.normal(0, 1e3, 4), 0, None))
+                    env.set_w(w)
+                omr = ((w[1] - w[0]) + (w[3] - w[2])) * IR
+                f0 = env.drone_eq(0.0, y, a)
+                sc = 1e-6 + np.abs(y) * 1e-3
+                d0, d1 = rms(y / sc), rms(f0 / sc)
+                h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+                h0 = min(h0, tb)                                     # select_initial_step's clamp
+                if k % 5 == 0:
+                    h0 = min(h0 * 10.0 ** rng.uniform(-2, 2), tb)    # the bound holds for ANY 0 < h0 <= h_max = t_bound
+                f1 = env.drone_eq(h0, y + h0 * f0, a)
+                d2 = rms((f1 - f0) / sc) / h0
+                plant = np.array([abs(F), abs(omr) / J[0], CM0 * sxx / J[0], 2 * CM0 * sxx / J[2], KDZ, 1 / M,
+                                  abs((J[2] - J[1]) / J[0]), abs((J[0] - J[2]) / J[1]), abs((J[1] - J[0]) / J[2])])
+                s = pb.pb_sum(P(y), P(f0), P(1 / sc), P(plant), tb)
+                d2b = np.sqrt(s / 13)
+                assert d2b >= d2 * (1 - 1e-9) - 1e-6, (variant, direct, k, d2b, d2)
+                worst = min(worst, d2b / max(d2, 1e-300))
+                ok = pb.pb_skippable(P(y), P(f0), P(1 / sc), P(plant), tb, d1, thr)
+                if ok:   # what the kernels rely on: proven => scipy's h1 >= t_bound
+                    assert max(d1, d2) <= thr and d1 > 1e-15
+                n_proven += ok; n += 1
+    assert worst >= 1.0 and n_proven > 0.5 * n, (worst, n_proven, n)
+    # the preconditions: a near-zero d1 (scipy's other branch) and a degenerate quaternion are never "proven"
+    y = np.zeros(13); y[6] = 1.0
+    z = np.zeros(13)
+    plant = np.array([M * G, 0, 1e-3, 2e-3, KDZ, 1 / M, 0.68, 0.68, 0.0])
+    assert pb.pb_skippable(P(y), P(z), P(np.full(13, 1e3)), P(plant), tb, 0.0, thr) == 0
+    y[6] = 0.3
+    assert pb.pb_skippable(P(y), P(np.full(13, 0.1)), P(np.full(13, 1e3)), P(plant), tb, 50.0, thr) == 0
