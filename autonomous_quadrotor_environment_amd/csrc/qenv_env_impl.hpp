@@ -520,7 +520,7 @@ template <typename T, typename S> struct EnvRegs {
 // storage type, the same cleared counters; the banked return and the episode count go to memory (a rare event)
 template <typename T, typename S>
 __device__ __forceinline__ void reset_env_regs(S* ws, int32_t* wsi, int64_t N, int64_t e, uint64_t seed, uint64_t episode,
-                                               int64_t env_offset, bool key_episode, EnvRegs<T, S>& r) {
+                                               int64_t env_offset, bool key_episode, EnvRegs<T, S>& r, S ang_s[3]) {
     using m = Mth<S>;
     st(ws, ROW_LAST_RETURN, N, e, (S)r.bk.ep_return);   // (what the memory version reads back from the row store_book has just written)
     const int32_t n_ep = wsi[IROW_EPISODES * N + e] + 1;
@@ -531,9 +531,13 @@ __device__ __forceinline__ void reset_env_regs(S* ws, int32_t* wsi, int64_t N, i
 #pragma unroll
     for (int k = 0; k < 13; ++k) r.ys[k] = (S)xf[k];
     const S* q = r.ys + 6;
-    r.bk.ang[0] = (T)m::atan2(S(2) * (q[0] * q[1] + q[2] * q[3]), S(1) - S(2) * (q[1] * q[1] + q[2] * q[2]));
-    r.bk.ang[1] = (T)m::asin(S(2) * (q[0] * q[2] - q[3] * q[1]));
-    r.bk.ang[2] = (T)m::atan2(S(2) * (q[0] * q[3] + q[1] * q[2]), S(1) - S(2) * (q[2] * q[2] + q[3] * q[3]));
+    // (ang_s: the angle rows in the STORAGE type, as reset_env_sampled writes them -- on the mixed handle, fp64 rows and fp32
+    //  arithmetic, the bookkeeping's copy is the rounded one a later load_book would read)
+    ang_s[0] = m::atan2(S(2) * (q[0] * q[1] + q[2] * q[3]), S(1) - S(2) * (q[1] * q[1] + q[2] * q[2]));
+    ang_s[1] = m::asin(S(2) * (q[0] * q[2] - q[3] * q[1]));
+    ang_s[2] = m::atan2(S(2) * (q[0] * q[3] + q[1] * q[2]), S(1) - S(2) * (q[2] * q[2] + q[3] * q[3]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.bk.ang[k] = (T)ang_s[k];
     r.bk.prev_shaping = T(0); r.bk.abs_sum = T(0); r.bk.ep_return = T(0); r.bk.reward = T(0);
     r.bk.i = 0; r.bk.flags = 0;
 }
@@ -600,12 +604,13 @@ __device__ __forceinline__ void fused_env_step(const StepArgs<T, S>& a, int64_t 
     }
     if (a.ar_on == 2 && (bk.flags & FLAG_DONE) != 0 && !warming) {
         // in-band: an episode that ends in a POLICY step restarts here (see k_step's epilogue)
-        reset_env_regs<T, S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, a.ar_key_episode != 0, r);
+        S ang_s[3];
+        reset_env_regs<T, S>(a.ws, a.wsi, N, e, a.ar_seed, a.ar_episode, a.ar_env_offset, a.ar_key_episode != 0, r, ang_s);
         if (last) {   // the rows reset_env_sampled overwrites
 #pragma unroll
             for (int k = 0; k < 13; ++k) st(a.ws, ROW_STATE + k, N, e, r.ys[k]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) st(a.ws, ROW_ANG + k, N, e, bk.ang[k]);
+            for (int k = 0; k < 3; ++k) st(a.ws, ROW_ANG + k, N, e, ang_s[k]);
             st(a.ws, ROW_PREV_SHAPING, N, e, S(0)); st(a.ws, ROW_ABS_SUM, N, e, S(0));
             st(a.ws, ROW_EP_RETURN, N, e, S(0)); st(a.ws, ROW_REWARD, N, e, S(0));
             a.wsi[IROW_I * N + e] = 0; a.wsi[IROW_FLAGS * N + e] = 0;

@@ -328,3 +328,31 @@ def test_fused_rollout_launch_equals_the_separate_launches(aq, handle):
             res.append([x.clone() for x in (ro.actions, ro.rewards, ro.masks, env.state, env.window)])
         for k, (x, y) in enumerate(zip(*res)):
             assert torch.equal(x, y), ("hidden 64", k)
+
+
+@pytest.mark.parametrize("handle", ["mixed", "lean"])
+def test_fused_launch_restart_in_its_last_step_leaves_the_angle_rows_of_the_storage_type(aq, handle):
+    """An env that ends its episode in the LAST step of a fused launch is restarted in registers and written back at once: the
+    angle rows of the new state must be the storage type's (fp64 on the mixed handle, whose bookkeeping runs in fp32), exactly
+    as reset_env_sampled leaves them after a per-step launch.  Short episodes make dozens of envs restart in every step;
+    every env field after the launch, bit for bit (found by tests/tools/fuzz_fused_rollout.py seeds 31 / 32)."""
+    import torch
+    kw = dict(mixed=dict(dtype=torch.float64, compute="f32"), lean=dict(dtype=torch.float64, compute="lean"))[handle]
+    w = aq.ActorCriticWeights.random(128, 75, 4, seed=11); w.std = 0.3
+    res = []
+    for fused in (False, True):
+        env = aq.BatchedQuad(1000, 0.01, 7, training=True, direct_control=1, T=5, **kw)
+        env.set_ppo_fused(fused)
+        ro = aq.PolicyRollout(env, w, 13, store_obs=True, auto_reset=True, seed=5, env_offset=40, inband=True)
+        ro.start()
+        if fused:
+            ro.run(9); ro.run(4)
+        else:
+            for _ in range(13):
+                ro.step()
+        env.ppo_flush()
+        res.append([getattr(env, f).clone() for f in ("state", "window", "i", "ang", "reward", "episode_return", "last_return",
+                                                      "episodes", "done", "solved")] + [ro.actions.clone(), ro.valid.clone()])
+    assert int(res[0][7].sum()) > 500   # restarts happened, many of them in a launch's last step
+    for k, (x, y) in enumerate(zip(*res)):
+        assert torch.equal(x, y), k
