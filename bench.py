@@ -253,7 +253,7 @@ def make_ppo_runner(env, controller, chunk, use_graph, seed, env_offset, n_globa
     dev = env.device if env is not None else dev
     w = load_policy(policy, dev)
     if controller == "ppo_actor":
-        ro = PolicyRollout(env, ActorCriticWeights(w.actor, None, env.device), chunk)
+        ro = PolicyRollout(env, w.actor_only(), chunk)
         if FUSED_ROLLOUT:   # the evaluation loop as ONE library call (qenv_policy_rollout: one launch of k_ppo_fused per chunk)
             def fused_body():
                 ro.t = 0
