@@ -495,16 +495,16 @@ __global__ __launch_bounds__(256, QENV_STEP_MIN_WAVES) void k_step(const StepArg
 // mostly fixed cost: every launch of the forward stages 159 KiB of weights per workgroup (13 k of its ~40 k cycles), every
 // launch of the step kernel starts with a load round trip that one wave per SIMD cannot hide, and both pay launch + drain.
 // Here a wave OWNS its 64-env blocks for the whole rollout: per step and block it runs mlp3_tile_forward on the block's two
-// 32-env tiles and then step_one on the 64 envs -- the same device functions on the same buffers in the same order as the two
+// 32-env tiles and then the env step on the 64 envs -- the same device functions on the same values in the same order as the two
 // kernels, so every buffer is bit-identical to the stepwise path (tests) -- and the weights are staged once per launch.
 // Nothing crosses waves (an env's window, action and state are touched by its own wave only): no grid-wide synchronisation,
-// only the wave's own memory ordering between the phases: its stores of one phase are the loads of the next, on the same CU --
-// a WORKGROUP-scope fence (a wait for the stores; the CU's vector L1 is coherent with the CU's own writes).  An agent-scope
-// fence writes back / invalidates the XCD's L2 every time (measured: the window loads that follow took 25 k cycles).
-// The block's 64 observation windows stay in registers for the whole horizon (75 floats per lane, env layout): the MFMA operands
-// of the two tiles come out of v_permlane32_swap, the observation copy is stored from the env layout, and per step only the slice
-// the env step has just pushed into the ring is read back.  Both tiles' outputs are finished in one 64-lane pass (exact tanh,
-// stores, sampling); the action reaches the env step in registers; the step's state rows are requested ahead of the tiles.
+// and since round 4 no memory ordering inside the loop either -- the block's observation windows (75 floats per lane, env
+// layout) AND its env state and bookkeeping (fused_env_step below) stay in registers for the whole horizon: the MFMA operands
+// of the two tiles come out of v_permlane32_swap, the observation copy is stored from the env layout, the slice a step pushes
+// goes straight into the window registers, the action reaches the env step in registers, and the state / bookkeeping rows and
+// the ring are written by the launch's last step.  (Round 3 ran the step through memory behind a workgroup-scope fence; an
+// agent-scope fence, the first version, wrote back / invalidated the XCD's L2 every step: 25 k cycles for the loads behind it.)
+// Both tiles' outputs are finished in one 64-lane pass (exact tanh, stores, sampling).
 // ---- the env step of k_ppo_fused: state and bookkeeping of the block's envs stay in REGISTERS for the whole horizon ---------
 // step_one's arithmetic, call for call (prepare_action, integrate, euler_update, done_reward on the same values: every buffer
 // the fused launch writes is compared bit for bit with the per-step launches), without its memory round trip: per step only what
@@ -654,9 +654,9 @@ __global__ __launch_bounds__(256) void k_ppo_fused(const FusedArgs<T, S> fa) {
 #pragma unroll 1
     for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < n_blocks; blk += wave_stride) {
         // ---- the block's 64 windows live in REGISTERS for the whole horizon: w[k] = element k (time order) of this lane's env.
-        // Read from the ring once; per step the newest slice (15 rows, just written by this wave's step) is read back and the
-        // window shifts by one slice.  (Reading the two tiles' windows from the ring every step was 80 loads of 256 B per wave
-        // and step on a CU path of ~12 B per clock: ~2.5 k cycles per tile in front of its first MFMA.)
+        // Read from the ring once; per step the slice the env step pushes enters the registers directly and the window shifts by
+        // one slice.  (Reading the two tiles' windows from the ring every step was 80 loads of 256 B per wave and step on a CU
+        // path of ~12 B per clock: ~2.5 k cycles per tile in front of its first MFMA.)
         const int64_t eb = (blk << bsh) + lane;
         const bool ev = eb < N && lane < benvs;
         const int64_t ebc = ev ? eb : N - 1;
