@@ -782,3 +782,33 @@ def test_ragged_sizes_fused_equals_stepwise_and_masked_reset(aq, N):
         one.reset(x0[:, e:e + 1].contiguous())
         one.reset_sampled(5, 3, 1000 + e, mask=torch.ones(1, dtype=torch.uint8, device="cuda"), push_window=True)
         assert torch.equal(one.state[:, 0], a.state[:, e]) and int(one.i[0]) == int(a.i[e]), e
+
+
+@pytest.mark.parametrize("handle", ["lean", "f64", "f32"])
+def test_probe_skip_in_the_constant_action_rollout_equals_the_full_initial_step(aq, handle):
+    """The constant-action rollout skips select_initial_step's second right-hand-side evaluation wherever
+    csrc/qenv_probe_bound.hpp proves it cannot matter; the per-step launches (k_step) always evaluate it.  Both must produce the
+    SAME bits: config 2's own states (positions exactly zero: their error scale is atol, the first sub-step of some envs is
+    shorter than the interval), wild states far outside the done box (the proof fails for some lanes of a wave, holds for others)
+    and an exact hover (scipy's other branch), dynamics only and full steps."""
+    import bench
+    from autonomous_quadrotor_environment_amd import _lib as L
+    kw = {"lean": dict(dtype=torch.float64, compute="lean"), "f64": dict(dtype=torch.float64), "f32": dict(dtype=torch.float32)}[handle]
+    N = 4096
+    x_cfg2 = bench.make_init("config2", 65536, 0, N)
+    rng = np.random.RandomState(3)
+    x_wild = bench.make_init("config3", 262144, 0, N)
+    x_wild[:, 1:6:2] *= rng.choice([0.01, 1.0, 4.0], (N, 1)); x_wild[:, 10:13] *= rng.choice([0.01, 1.0, 5.0], (N, 1))
+    x_wild[::64] = [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]   # an exact hover in every wave
+    for x0, dyn_only in ((x_cfg2, True), (x_wild, True), (x_wild, False)):
+        xs = torch.from_numpy(np.ascontiguousarray(x0.T))
+        a = aq.BatchedQuad(N, 0.01, 10 ** 9, training=False, direct_control=1, T=1, **kw)
+        b = aq.BatchedQuad(N, 0.01, 10 ** 9, training=False, direct_control=1, T=1, **kw)
+        a.reset(xs); b.reset(xs)
+        flags = L.STEP_DYNAMICS_ONLY if dyn_only else L.STEP_FULL
+        a.rollout("const", 7, flags=flags)
+        for _ in range(7):
+            b.step(None, flags=flags)
+        both_nan = torch.isnan(a.state) & torch.isnan(b.state)   # (a wild env may blow up: then in both, at the same place)
+        assert bool(((a.state == b.state) | both_nan).all()), (handle, dyn_only)
+        assert bool(torch.isfinite(a.state[:, ::64]).all())
