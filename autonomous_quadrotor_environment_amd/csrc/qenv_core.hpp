@@ -530,10 +530,12 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
             const T e = T(dp::E1) * k1[i] + T(dp::E3) * k3[i] + T(dp::E4) * k4[i] + T(dp::E5) * k5[i] +
                         T(dp::E6) * k6[i] + T(dp::E7) * k7[i];
             const T sc = T(1e-6) + m::max_abs(y[i], yn[i]) * T(1e-3);
-            const T r = e * m::rcp_ctl(sc);
+            // (fp32 arithmetic keeps h inside every term: with scales down to 1e-6 the un-scaled sum of a diverging state
+            // overflows, and inf * h^2 stays inf however far the controller shrinks h -- the attempt could never recover)
+            const T r = (sizeof(T) == 4 ? h * e : e) * m::rcp_ctl(sc);
             err2 += r * r;
         }
-        err2 = err2 * (h * h);
+        if constexpr (sizeof(T) != 4) err2 = err2 * (h * h);
         if constexpr (m::lean) {
             // the hardware reciprocal is good to 2^-23: whenever the fast norm cannot decide err < 1 with a wide margin,
             // form it again with full-precision quotients (rare: the branch is taken by ~1e-5 of the attempts)
@@ -591,7 +593,8 @@ __device__ __forceinline__ T rk45_initial_step(const T y[13], const T k1[13], co
     if constexpr (!P::robust && QENV_PROBE_SKIP) if (pl.skip_probe) {
         ProbePlant<T> pp;
         pp.F_abs = m::abs(u.F); pp.omrj_abs = m::abs(u.omrj); pp.cmj_xy = pl.cmj_xy; pp.cmj_z = pl.cmj_z;
-        pp.kd = T(phys::KDZ > phys::KDX ? phys::KDZ : phys::KDX); pp.inv_m = T(1.0 / phys::M);
+        constexpr double kd_xy = phys::KDY > phys::KDX ? phys::KDY : phys::KDX;   // the largest of the three drag coefficients
+        pp.kd = T(phys::KDZ > kd_xy ? phys::KDZ : kd_xy); pp.inv_m = T(1.0 / phys::M);
         pp.cx = T((phys::JZ - phys::JY) / phys::JX < 0 ? -(phys::JZ - phys::JY) / phys::JX : (phys::JZ - phys::JY) / phys::JX);
         pp.cy = T((phys::JX - phys::JZ) / phys::JY < 0 ? -(phys::JX - phys::JZ) / phys::JY : (phys::JX - phys::JZ) / phys::JY);
         pp.cz = T((phys::JY - phys::JX) / phys::JZ < 0 ? -(phys::JY - phys::JX) / phys::JZ : (phys::JY - phys::JX) / phys::JZ);

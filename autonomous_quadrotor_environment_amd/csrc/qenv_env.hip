@@ -155,7 +155,7 @@ int qenv_outer_reset(qenv_t q, const uint8_t* mask) {
 int qenv_set_ppo_fused(qenv_t q, int enabled) {
     if (!q) return fail(QENV_ERR_ARG, "qenv_set_ppo_fused: null handle");
     q->ppo_fused = enabled ? 1 : 0;
-    q->ppo_fused_block = (enabled == 5 || enabled == 6) ? enabled : 0;
+    if (enabled == 5 || enabled == 6) q->ppo_fused_block = enabled;   // a plain 0 / 1 leaves a forced block as it is
     return QENV_OK;
 }
 

@@ -1564,6 +1564,19 @@ template <typename T, typename S, bool LEAN = false> int do_ppo_fused(qenv_s* q,
     FusedArgs<T, S> fa;
     fa.st = make_step_args<T, S>(q, p->out_action, nullptr, nullptr, p->out_reward, p->out_done, p->out_mask, QENV_STEP_NO_AUX, q->win_head,
                                  deterministic ? nullptr : &ex);
+    // fused_env_step restates step_one for the plain in-band case only: whatever else a step can carry -- a mask or an env
+    // list, an overlapped-step skip list, an observation output, a mode with auxiliary outputs, an outer loop, a sensor, a
+    // robust plant -- is refused HERE, so a regression of the caller's gate (ppo_fused_ok) fails loudly instead of
+    // computing a different env
+    {
+        const auto& st = fa.st;
+        if (st.mask || st.idx || st.count || st.env_skip || st.out_obs || st.sens || st.outer_kind != QENV_OUTER_NONE || q->robust ||
+            (st.mode & ~QENV_STEP_NO_AUX) != 0 || st.ar_idx || st.ar_count || st.ar_flags_next || !st.win || q->cfg.T != 5 ||
+            q->cfg.integrator != QENV_RK45 || !q->cfg.direct_control)
+            return fail(QENV_ERR_STATE, "k_ppo_fused: the step carries a feature the fused launch does not implement (mask / env list / "
+                                        "skip list / out_obs / aux mode / outer loop / sensor / robust plant / list auto-reset); "
+                                        "the separate launches handle it (qenv_set_ppo_fused(q, 0))");
+    }
     MlpArgs& m = fa.ml;
     m = MlpArgs{};
     m.win = q->window; m.N = q->N; m.T = q->cfg.T; m.head = q->win_head; m.n_out = 4; m.final_tanh = 1;

@@ -10,6 +10,7 @@ Reference (relative to /root/reference):
 """
 import ctypes as C
 import itertools
+import weakref
 
 import numpy as np
 import torch
@@ -27,13 +28,23 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-# One version cell per weight STORAGE (keyed by the first layer's device pointer), shared by every ActorCriticWeights that
-# wraps the same tensors: `ActorCriticWeights(w.actor, None)` is such an alias (dev() hands fp32 device tensors back as they
-# are), and an env that holds the alias must see the learner's touch() of the object it trains.  Version numbers come from
-# one process-wide counter, so a number is never handed out twice (a fresh storage at a recycled address cannot collide
-# with an image built from the old one).
-_VERSION_CELLS = {}
+# One version cell per weight STORAGE, shared by every ActorCriticWeights that wraps the same tensors:
+# `ActorCriticWeights(w.actor, None)` is such an alias (dev() hands fp32 device tensors back as they are), and an env that
+# holds the alias must see the learner's touch() of the object it trains.  Ownership: the wrappers hold their cells strongly;
+# the registry (device pointer of the first layer -> cell) holds them weakly, so an entry goes when the last wrapper of a
+# storage goes, and a cell is registered under ONE address -- its home -- at a time (re-homing drops the old key: a later,
+# unrelated tensor that the caching allocator places at a freed address starts a cell of its own).  Version numbers come
+# from one process-wide counter, so a number is never handed out twice.
+class _VersionCell:
+    __slots__ = ("v", "home", "__weakref__")
+
+    def __init__(self, home):
+        self.v = next(_NEXT_VERSION)
+        self.home = home          # data_ptr() of the first layer where the trained values live now
+
+
 _NEXT_VERSION = itertools.count(1)
+_VERSION_CELLS = weakref.WeakValueDictionary()
 
 
 def _version_cell(t_in, t_dev):
@@ -41,7 +52,8 @@ def _version_cell(t_in, t_dev):
     alias = isinstance(t_in, torch.Tensor) and t_in.device == t_dev.device and t_in.data_ptr() == p
     cell = _VERSION_CELLS.get(p) if alias else None
     if cell is None:   # our own copy of the caller's numbers (or a storage nobody registered): a new cell
-        cell = _VERSION_CELLS[p] = [next(_NEXT_VERSION)]
+        cell = _VersionCell(p)
+        _VERSION_CELLS[p] = cell
     return cell
 
 
@@ -67,14 +79,28 @@ class ActorCriticWeights:
             self._cells["critic"] = _version_cell(critic[0], self.critic[0])
 
     def version_of(self, head):
-        """The version of `head`'s storage, looked up by where its first layer lives NOW (PpoLearner re-homes the tensors
-        into its flat parameter buffer: the cell follows them)."""
+        """The version of `head`'s storage.  A wrapper whose tensors are no longer where the cell's values live -- an alias
+        made BEFORE a PpoLearner re-homed the weights into its flat parameter buffer -- holds stale copies and raises."""
         t = self.head(head)[0]
-        cell = _VERSION_CELLS.get(t.data_ptr())
-        if cell is None:
-            cell = _VERSION_CELLS[t.data_ptr()] = self._cells.get(head) or [next(_NEXT_VERSION)]
-        self._cells[head] = cell
-        return cell[0]
+        cell = self._cells[head]
+        if cell.home != t.data_ptr():
+            raise RuntimeError(f"ActorCriticWeights: this wrapper's {head} tensors are not the trained ones any more (a PpoLearner "
+                               "moved the weights into its flat parameter buffer after this alias was made); make the alias "
+                               "(actor_only()) after constructing the learner")
+        return cell.v
+
+    def _rehome(self):
+        """The wrapper's tensors were replaced by views of another buffer holding the same values (PpoLearner's flat parameter
+        buffer): the cells follow them -- the old address is released -- and get a new version."""
+        for head in ("actor", "critic"):
+            if head == "critic" and self.critic is None:
+                continue
+            cell, p = self._cells[head], self.head(head)[0].data_ptr()
+            if _VERSION_CELLS.get(cell.home) is cell:
+                del _VERSION_CELLS[cell.home]
+            cell.home = p
+            _VERSION_CELLS[p] = cell
+            cell.v = next(_NEXT_VERSION)
 
     @property
     def version(self):
@@ -86,8 +112,8 @@ class ActorCriticWeights:
         for head in ("actor", "critic"):
             if head == "critic" and self.critic is None:
                 continue
-            self.version_of(head)   # (binds the cell to the tensors' current home)
-            self._cells[head][0] = next(_NEXT_VERSION)
+            self.version_of(head)   # (a stale alias raises here rather than announce values it does not hold)
+            self._cells[head].v = next(_NEXT_VERSION)
 
     @classmethod
     def from_state_dict(cls, sd, device="cuda"):
@@ -306,7 +332,7 @@ class PpoLearner:
         for (h, k), p in zip(keys, params):
             weights.head(h)[k] = self.flat_p[off:off + p.numel()].view_as(p)
             off += p.numel()
-        weights.touch()   # the tensors moved into the flat buffer: the version cells follow them to their new home
+        weights._rehome()   # the tensors moved into the flat buffer: the version cells follow them to their new home
         if self.learn_std and not self.fused_loss:
             raise ValueError("learn_std needs the fused-loss backward (hidden 16, 32, 64 or 128)")
         self.std_param = self.flat_p[-1:] if self.learn_std else None
@@ -500,14 +526,16 @@ class PpoLearner:
         self.w.touch()
         return out
 
-    def update(self, rollout, returns, adv, minibatch=None, generator=None, graph=False):
+    def update(self, rollout, returns, adv, minibatch=None, generator=None, graph=False, perms=None):
         """K_epochs passes over the collected rollout, returning the list of loss dicts.
         graph=True (full-batch epochs, fixed std, one learner): the epoch is replayed from a hipGraph.
         minibatch=None: full-batch epochs (ppo.py:172-203; the reference's randperm of a full batch does not change
         loss.mean()).  minibatch=B: the schedule of visual_landing/ppo_trainer.py:187-196 -- every epoch walks a fresh
         random permutation in batches of B samples, one Adam step per batch, the remainder as a last smaller batch;
         here the permutation is over the stored time steps and a batch is the B // n_envs steps it covers (all envs
-        of a step stay together, so nothing is gathered sample by sample)."""
+        of a step stay together, so nothing is gathered sample by sample).  A remainder of ONE sample is dropped, as
+        `if rest_range > 1` does there (:193).  perms (with minibatch): the K_epochs permutations to walk instead of fresh
+        torch.randperm draws -- [K_epochs, n] integers (a recorded schedule: the G26 fixture replays the reference's)."""
         n = rollout.t
         out = []
         valid = getattr(rollout, "valid", None)
@@ -539,10 +567,15 @@ class PpoLearner:
             return out
         N = rollout.obs.shape[2]
         per = max(1, int(minibatch) // N)
-        for _ in range(self.K_epochs):
-            perm = torch.randperm(n, device=rollout.obs.device, generator=generator)
-            for lo in range(0, n, per):
-                idx = perm[lo:lo + per]
+        if perms is not None:
+            perms = torch.as_tensor(perms, device=rollout.obs.device, dtype=torch.int64)
+            if tuple(perms.shape) != (self.K_epochs, n):
+                raise ValueError(f"perms: expected [{self.K_epochs}, {n}] (one permutation of the stored steps per epoch)")
+        for ep in range(self.K_epochs):
+            perm = perms[ep] if perms is not None else torch.randperm(n, device=rollout.obs.device, generator=generator)
+            rest = n % per
+            batches = [perm[k * per:(k + 1) * per] for k in range(n // per)] + ([perm[n - rest:]] if rest * N > 1 else [])
+            for idx in batches:
                 out.append(self.gradients(rollout.obs[idx], rollout.actions[idx], rollout.logprobs[idx], adv[idx], returns[idx]))
                 self.adam_step()
         return out

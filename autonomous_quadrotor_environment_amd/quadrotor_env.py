@@ -598,7 +598,8 @@ class BatchedQuad:
     def set_ppo_fused(self, on=True, block=None):
         """Whether PolicyRollout.run (in-band) and policy_rollout use the ONE fused launch (policy + env step of the whole
         call, k_ppo_fused; the default) where it applies, or the separate policy / env-step launches.  Bit-identical results.
-        block: force 32- or 64-env blocks per wavefront (default: 32 for batches that would leave half the wavefronts idle)."""
+        block: force 32- or 64-env blocks per wavefront (default: 32 for batches that would leave half the wavefronts idle);
+        block=None leaves a block forced earlier as it is (set_ppo_fused_block(None) clears it)."""
         self._bind()
         if block not in (None, 32, 64):
             raise ValueError("block: None (chosen by the batch size), 32 or 64 envs per wavefront")

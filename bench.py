@@ -4,10 +4,17 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over this rank's batch: one `quad.step()` for every env.
-Default workload = BASELINE.json configs[1]: 65 536 parallel envs per GPU, zero action from a
-(perturbed) hover, dynamics only, the reference's integrator (scipy-exact adaptive RK45).  Envs
-shard across ranks with no data-path collective (weak scaling: per-GPU batch fixed); the episode
-returns are all-gathered once after the timed region for the configs that have rewards.
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration: 262 144 parallel
+envs per GPU, the LQR inner loop (lqr_quad.py:123-168) on random initial states (seed 3), the full
+step (integrator, Euler angles, done, reward), the reference's integrator (scipy-exact adaptive RK45),
+500-step episodes.  (Rounds 1-4 quoted configs[1], the smaller one; it is now the first entry of
+`configs`, perturbed and literally-at-hover.)  Envs shard across ranks with no data-path collective
+(weak scaling: per-GPU batch fixed); the episode returns are all-gathered once after the timed region
+for the configs that have rewards.
+
+Rank 0 prints TWO lines: first `{"bench_detail": ...}` (every slice in full: configs, next_rows, extras),
+then -- last, so that a tail of stdout holds it whole -- the ONE contract line `{"metric": ...}` with the
+headline, its roofline, the CPU baseline and a compact copy of every slice.
 
 N > 1: one process per GPU over RCCL.  Under `python -m torch.distributed.run` the ranks come
 from the environment; started plainly with `--gpus N` this process only launches those N ranks
@@ -21,9 +28,9 @@ for all of them -- fp32 arithmetic (fp32 and mixed handles) is at 1e-4 / 5e-5 af
 config 2 already (thrust minus weight cancels to 1e-6 m/s^2 in fp32).
 
 The K-step region (barrier + sync on both sides, exactly K steps) is repeated until >= 0.3 s
-have been timed; `ms_per_step` / `value` are the MEDIAN region.  Rank 0 prints ONE JSON line
-with the contract fields plus `roofline`, `cpu_baseline`, `sustained` and (default 1-GPU run)
-`configs`: short per-GPU slices of BASELINE configs[2..4].  A rank's clock for a region stops when its own GPU
+have been timed; `ms_per_step` / `value` are the MEDIAN region.  The contract line carries
+the contract fields plus `roofline`, `cpu_baseline`, `sustained` and (default run)
+`configs`: short per-GPU slices of the other BASELINE configs.  A rank's clock for a region stops when its own GPU
 has finished (torch.cuda.synchronize); the MAX all-reduce over the ranks closes the bracket afterwards.
 
 --workload config5 can collect the rank's env range as `--stream-shards` S shards on their own HIP streams (default 1: since
@@ -60,8 +67,11 @@ WORKLOADS = {
     # name: (envs/GPU, direct_control, controller, flags, bytes/env-step, qualified handle, description)
     "config2": (65536, 1, "const", 1, BYTES_DYNAMICS, "lean",
                 "BASELINE configs[1]: 65536 envs/GPU, zero action, perturbed hover, dynamics only"),
+    "config2_hover": (65536, 1, "const", 1, BYTES_DYNAMICS, "lean",
+                      "BASELINE configs[1] literally: 65536 envs/GPU, zero action from EXACT hover (f0 = 0: scipy's h0 = 1e-6 "
+                      "branch, ~5 growing sub-steps = ~32 right-hand sides per step although nothing moves), dynamics only"),
     "config3": (262144, 0, "lqr", 2, BYTES_FULL, "lean",
-                "BASELINE configs[2]: 262144 envs/GPU, LQR inner loop, random init, full step"),
+                "BASELINE configs[2]: 262144 envs/GPU, LQR inner loop, random init (seed 3), full step, 500-step episodes"),
     # PPO workloads: controller names select the runner below; bytes from SURVEY.md section 8d
     "config4": (131072, 1, "ppo_actor", 2, BYTES_FULL + 360, "lean",
                 "BASELINE configs[3]: 131072 envs/GPU (1048576 on 8), PPO actor MLP 75-128-128-4 (matrix cores, fp32-accurate) in the "
@@ -76,6 +86,7 @@ MAX_CLOCK_GHZ = 2.4
 # matrix-core instructions k_mlp<128,5,BF16=2> executes per 32-env tile: name -> (count, pipe cycles each, flops each)
 # layer 1: 4 output tiles x 5 k-steps x 6 split products; layer 2: 4 x 4 x 2 x 6 (k_mlp_v3, csrc/qenv_ppo.hip)
 MLP_MFMA = {"v_mfma_f32_32x32x16_bf16": (120 + 192, 32, 2 * 32 * 32 * 16)}   # round 3: layer 3 runs on the vector lanes
+DEFAULT_WORKLOAD = "config3"   # BASELINE's largest single-GPU configuration (rounds 1-4: config2)
 HANDLES = {  # --dtype -> (torch dtype of the rows, compute mode, arithmetic type reported as `dtype`)
     "f32": (torch.float32, None, "f32"),
     "mix": (torch.float64, "f32", "f32"),
@@ -89,7 +100,7 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20000)
     p.add_argument("--warmup", type=int, default=2000)
-    p.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    p.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     p.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the workload's own size)")
     p.add_argument("--integrator", default="rk45", choices=["rk45", "dp5", "rk4"])
     p.add_argument("--dtype", default="auto", choices=["auto", "f32", "f64", "mix", "lean"],
@@ -162,6 +173,8 @@ def self_launch(args):
     for ln in proc.stdout:
         if ln.startswith('{"metric"'):
             line = ln.strip()
+        elif ln.startswith('{"bench_detail"'):
+            print(ln.strip(), flush=True)
         else:
             sys.stderr.write(ln)
     rc = proc.wait()
@@ -176,12 +189,15 @@ def self_launch(args):
 # ---- workload construction ----------------------------------------------------------------------------------------
 def make_init(workload, n_global, lo, hi):
     from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
-    x0 = fast_random_init_states(2 if workload == "config2" else 3, n_global, lo, hi)
+    x0 = fast_random_init_states(2 if workload.startswith("config2") else 3, n_global, lo, hi)
     if workload == "config2":  # hover + N(0, 0.1) velocities and body rates
         x0[:, 0:5:2] = 0.0
         x0[:, 1:6:2] *= 0.05
         x0[:, 6:10] = [1, 0, 0, 0]
         x0[:, 10:13] *= 0.05
+    elif workload == "config2_hover":  # det_state = [0,0,0,0,0,0,1,0,0,0,0,0,0] for every env
+        x0[:] = 0.0
+        x0[:, 6] = 1.0
     return x0
 
 
@@ -371,7 +387,7 @@ def timed_regions(run, per_call, steps, world, dev, min_seconds, max_regions=500
             return ts
 
 
-def kernel_launch_us(run, per_call, launch, reps=8):
+def kernel_launch_us(run, per_call, launch, reps=8, train=0):
     """Average launch-to-launch interval (kernel duration + dependent-launch boundary) of the dominant kernel on a
     saturated stream, from HIP events on the launch stream (the env launches on
     torch's current stream, so torch.cuda.Event brackets it).  An event pair costs more than a short kernel (its two
@@ -384,7 +400,9 @@ def kernel_launch_us(run, per_call, launch, reps=8):
     torch.cuda.synchronize()
     a.record(); run(); b.record()
     torch.cuda.synchronize()
-    train = int(min(2000, max(4, np.ceil(2000.0 / max(a.elapsed_time(b) * 1e3, 1.0)))))
+    whole = train > 0   # a train of a fixed length (one whole episode of an episodic workload: every phase of the episode
+    #                     -- the retry-heavy first steps, the reset launch -- is in every bracket): the plain mean
+    train = train or int(min(2000, max(4, np.ceil(2000.0 / max(a.elapsed_time(b) * 1e3, 1.0)))))
     ts = []
     for _ in range(reps):
         a.record()
@@ -394,7 +412,7 @@ def kernel_launch_us(run, per_call, launch, reps=8):
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e3 / train)
     ts.sort()
-    us = float(np.mean(ts[: max(1, len(ts) * 3 // 4)]))  # drop the slowest quarter (clock ramps, interrupts)
+    us = float(np.mean(ts)) if whole else float(np.mean(ts[: max(1, len(ts) * 3 // 4)]))  # drop the slowest quarter (clock ramps, interrupts)
     return us if launch == "fused" else us / per_call
 
 
@@ -412,7 +430,7 @@ def pick(total, cap, mult=1):
 
 
 def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_graph, envs, rank, world, dev,
-            min_seconds, stream_shards=1, policy="trained", schedule="inband"):
+            min_seconds, stream_shards=1, policy="trained", schedule="inband", want_sustained=False, want_step_api=False):
     """One workload on this rank's shard: W untimed warm-up steps, the K-step region repeated (median), the dominant
     kernel's per-launch time by HIP events, and its roofline block.  Returns (result dict, env, runner info)."""
     from autonomous_quadrotor_environment_amd.distributed import all_gather_returns, shard_range
@@ -508,7 +526,13 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
     spl = chunk if launch == "fused" else 1
     # (the PPO workloads time their dominant kernel, the policy forward, by itself below: `run` is a whole horizon there,
     # collectives included)
-    k_us = kernel_launch_us(run, per_call, launch) if not ppo else 1.0
+    if ppo:
+        k_us = 1.0
+    elif episodic and launch == "fused":   # whole episodes per event bracket (the reset launch rides along: ~10 us in 15 ms)
+        ep["n"] = EPISODE_STEPS            # every bracket starts at an episode start
+        k_us = kernel_launch_us(run, per_call, launch, reps=4, train=max(1, EPISODE_STEPS // per_call))
+    else:
+        k_us = kernel_launch_us(run, per_call, launch)
     algo_bytes = bytes_per_step * (hi - lo) * spl
     achieved = algo_bytes / (k_us * 1e-6) / 1e9
     ttype = {"f32": "float, float", "mix": "float, double", "lean": "double, double (lean)", "f64": "double, double"}[handle]
@@ -588,7 +612,34 @@ def measure(workload, handle, integrator, launch, steps, warmup, chunk_arg, no_g
                                        "block_step_cycles_median": st["step_cycles_median"], "env_step_cycles_median": ph["env step"][1],
                                        "source": "recorded: profiles/r03_fused_stamps_*.json (a 32-env tile of layers 1-3 on its lone "
                                                  "wave; a block-step = two tiles + the env step of 64 envs)"}
+    # what the same kernel sustains when the launch granularity is not tied to K: 250-step launches, one bracket around
+    # >= min_seconds of them (the driver's K = 20 makes every region a single 20-step launch + its sync); episodic
+    # workloads keep their 500-step episodes (two launches and a reset each)
+    sustained = None
+    if want_sustained and not ppo and launch == "fused":
+        r2, pc, _ = runner(250)
+        r2 = episodic_run(r2, pc)
+        ep["n"] = EPISODE_STEPS
+        time_region(r2, pc, 500, world, dev)
+        t1 = time_region(r2, pc, 500, world, dev)
+        n_l = max(1, int(np.ceil(min_seconds / max(t1, 1e-6))))
+        if world > 1:  # the same launch count on every rank
+            t = torch.tensor([n_l], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n_l = int(t.item())
+        s_ = time_region(r2, pc, 500 * n_l, world, dev)
+        sustained = {"value": n_global * 500 * n_l / s_, "unit": "env-steps/s", "steps": 500 * n_l, "steps_per_launch": 250,
+                     "seconds": s_, "hbm_frac": n_global / world * 500 * n_l / s_ * bytes_per_step / 1e9 / HBM_PEAK_GBPS}
+    step_api = None
+    if want_step_api and not ppo and world == 1:   # the path quad.step() callers take: one launch per env step (hipGraph replay)
+        r3, pc3, _ = (make_runner(env, controller, flags, "step", 250, not no_graph) + (None,))
+        r3 = episodic_run(r3, pc3)
+        ep["n"] = EPISODE_STEPS
+        time_region(r3, pc3, 250, world, dev)
+        step_api = {"value": n_global * 1000 / time_region(r3, pc3, 1000, world, dev), "unit": "env-steps/s",
+                    "launch": "one kernel launch per env step, 250 per hipGraph replay" if not no_graph else "one eager launch per env step"}
     res = {"value": value, "ms_per_step": secs / steps * 1e3, "regions": len(regions),
+           "ms_per_step_mean": float(np.mean(regions)) / steps * 1e3, "sustained": sustained, "step_api": step_api,
            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3,
            "timed_seconds": float(sum(regions)), "finite": finite, "chunk": chunk, "launch": launch,
            "hip_graph": (launch == "step" and not no_graph and controller != "ppo_rollout" and not fused_ppo),
@@ -714,13 +765,50 @@ def slice_of(r, name, handle):
            "achieved": rf["achieved"], "roofline_unit": rf["unit"], "stream_shards": r["stream_shards"],
            "episode_steps": r["episode_steps"], "envs_per_kernel_launch": rf.get("envs_per_launch", r["envs_per_gpu"]),
            "all_gathered_returns": r["all_gather_len"], "all_gather_us": r["all_gather_us"]}
-    for k in ("schedule", "valid_row_fraction", "obs_layout"):
+    for k in ("schedule", "valid_row_fraction", "obs_layout", "sustained", "step_api"):
         if r.get(k) is not None:
             out[k] = r[k]
-    for k in ("valu", "mfma_cycles_per_tile", "algorithmic", "bf16_products_tflops"):
+    for k in ("valu", "mfma_cycles_per_tile", "algorithmic", "bf16_products_tflops", "traffic"):
         if k in rf:
             out[k] = rf[k]
     return out
+
+
+COMPACT_KEYS = ("value", "ms_per_step", "steps", "envs_per_gpu", "global_envs", "handle", "finite", "bound", "frac", "kernel_us",
+                "all_gathered_returns", "all_gather_us", "valid_row_fraction")
+
+
+def compact(sl):
+    """The few fields of a slice that the contract line repeats (the whole slice is in the detail line)."""
+    out = {k: sl[k] for k in COMPACT_KEYS if sl.get(k) is not None}
+    if sl.get("weights"):
+        out["weights"] = sl["weights"].split(" ")[0]
+    if sl.get("sustained"):
+        out["sustained_value"] = sl["sustained"]["value"]
+    if isinstance(sl.get("valu"), dict):
+        out["valu_issue_frac"] = sl["valu"]["issue_frac"]
+    if isinstance(sl.get("cpu_baseline"), dict):
+        out["cpu_value"] = sl["cpu_baseline"]["value"]
+    return out
+
+
+def measured_row_copy(dev):
+    """The HBM denominator measured on this box: a row copy with the env kernels' access shape (13 SoA rows,
+    one lane per env), 872 MB read + 872 MB written per launch, far beyond the 256 MiB Infinity Cache.  GB/s."""
+    from autonomous_quadrotor_environment_amd import _lib as L
+    import ctypes as C
+    n_c = 16 * 1024 * 1024
+    src = torch.rand(13, n_c, device=dev, dtype=torch.float32); dst = torch.empty_like(src)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    copy = lambda: L.check(L.lib.qenv_debug_copy_rows(L.F32, L.ptr(dst), L.ptr(src), 13, n_c, st), "copy")
+    for _ in range(3):
+        copy()
+    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a_.record()
+    for _ in range(10):
+        copy()
+    b_.record(); torch.cuda.synchronize()
+    return round(2 * 13 * n_c * 4 * 10 / (a_.elapsed_time(b_) * 1e-3) / 1e9, 1)
 
 
 def main():
@@ -737,12 +825,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     handle = WORKLOADS[args.workload][5] if args.dtype == "auto" else args.dtype
+    default_run = args.workload == DEFAULT_WORKLOAD and args.envs == 0   # the line the driver records
 
     res, env, (controller, flags, no_graph, bytes_per_step, n_global) = measure(
         args.workload, handle, args.integrator, args.launch, args.steps, args.warmup, args.chunk, args.no_graph,
-        args.envs, rank, world, dev, args.min_seconds, args.stream_shards, args.policy, args.schedule)
+        args.envs, rank, world, dev, args.min_seconds, args.stream_shards, args.policy, args.schedule,
+        want_sustained=not args.no_sustained, want_step_api=default_run and not args.no_extras)
     ppo = controller.startswith("ppo")
     qualified = WORKLOADS[args.workload][5]
+    rf = res["roofline"]
+    if "valu" in rf:   # both fractions side by side: HBM on the algorithmic bytes (the contract's `frac`) and vector issue
+        rf["hbm_algorithmic_frac"] = rf["frac"]
+        rf["valu_issue_frac"] = rf["valu"]["issue_frac"]
     out = {
         "metric": "quadrotor env-steps/sec", "value": res["value"], "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
@@ -762,29 +856,22 @@ def main():
                    "all_gathered_returns": res["all_gather_len"], "all_gather_us": res["all_gather_us"]},
         "timing": {"regions": res["regions"], "statistic": "median of the K-step regions (each barrier+sync bracketed)",
                    "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
-                   "timed_seconds": res["timed_seconds"]},
-        "roofline": res["roofline"],
+                   "ms_per_step_mean": res["ms_per_step_mean"], "timed_seconds": res["timed_seconds"]},
+        "roofline": rf,
     }
-
-    # what the same kernel sustains when the launch granularity is not tied to K: 250-step launches, one bracket around
-    # >= 0.3 s of them (the driver's K = 20 makes every region a single 20-step launch + its sync)
-    if not ppo and args.launch == "fused" and not args.no_sustained:
-        r2, pc = make_runner(env, controller, flags, "fused", 250, False)
-        time_region(r2, pc, 250, world, dev)
-        t1 = time_region(r2, pc, 250, world, dev)
-        n_l = max(1, int(np.ceil(args.min_seconds / max(t1, 1e-6))))
-        if world > 1:  # the same launch count on every rank
-            t = torch.tensor([n_l], device=dev, dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            n_l = int(t.item())
-        s = time_region(r2, pc, 250 * n_l, world, dev)
-        out["sustained"] = {"value": n_global * 250 * n_l / s, "unit": "env-steps/s", "steps": 250 * n_l,
-                            "steps_per_launch": 250, "seconds": s}
+    if default_run:
+        out["headline_changed"] = ("config2->config3 (round 5): `value` is BASELINE configs[2], the largest single-GPU "
+                                   "configuration; rounds 1-4 quoted configs[1], now configs.config2 / configs.config2_hover")
+    if res["sustained"]:
+        out["sustained"] = res["sustained"]
+    if res["step_api"]:
+        out["per_step_api"] = res["step_api"]
     del env
+    detail = {}
 
-    # the default single-GPU run of config 2 also reports the other operating points (a few seconds): the
-    # per-step API path (hipGraph-replayed qenv_step launches) and the fixed-step integrators
-    if (args.extras or (args.workload == "config2" and not args.no_extras and args.envs == 0)) and world == 1 and not ppo:
+    # --extras: the other operating points of a non-PPO workload (a few seconds): the per-step API path (hipGraph-replayed
+    # qenv_step launches) and the fixed-step integrators, each in both launch modes, and the fp32 handle
+    if args.extras and world == 1 and not ppo:
         from autonomous_quadrotor_environment_amd.distributed import shard_range
         lo, hi = shard_range(n_global, rank, world)
         extras = {}
@@ -794,64 +881,43 @@ def main():
             for launch in ("step", "fused"):
                 r2, pc = make_runner(e2, controller, flags, launch, ck, not args.no_graph)
                 time_region(r2, pc, ck, 1, dev)
-                s = time_region(r2, pc, 2000, 1, dev)
-                extras[f"{integ}:{launch}"] = n_global * 2000 / s
+                s = time_region(r2, pc, 500, 1, dev)
+                extras[f"{integ}:{launch}"] = n_global * 500 / s
             del e2
         if handle != "f32":  # the fp32 handle (outside the tolerance over >= 500 open-loop steps) for comparison
             e2 = build_env(args.workload, "f32", "rk45", n_global, lo, hi, dev)
             r2, pc = make_runner(e2, controller, flags, "fused", ck, False)
             time_region(r2, pc, ck, 1, dev)
-            extras["rk45:fused:f32_handle"] = n_global * 2000 / time_region(r2, pc, 2000, 1, dev)
+            extras["rk45:fused:f32_handle"] = n_global * 500 / time_region(r2, pc, 500, 1, dev)
             del e2
-        # config 2's unperturbed variant: at EXACT hover f0 = 0, scipy's select_initial_step takes its
-        # h0 = 1e-6 branch and every env step costs ~5 growing sub-steps although the state does not move
-        e3 = build_env(args.workload, handle, "rk45", n_global, lo, hi, dev)
-        hover = torch.zeros(13, e3.n_envs, device=dev, dtype=e3.dtype); hover[6] = 1
-        e3.reset(hover)
-        r3, pc = make_runner(e3, controller, flags, "fused", ck, False)
-        time_region(r3, pc, ck, 1, dev)
-        extras["rk45:fused:exact_hover"] = n_global * 2000 / time_region(r3, pc, 2000, 1, dev)
-        del e3
-        out["extras_env_steps_per_s"] = extras
-        out["extras_note"] = "2000-step regions, 250-step launches / graph replays, same handle as `value` unless named"
+        detail["extras_env_steps_per_s"] = extras
+        detail["extras_note"] = "500-step regions from the initial states, 250-step launches / graph replays, same handle as `value` unless named"
         # the same operating points as a fraction of the 8 TB/s HBM peak on the algorithmic bytes per env step;
-        # BASELINE.json words config 2 as "RK4 dynamics only": that operating point is extras["rk4:fused"]
-        out["extras_hbm_frac"] = {k: round(v * bytes_per_step / 1e9 / HBM_PEAK_GBPS, 4) for k, v in extras.items()}
-        # the denominator measured on this box: a row copy with the env kernels' access shape (13 SoA rows,
-        # one lane per env), 872 MB read + 872 MB written per launch, far beyond the 256 MiB Infinity Cache
-        from autonomous_quadrotor_environment_amd import _lib as L
-        import ctypes as C
-        n_c = 16 * 1024 * 1024
-        src = torch.rand(13, n_c, device=dev, dtype=torch.float32); dst = torch.empty_like(src)
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        copy = lambda: L.check(L.lib.qenv_debug_copy_rows(L.F32, L.ptr(dst), L.ptr(src), 13, n_c, st), "copy")
-        for _ in range(3):
-            copy()
-        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); a_.record()
-        for _ in range(10):
-            copy()
-        b_.record(); torch.cuda.synchronize()
-        out["roofline"]["measured_row_copy_GBps"] = round(2 * 13 * n_c * 4 * 10 / (a_.elapsed_time(b_) * 1e-3) / 1e9, 1)
-        del src, dst
+        # BASELINE.json words config 2 as "RK4 dynamics only": that operating point is extras["rk4:fused"] of --workload config2
+        detail["extras_hbm_frac"] = {k: round(v * bytes_per_step / 1e9 / HBM_PEAK_GBPS, 4) for k, v in extras.items()}
+    if default_run and world == 1 and not args.no_extras:
+        out["roofline"]["measured_row_copy_GBps"] = measured_row_copy(dev)
+        out["roofline"]["frac_of_measured_row_copy"] = rf["achieved"] / out["roofline"]["measured_row_copy_GBps"]
 
-    # short per-GPU slices of the other BASELINE configs (LQR full step, PPO actor in the loop, full PPO rollout + GAE), each
-    # on its qualified handle: the driver's record then covers the 224-B step, the controller and the MLP.  One GPU: config
-    # 3, config 4 (trained actor) and its random-policy variant, config 5 (trained and random policy), each with a ~1 s CPU
-    # baseline beside it.  N > 1: BASELINE defines configs 4 and 5 on the whole node -- they run at their per-GPU sizes on
-    # every rank (max-over-ranks timing, like `value`) and end with the RCCL all-gather of the episode returns, whose
-    # length and own time are in the slice.
-    if args.workload == "config2" and not args.no_subconfigs and args.envs == 0:
+    # short per-GPU slices of the other BASELINE configs, each on its qualified handle: the driver's record then covers the
+    # dynamics-only step, the PPO actor in the loop and the full PPO rollout + GAE besides the LQR headline.  One GPU:
+    # config 2 (perturbed hover, and literally at hover), config 4 (trained actor) and its random-policy variant, config 5
+    # (trained and random policy), each with a ~1 s CPU baseline beside it.  N > 1: BASELINE defines configs 4 and 5 on the
+    # whole node -- they run at their per-GPU sizes on every rank (max-over-ranks timing, like `value`) and end with the
+    # RCCL all-gather of the episode returns, whose length and own time are in the slice.
+    if default_run and not args.no_subconfigs:
         subs = {}
         if world == 1:
-            plan = (("config3", "config3", 250, 250, None), ("config4", "config4", 250, 50, "trained"),
+            plan = (("config2", "config2", 20, 20, None), ("config2_hover", "config2_hover", 250, 250, None),
+                    ("config4", "config4", 250, 50, "trained"),
                     ("config4_random_policy", "config4", 250, 50, "random"), ("config5", "config5", 128, 128, "trained"),
                     ("config5_random_policy", "config5", 128, 128, "random"))
         else:
             plan = (("config4", "config4", 250, 50, "trained"), ("config5", "config5", 128, 128, "trained"))
         for key, name, k_steps, w_steps, pol in plan:
             r, e_, _ = measure(name, WORKLOADS[name][5], "rk45", "fused", k_steps, w_steps, 0, False, 0, rank, world, dev, 0.2,
-                               args.stream_shards, pol or "trained", args.schedule)
+                               args.stream_shards, pol or "trained", args.schedule,
+                               want_sustained=(key == "config2"), want_step_api=(key == "config2" and world == 1))
             subs[key] = slice_of(r, name, WORKLOADS[name][5])
             subs[key]["steps"] = k_steps
             del e_
@@ -859,12 +925,19 @@ def main():
                 c = cpu_baseline(name, "rk45", 1.5, pol or "trained", steps=100)
                 subs[key]["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample", "single_thread_rate",
                                                                "fp32_build")}
-        out["configs"] = subs
+        if "config2" in subs:
+            subs["config2"]["note"] = ("rounds 1-4's headline: `value` = every timed region ONE 20-step launch (the driver's K), "
+                                       "`sustained` = 250-step launches")
+        detail["configs"] = subs
+        out["configs"] = {k: compact(v) for k, v in subs.items()}
     # the two GEMM-shaped rows that are not a BASELINE config of their own: config 4's dense-tail shape
     # (rl_nn_model.py 800 -> 64 -> 64 -> 3 on synthetic U(-1,1) features, 131 072 samples) and one PPO update epoch over a
     # config-5 horizon (65 536 envs x 128 steps = 8.4 M samples: fused-loss backward, weight gradients, Adam, both heads)
-    if args.workload == "config2" and world == 1 and not args.no_subconfigs and args.envs == 0:
-        out["next_rows"] = next_rows(dev, args.policy)
+    if default_run and world == 1 and not args.no_subconfigs:
+        nr = next_rows(dev, args.policy)
+        detail["next_rows"] = nr
+        out["next_rows"] = {"dense_tail_800_64_64_3": {k: nr["dense_tail_800_64_64_3"][k] for k in ("samples", "kernel_us", "hbm_frac", "mfma_pipe_busy_at_nominal_clock")},
+                            "ppo_update_epoch": {k: nr["ppo_update_epoch"][k] for k in ("samples", "seconds", "samples_per_s", "hbm_GB_per_epoch", "hbm_GBps")}}
     if world > 1:
         out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
         out["dist_backend"] = dist.get_backend()
@@ -872,7 +945,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.integrator, args.cpu_seconds, args.policy)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        if detail:
+            print(json.dumps({"bench_detail": detail}), flush=True)
+        print(json.dumps(out), flush=True)   # the contract line: last
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

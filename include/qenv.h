@@ -436,7 +436,8 @@ int qenv_policy_rollout(qenv_t q, int k_in, int hidden, const float *W1, const f
  * one fused launch where it applies (1, the default; the environment variable QENV_PPO_FUSED sets the initial value) or as the
  * separate policy / env-step launches (0).  Results are bit-identical either way.  5 / 6: on, with the launch's env blocks forced
  * to 32 / 64 envs per wavefront (by default a batch that leaves half the chip's wavefronts without a 64-env block runs as 32-env
- * blocks: one policy tile and a half-wave env step per wavefront and step; the tests force both). */
+ * blocks: one policy tile and a half-wave env step per wavefront and step; the tests force both).  A plain 0 / 1 leaves a
+ * block forced earlier (here or by qenv_set_ppo_fused_block) as it is; qenv_set_ppo_fused_block(q, 0) clears it. */
 int qenv_set_ppo_fused(qenv_t q, int enabled);
 /* ABI 8.  Only the env block of the fused launch -- 0 (chosen by the batch size), 32 or 64 envs per wavefront -- leaving the
  * on / off state of qenv_set_ppo_fused (and of QENV_PPO_FUSED) as it is: what a caller that runs several handles side by side

@@ -1019,8 +1019,188 @@ def g22():
          out_critic32=out_c.numpy(), out_actor64=ref_a.numpy(), out_critic64=ref_c.numpy(), **w)
 
 
+def g26():
+    """a22, the landing trainer's variant (visual_landing/ppo_trainer.py): `PPO.update` -- get_advantages (ddof 1), K_epochs = 5
+    passes over fresh permutations in minibatches of BATCH_SIZE = 1536 with the remainder as a last smaller batch (:187-196)
+    -- and `PPO.optimizer_step` (:96-131: joint-probability ratio, clipped surrogate, actor.mean() + 0.01 (-H).mean() + 0.5 MSE,
+    Adam lr 2e-5 over policy.parameters(), the learned std among them) are the REFERENCE'S OWN methods, taken out of the file
+    with ast (the module's top imports need a GPU model zoo and PPO.__init__ builds the conv policy and reads / writes
+    ./visual_landing/*.pth) together with the module-level hyper-parameters they close over.  The policy they train is a
+    subclass of the reference's rl_nn_model_v2.ActorCritic that keeps the class's own `evaluate` (MultivariateNormal over
+    diag(std^2), entropy, squeezed value: :232-247) and `std` parameter and replaces only the two networks -- the conv + fc
+    actor / critic, out of scope -- by the controller's MLP heads (75 -> 32 -> 32 -> 4 tanh / 1) on the `sens` vector.
+    torch.randperm is recorded (the fixture holds every epoch's permutation) and torch.save is a no-op.  Harness-side
+    import stubs: cv2, torchvision (absent here; the v2 module uses them in plotting helpers only)."""
+    for name in ("cv2", "torchvision", "torchvision.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    with quiet:
+        from visual_landing.rl_nn_model_v2 import ActorCritic as LandingV2
+    torch.autograd.set_detect_anomaly(False)   # (the v2 module switches it on process-wide at import, quirk Q14)
+    H = 32
+
+    class MlpLanding(LandingV2):
+        def __init__(self, std):
+            torch.nn.Module.__init__(self)
+            self.device = torch.device("cpu")
+            tanh, lin = torch.nn.Tanh, torch.nn.Linear
+            self.actor_mlp = torch.nn.Sequential(lin(75, H), tanh(), lin(H, H), tanh(), lin(H, 4), tanh())
+            self.critic_mlp = torch.nn.Sequential(lin(75, H), tanh(), lin(H, H), tanh(), lin(H, 1))
+            self.std = torch.nn.Parameter(torch.tensor(std))
+            self.action_var = torch.full((4,), 1, device=self.device, dtype=torch.float)
+
+        def forward(self, image, sens):
+            return self.actor_mlp(sens)
+
+        def critic(self, image, sens, action):
+            return self.critic_mlp(sens)
+
+    tree = ast.parse(_src("visual_landing/ppo_trainer.py"))
+    perms = []
+
+    class TorchProxy:
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def save(*a, **k):
+            pass
+
+        @staticmethod
+        def randperm(n, device=None):
+            p = torch.randperm(n)
+            perms.append(p.numpy().copy())
+            return p
+    ns = {"torch": TorchProxy(), "nn": torch.nn, "np": np}
+    for node in tree.body:   # lr_ac, action_std, K_epochs, eps_clip, gamma, betas, BATCH_SIZE: the file's own values
+        if isinstance(node, ast.Assign) and all(isinstance(t, ast.Name) for t in node.targets):
+            exec(compile(ast.Module([node], []), "ppo_trainer(constants)", "exec"), ns)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "PPO"][0]
+    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("optimizer_step", "get_advantages", "update")]
+    exec(compile(ast.Module(keep, []), "ppo_trainer.PPO(methods)", "exec"), ns)
+    torch.manual_seed(26)
+    ppo = type("PPO", (), {f.name: ns[f.name] for f in keep})()   # the attributes PPO.__init__ sets (:41-79), minus the conv policy and the checkpoint files
+    ppo.device = torch.device("cpu")
+    ppo.critic_loss_memory, ppo.actor_loss_memory, ppo.critic_epoch_loss, ppo.actor_epoch_loss = [], [], [], []
+    ppo.betas, ppo.gamma, ppo.eps_clip, ppo.K_epochs = ns["betas"], ns["gamma"], ns["eps_clip"], ns["K_epochs"]
+    ppo.policy = MlpLanding(ns["action_std"])
+    ppo.optimizer_ac = torch.optim.Adam(ppo.policy.parameters(), lr=ns["lr_ac"], betas=ns["betas"])
+    ppo.policy_old = MlpLanding(ns["action_std"])
+    ppo.policy_old.load_state_dict(ppo.policy.state_dict())
+    ppo.MseLoss = torch.nn.MSELoss()
+    names = {"actor_0": ppo.policy.actor_mlp[0], "actor_2": ppo.policy.actor_mlp[2], "actor_4": ppo.policy.actor_mlp[4],
+             "critic_0": ppo.policy.critic_mlp[0], "critic_2": ppo.policy.critic_mlp[2], "critic_4": ppo.policy.critic_mlp[4]}
+    grab = lambda: dict({f"{k}_{p}": getattr(l, p).detach().numpy().astype(np.float64).copy() for k, l in names.items()
+                         for p in ("weight", "bias")}, std=np.float64(ppo.policy.std.item()))
+    w0 = grab()
+    # a memory filled the way rl_worker does through policy_old.act (rl_nn_model_v2.py:217-234): actions sampled from
+    # MultivariateNormal(mean, std^2 I), their joint log-probability, the critic's value
+    rng = np.random.RandomState(126)
+    n = 2 * ns["BATCH_SIZE"] + 500          # two full minibatches and a remainder per epoch
+    sens = rng.normal(0, 0.5, (n, 75)).astype(np.float32)
+    sens[:, 0:4] = np.clip(sens[:, 0:4], -1, 1)
+
+    class Mem:
+        pass
+    mem = Mem()
+    with torch.no_grad():
+        st = torch.from_numpy(sens)
+        mean = ppo.policy_old.forward(None, st)
+        cov = torch.diag(ppo.policy_old.action_var) * ppo.policy_old.std * ppo.policy_old.std
+        dist = torch.distributions.MultivariateNormal(mean, cov)
+        act = dist.sample()
+        logp = dist.log_prob(act)
+        val = ppo.policy_old.critic(None, st, act).flatten()
+    mem.states = np.zeros((n, 1), np.float32).tolist()       # the camera frames: the MLP heads do not read them
+    mem.last_conv = np.zeros((n, 1), np.float32).tolist()
+    mem.actions, mem.logprobs, mem.sens = act.numpy().tolist(), logp.numpy().tolist(), sens.tolist()
+    mem.state_value = val.numpy().tolist()
+    mem.rewards = rng.normal(0, 1, n).astype(np.float32).tolist()
+    mem.is_terminals = (rng.rand(n) < 0.01).tolist()
+    mem.is_terminals[-1] = True
+    # what update() derives first (recorded for the test: GAE itself is pinned by g10)
+    sv = torch.cat((torch.tensor(mem.state_value), torch.tensor([0.0])))
+    ret, adv = ppo.get_advantages(sv, np.logical_not(mem.is_terminals), torch.tensor(mem.rewards))
+    with quiet:
+        ppo.update(mem)
+    w1 = grab()
+    rec = dict(sens=sens, actions=act.numpy().astype(np.float64), logprobs=logp.numpy().astype(np.float64),
+               values=val.numpy().astype(np.float64), rewards=np.array(mem.rewards, dtype=np.float64),
+               is_terminals=np.array(mem.is_terminals), returns=ret.numpy().astype(np.float64), adv=adv.numpy().astype(np.float64),
+               perms=np.array(perms), batch_size=np.int64(ns["BATCH_SIZE"]), K_epochs=np.int64(ns["K_epochs"]),
+               lr=np.float64(ns["lr_ac"]), eps_clip=np.float64(ns["eps_clip"]), c_entropy=np.float64(0.01), c_value=np.float64(0.5),
+               actor_loss_mean=np.float64(ppo.actor_loss_memory[-1]), critic_loss_mean=np.float64(ppo.critic_loss_memory[-1]))
+    assert len(perms) == ns["K_epochs"] and all(len(p) == n for p in perms)
+    for k in w0:
+        rec["w0_" + k] = w0[k]; rec["w1_" + k] = w1[k]
+    save("g26_landing_trainer_update", **rec)
+
+
+def g27():
+    """The tracking script environment/controller/vel_control_ppo.py (:23-150) as it stands: unit steps and ramps of the
+    velocity reference on x / y / z / xyz fed to the trained N = 128 policy by OFFSETTING ITS OBSERVATION (`dl_input(state +
+    ERROR)`), the z ramp repeating the x ramp (quirk Q10).  The script runs at import, globs the author's home directory for
+    the checkpoint and plots; it is executed whole through ast with three names of its namespace replaced: `glob` (returns
+    the checked-in checkpoint), `plotter` (no-op) and `quad` (the reference's class, recording what step() returns); every
+    loop, constant and branch is the script's own.  Stored per case: the state after every step, the action, and the
+    offset the script added to the observation it pushed."""
+    tree = ast.parse(_src("environment/controller/vel_control_ppo.py"))
+    body = [n for n in tree.body if not isinstance(n, (ast.Import, ast.ImportFrom))
+            and not (isinstance(n, ast.Expr) and isinstance(n.value, ast.Call) and "path" in ast.dump(n.value.func))
+            and not (isinstance(n, ast.Expr) and isinstance(n.value, ast.Constant))]
+    ckpt = os.path.join(REF, "environment/controller/solved/nn_old_solved_128_32000_e8f2b04d78f34fc794e686dcb00944d2.pth")
+    logs = []
+
+    class RecQuad(qe.quad):
+        def __init__(self, *a, **k):
+            with contextlib.redirect_stdout(io.StringIO()):
+                super().__init__(*a, **k)
+            logs.append({"state": [], "action": [], "obs": [], "pushed": [], "done": []})
+
+        def step(self, action):
+            out = super().step(action)
+            if self.i > self.T:   # (reset()'s warm-up steps are not the loop's)
+                lg = logs[-1]
+                lg["state"].append(np.array(self.state, dtype=float)); lg["action"].append(np.array(action, dtype=float).ravel())
+                lg["obs"].append(np.array(out[0], dtype=float).ravel()); lg["done"].append(bool(out[2]))
+            return out
+
+    class RecDl(dl_in_gen):
+        def dl_input(self, states, actions):
+            st = np.asarray(states, dtype=float)
+            if st.ndim == 1 or st.shape[0] == 1:
+                logs[-1]["pushed"].append(st.ravel().copy())
+            return super().dl_input(states, actions)
+
+    class NoPlot:
+        def __init__(self, *a, **k):
+            pass
+
+        def add(self, *a, **k):
+            pass
+
+        def plot(self, *a, **k):
+            pass
+    fake_glob = types.SimpleNamespace(glob=lambda pattern: [ckpt])
+    ns = {"np": np, "torch": torch, "quad": RecQuad, "plotter": NoPlot, "dl_in_gen": RecDl, "ActorCritic": ActorCritic,
+          "glob": fake_glob, "time": __import__("time")}
+    with quiet:
+        exec(compile(ast.Module(body, []), "vel_control_ppo", "exec"), ns)
+    assert len(logs) == 8
+    rec = {"names": np.array(ns["NAME_T"])}
+    for k, lg in enumerate(logs):
+        n = len(lg["state"])
+        assert n == len(lg["pushed"]) == len(lg["action"]) and n > 0
+        rec[f"state_{k}"] = np.array(lg["state"])
+        rec[f"action_{k}"] = np.array(lg["action"])
+        rec[f"offset_{k}"] = np.array(lg["pushed"]) - np.array(lg["obs"])   # what the script added: ERROR[i_alvo] / RAMP[i]
+        rec[f"done_{k}"] = np.array(lg["done"])
+    rec["x0"] = np.array([0, 0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0])
+    save("g27_vel_control_ppo", **rec)
+
+
 if __name__ == "__main__":
     print("reference:", REF, "| numpy", np.__version__, "| scipy", scipy.__version__, "| torch", torch.__version__)
-    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25"]
+    todo = sys.argv[1:] or ["g1", "g2_g3", "g4_g13", "g5", "g6", "g8_g9_ppo", "g7", "g10", "g11", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27"]
     for name in todo:
         globals()[name]()

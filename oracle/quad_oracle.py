@@ -163,6 +163,59 @@ def ppo_loss(mean, value, actions, old_logprob, adv, returns, std, eps=0.2):
     return out
 
 
+def ppo_update(actor, critic, std, obs, actions, old_logprob_joint, adv, returns, batches, lr, betas=(0.9, 0.999), eps=1e-8,
+               eps_clip=0.2, c_value=0.5, c_entropy=0.006, learn_std=False):
+    """The optimisation loop both PPO.update variants share, in fp64 numpy (test infrastructure; small batches only):
+    environment/controller/ppo.py:172-203 (full batch per epoch: `batches` = K_epochs x [all samples], c_entropy 0.006) and
+    visual_landing/ppo_trainer.py:96-131,187-196 (`batches` = the minibatches of every epoch in order, c_entropy 0.01,
+    learned std).  Per batch: evaluate (model.py:74-85 / rl_nn_model_v2.py:232-247: Normal(mean, std) per action dimension,
+    joint log-probability = their sum, entropy = 4 (1/2 + log(2 pi)/2 + log std)), ratio = exp(logp - old logp), loss =
+    mean(-min(ratio A, clip(ratio, 1 - eps_clip, 1 + eps_clip) A)) + c_value mean((V - R)^2) - c_entropy mean(entropy),
+    backward, one torch.optim.Adam step over [actor, critic(, std)].
+    actor / critic: [W1, b1, W2, b2, W3, b3] (torch layout), tanh hidden layers, tanh on the actor's output.
+    Returns (actor, critic, std, [per-batch dict(actor=, critic=)])."""
+    P = [np.array(v, dtype=np.float64) for v in list(actor) + list(critic)] + [np.array(float(std))]
+    m = [np.zeros_like(v) for v in P]
+    v2 = [np.zeros_like(v) for v in P]
+    obs, actions, lpo, adv, returns = (np.asarray(a, dtype=np.float64) for a in (obs, actions, old_logprob_joint, adv, returns))
+    log = []
+
+    def mlp(x, W, final_tanh):
+        h1 = np.tanh(x @ W[0].T + W[1]); h2 = np.tanh(h1 @ W[2].T + W[3]); o = h2 @ W[4].T + W[5]
+        return h1, h2, (np.tanh(o) if final_tanh else o)
+
+    def mlp_back(x, W, h1, h2, out, d_out, final_tanh):
+        dz3 = d_out * (1 - out * out) if final_tanh else d_out
+        dz2 = (dz3 @ W[4]) * (1 - h2 * h2)
+        dz1 = (dz2 @ W[2]) * (1 - h1 * h1)
+        return [dz1.T @ x, dz1.sum(0), dz2.T @ h1, dz2.sum(0), dz3.T @ h2, dz3.sum(0)]
+    for t, idx in enumerate(batches, 1):
+        x, a, A, R = obs[idx], actions[idx], adv[idx], returns[idx]
+        B, sd = len(idx), float(P[12])
+        h1, h2, mean = mlp(x, P[0:6], True)
+        d = a - mean
+        logp = (-0.5 * d * d / sd ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi)).sum(1)
+        ratio = np.exp(logp - lpo[idx])
+        s1, s2 = ratio * A, np.clip(ratio, 1 - eps_clip, 1 + eps_clip) * A
+        use1 = s1 <= s2                                                     # torch.min: surr1 on ties
+        live = use1 | ((ratio > 1 - eps_clip) & (ratio < 1 + eps_clip))    # the clamp passes a gradient only inside the clip
+        g_lp = np.where(live, -A * ratio, 0.0) / B                          # d mean(actor_loss) / d logp
+        g = mlp_back(x, P[0:6], h1, h2, mean, g_lp[:, None] * d / sd ** 2, True)
+        c1, c2, val = mlp(x, P[6:12], False)
+        err = val[:, 0] - R
+        g += mlp_back(x, P[6:12], c1, c2, val, (2 * c_value * err / B)[:, None], False)
+        g_std = (g_lp * ((d * d / sd ** 2 - 1).sum(1) / sd)).sum() - c_entropy * 4.0 / sd
+        g.append(np.array(g_std if learn_std else 0.0))
+        log.append(dict(actor=float(np.mean(-np.minimum(s1, s2))), critic=float(c_value * np.mean(err * err))))
+        for k in range(13):   # torch.optim.Adam (no amsgrad, no weight decay)
+            if k == 12 and not learn_std:
+                continue
+            m[k] = betas[0] * m[k] + (1 - betas[0]) * g[k]
+            v2[k] = betas[1] * v2[k] + (1 - betas[1]) * g[k] * g[k]
+            P[k] = P[k] - lr / (1 - betas[0] ** t) * m[k] / (np.sqrt(v2[k]) / np.sqrt(1 - betas[1] ** t) + eps)
+    return P[0:6], P[6:12], float(P[12]), log
+
+
 def visual_reward(total_steps, marker, pos, vel, control, last_shaping, step, ang, v_ang):
     out = np.zeros(4)
     ls = 0.0 if last_shaping is None else float(last_shaping)

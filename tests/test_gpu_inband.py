@@ -330,6 +330,51 @@ def test_fused_rollout_launch_equals_the_separate_launches(aq, handle):
             assert torch.equal(x, y), ("hidden 64", k)
 
 
+@pytest.mark.parametrize("n,mode", [(65536, "sampling"), (131072, "deterministic")])
+def test_fused_rollout_launch_at_bench_size_equals_the_separate_launches(aq, n, mode):
+    """The kernel and the sizes bench.py times: config 5's per-GPU batch (65 536 envs, in-band sampling rollout, the launch's
+    own choice of 64-env blocks: 1 024 waves x one block) and config 4's (131 072 envs, deterministic evaluation: two blocks
+    per wave), the reference's trained weights, the lean handle -- k_ppo_fused for 12 steps (two calls: the second starts at a
+    ring head != 0) against the per-step launches: every rollout buffer and every env field, bit for bit.  Short episodes
+    (n = 9) make envs end and restart inside the sampling launch."""
+    w, _ = _weights(aq)
+    H = 12
+    res = []
+    for fused in (False, True):
+        if mode == "sampling":
+            env = aq.BatchedQuad(n, 0.01, 9, training=True, direct_control=1, T=5, **LEAN)
+            env.set_ppo_fused(fused)
+            ro = aq.PolicyRollout(env, w, H, store_obs=True, auto_reset=True, seed=4, env_offset=3 * n, inband=True)
+            ro.start()
+            if fused:
+                ro.run(7); ro.run(H - 7)
+            else:
+                for _ in range(H):
+                    ro.step()
+            env.ppo_flush()
+            bufs = (ro.actions, ro.logprobs, ro.rewards, ro.masks, ro.obs, ro.valid)
+        else:
+            env = aq.BatchedQuad(n, 0.01, 500, training=False, direct_control=1, T=5, **LEAN)
+            env.set_ppo_fused(fused)
+            ro = aq.PolicyRollout(env, aq.ActorCriticWeights(w.actor, None, env.device), H)
+            ro.start(env.sample_init_states(4, 0, 0))
+            if fused:
+                ro.run_deterministic(7); ro.run_deterministic(H - 7)
+            else:
+                for _ in range(H):
+                    ro.step(deterministic=True)
+            bufs = (ro.actions, ro.rewards, ro.masks, ro.done)
+        assert env.ppo_fused == (fused, None)      # the block is the launch's own choice (64 at these sizes)
+        res.append([x.clone() for x in bufs] + [getattr(env, f).clone() for f in
+                    ("state", "window", "i", "ang", "ang_vel", "reward", "episode_return", "last_return", "episodes", "done", "solved")])
+        del env, ro
+    for k, (x, y) in enumerate(zip(*res)):
+        assert torch.equal(x, y), (mode, k)
+    assert bool(torch.isfinite(res[0][-11]).all())
+    if mode == "sampling":
+        assert int(res[0][-3].sum()) > n // 2   # episodes ended and restarted inside the launches
+
+
 @pytest.mark.parametrize("handle", ["mixed", "lean"])
 def test_fused_launch_restart_in_its_last_step_leaves_the_angle_rows_of_the_storage_type(aq, handle):
     """An env that ends its episode in the LAST step of a fused launch is restarted in registers and written back at once: the

@@ -383,6 +383,105 @@ def test_ppo_actor_in_loop_teacher_forced_golden(aq, oracle, dt):
         assert bool(env.solved[e]) == bool(r.solved) and bool(env.done[e]) == bool(r.done)
 
 
+@pytest.mark.parametrize("dt", ["lean", "f64"])
+def test_vel_control_ppo_tracking_golden(aq, oracle, dt):
+    """G27 = environment/controller/vel_control_ppo.py:65-150 (the script itself, executed whole by oracle/gen_golden.py):
+    the trained N = 128 policy tracks unit steps and ramps of the velocity reference because the caller OFFSETS ITS OBSERVATION
+    (`dl_input(state + ERROR)`).  The eight cases run side by side as one 8-env batch through the drop-in calls -- actor forward
+    on the ring, step, window_push of the offset observation -- for all 500 steps:
+    (i)  free-running closed loop: states within 3e-5 and actions within 2e-6 of the reference (whose actor is fp32 torch and
+         whose step sees float32 actions, SURVEY.md section 8c; the fp64 oracle in the same loop is at 1e-5 / 3e-7);
+    (ii) teacher-forced env: the reference's recorded actions through the device against oracle twins, 1e-9;
+    (iii) the z ramp repeats the x ramp (quirk Q10), and the policy does track."""
+    g, wg = golden("g27_vel_control_ppo"), golden("g9_mlp_N128")
+    w = aq.ActorCriticWeights.from_state_dict({k: wg[k] for k in wg.files if k.startswith(("actor", "critic"))})
+    x0 = np.repeat(g["x0"][:, None], 8, 1)
+    off = np.stack([g[f"offset_{k}"] for k in range(8)], 2)      # [500, 14, 8]
+    rec_s = np.stack([g[f"state_{k}"] for k in range(8)], 1)     # [500, 8, 13]
+    rec_a = np.stack([g[f"action_{k}"] for k in range(8)], 2)    # [500, 4, 8]
+    env = aq.BatchedQuad(8, 0.01, 500, training=False, direct_control=1, T=5, **_kw(dt))
+    env.reset(torch.from_numpy(x0), return_history=False, push_window=True)
+    mean = torch.empty(4, 8, device="cuda", dtype=env.dtype)
+    worst = worst_a = 0.0
+    for i in range(500):
+        env.mlp_forward(w, "actor", out=mean)
+        worst_a = max(worst_a, float(np.max(np.abs(_np(mean) - rec_a[i]))))
+        obs, _, done = env.step(mean)
+        worst = max(worst, scaled_err(_np(env.state).T, rec_s[i]))
+        env.window_push(obs + torch.from_numpy(off[i]).to(obs), mean)
+    assert worst < 3e-5 and worst_a < 2e-6, (worst, worst_a)
+    assert bool(done.all())                                       # i = n: every episode times out at step 500, as recorded
+    st = _np(env.state).T
+    assert np.array_equal(st[6], st[4]) and np.abs(st[3, 1:6:2] - 1.0).max() < 0.01   # (iii)
+    # (ii) recorded actions in, oracle twins beside
+    refs = []
+    for k in range(8):
+        r = oracle.OracleQuad(0.01, 500, training=False, direct_control=1, T=5)
+        r.reset(g["x0"])
+        refs.append(r)
+    env.reset(torch.from_numpy(x0), return_history=False, push_window=True)
+    worst_o = 0.0
+    for i in range(500):
+        env.step(torch.from_numpy(np.ascontiguousarray(rec_a[i])), flags=2)
+        for k, r in enumerate(refs):
+            r.step(rec_a[i, :, k])
+        worst_o = max(worst_o, scaled_err(_np(env.state).T, np.array([r.state for r in refs])))
+    assert worst_o < 1e-9, worst_o
+
+
+@pytest.mark.parametrize("dt", ["lean", "f64", "f32"])
+def test_gimbal_edge_nan_angles_leave_done_clear(aq, oracle, dt):
+    """Quirk Q6 (quaternion_euler_utility.py:41-47): at a pitch of exactly pi/2 the arcsin argument 2 (q0 q2 - q3 q1) of the
+    NORMALISED quaternion rounds to just below 1, to 1 or to just above 1; above 1 arcsin is NaN, the reference prints its
+    warning, and in done_condition (quadrotor_env.py:500-509) every `>=` on a NaN is false: theta cannot end the episode.
+    Envs at rest with gimbal-locked attitudes (the carried quaternion scaled off the unit sphere so that the normalisation
+    rounds differently) take the warm-up step of reset (T = 1, zero_control) and one more: nothing turns, so the quaternion
+    they are scored on is the one they started with.  Roll and yaw are rounding noise there (atan2 of two such residues), so
+    the rule is checked the way the reference evaluates it, on the device's OWN angles:
+        done == any(|[phi, theta, psi]| >= [pi/2, pi/2, 3 pi/4])  with every comparison on a NaN false
+    (velocities and rates are far from their bounds after two steps); the second step's reward is NaN exactly where theta is
+    (the shaping reads the angles); all three classes of theta occur, NaN with done clear among them.  The fp64 oracle fed the
+    same states obeys the same rule.  (Which class a sample falls in is the last bit of the normalisation -- rsqrt and a
+    product here, a division by numpy's norm there -- so the classes are not compared sample by sample.)"""
+    n = 4096
+    rng = np.random.RandomState(61)
+    ang = np.stack([rng.uniform(-1, 1, n), np.full(n, np.pi / 2), rng.uniform(-1, 1, n)], 1)
+    q = np.array([oracle.euler_quat(a) for a in ang]) * rng.uniform(0.7, 1.3, (n, 1))
+    x0 = np.zeros((n, 13)); x0[:, 6:10] = q
+    env = aq.BatchedQuad(n, 0.01, 1000, training=True, direct_control=1, T=1, **_kw(dt))
+    env.reset(torch.from_numpy(x0.T.copy()))
+    a1, d1 = _np(env.ang), _np(env.done).astype(bool)
+    env.step(None)
+    a2, d2, rw = _np(env.ang), _np(env.done).astype(bool), _np(env.reward)
+    assert torch.equal(env.state[6:10].double().cpu(), torch.from_numpy(q.T).to(env.dtype).double())   # nothing turned
+    lim = np.array([np.pi / 2, np.pi / 2, 0.75 * np.pi])[:, None]
+    if dt == "f32":
+        lim = lim.astype(np.float32).astype(np.float64)           # the bounds as the handle's arithmetic holds them
+    with np.errstate(invalid="ignore"):
+        rule1, rule2 = (np.abs(a1) >= lim).any(0), (np.abs(a2) >= lim).any(0)
+    assert np.array_equal(d1, rule1) and np.array_equal(d2, d1 | rule2)          # (done is sticky)
+    nan = np.isnan(a2[1])
+    assert np.array_equal(np.isnan(a1[1]), nan)                                  # the same quaternion, the same class
+    hit = ~nan & (np.abs(a2[1]) >= lim[1])
+    assert nan.sum() > 50 and hit.sum() > 50 and (~nan & ~hit).sum() > 50, (nan.sum(), hit.sum())
+    assert (nan & ~d2).sum() > 10 and d2[hit].all()                              # NaN theta: the episode goes on
+    assert np.array_equal(np.isnan(rw), nan)
+    assert np.abs(a2[1][~nan]).min() > np.pi / 2 - (1e-3 if dt == "f32" else 1e-7)
+    cls = {"nan_open": 0, "hit": 0, "below": 0}
+    for e in range(0, n, 8):     # the oracle on a subsample: the same rule, the same classes
+        r = oracle.OracleQuad(0.01, 1000, training=True, direct_control=1, T=1)
+        r.reset(x0[e])
+        r.step(np.zeros(4))
+        with np.errstate(invalid="ignore"):
+            rule = bool((np.abs(r.ang) >= lim[:, 0]).any())
+        t = r.ang[1]
+        assert np.isnan(r.reward) == np.isnan(t)
+        if not rule:
+            assert not r.done
+        cls["nan_open" if (np.isnan(t) and not r.done) else "hit" if (not np.isnan(t) and abs(t) >= np.pi / 2) else "below"] += 1
+    assert min(cls.values()) > 3, cls
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 def test_gae_golden(aq, dt):
     g = golden("g10_gae")

@@ -422,6 +422,47 @@ def test_ppo_update_against_the_reference_update(aq):
     assert np.median(d) < 2e-6
 
 
+def test_landing_trainer_update_against_the_reference_update(aq):
+    """a22's second variant pinned by the reference itself (fixture g26 = visual_landing/ppo_trainer.py's OWN optimizer_step /
+    update loop, :96-131,:187-196, run on an MLP-backed subclass of its rl_nn_model_v2.ActorCritic): K = 5 epochs over the
+    reference's recorded permutations in minibatches of 1536 + the remainder of 500 = 15 Adam steps (lr 2e-5), loss
+    actor.mean() + 0.01 (-H).mean() + 0.5 MSE on the JOINT action probability, the std trained with the weights.
+    PpoLearner(c_entropy=0.01, learn_std=True).update(minibatch=1536, perms=...) lands on the reference's weights: they moved
+    by up to 3e-4 (15 steps of ~lr each), the device is within 2e-6 of them on 97 % (fp32 kernels against fp32 torch; a
+    weight whose gradient sits at fp32 noise can differ by a few lr, as in the g21 test), and the trained std agrees to 1e-6."""
+    import types
+    g = golden("g26_landing_trainer_update")
+    w = aq.ActorCriticWeights.from_state_dict({k[3:]: g[k] for k in g.files if k.startswith("w0_") and k != "w0_std"})
+    w.std = float(g["w0_std"])
+    n = g["sens"].shape[0]
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", torch.float32)
+    # get_advantages of the trainer (ddof 1) on the device reproduces what update() derived (float32 recurrences there)
+    ret, adv = aq.gae(f(np.append(g["values"], 0.0)).reshape(n + 1, 1), f(1.0 - g["is_terminals"]).reshape(n, 1),
+                      f(g["rewards"]).reshape(n, 1), ddof=1, group=False)
+    assert rel_err(_np(ret).ravel(), g["returns"], 1.0) < 2e-5 and rel_err(_np(adv).ravel(), g["adv"], 1.0) < 5e-5
+    # the optimisation itself on the reference's own returns / advantages (so that the comparison below is the update's)
+    lp = np.zeros((n, 4)); lp[:, 0] = g["logprobs"]      # the trainer stores the JOINT log-probability: the kernel sums the rows
+    ro = types.SimpleNamespace(t=n, obs=f(g["sens"]).reshape(n, 75, 1), actions=f(g["actions"]).reshape(n, 4, 1),
+                               logprobs=f(lp).reshape(n, 4, 1))
+    learner = aq.PpoLearner(w, lr=float(g["lr"]), K_epochs=int(g["K_epochs"]), eps_clip=float(g["eps_clip"]),
+                            c_value=float(g["c_value"]), c_entropy=float(g["c_entropy"]), group=False, learn_std=True)
+    out = learner.update(ro, f(g["returns"]).reshape(n, 1), f(g["adv"]).reshape(n, 1), minibatch=int(g["batch_size"]),
+                         perms=g["perms"])
+    assert len(out) == 15 and learner.step == 15
+    assert abs(float(np.mean([float(o["actor"]) for o in out])) - float(g["actor_loss_mean"])) < 2e-6
+    assert abs(float(np.mean([float(o["critic"]) for o in out])) - float(g["critic_loss_mean"])) < 2e-5
+    names = [f"{h}_{l}_{p}" for h in ("actor", "critic") for l in (0, 2, 4) for p in ("weight", "bias")]
+    got = np.concatenate([_np(t).ravel() for h in ("actor", "critic") for t in w.head(h)])
+    ref = np.concatenate([g["w1_" + k].ravel() for k in names])
+    start = np.concatenate([g["w0_" + k].ravel() for k in names])
+    d, moved = np.abs(got - ref), np.abs(ref - start)
+    assert moved.max() > 2.5e-4
+    assert np.mean(d < 2e-6) > 0.97 and np.median(d) < 2e-7 and d.max() < 1e-4, (np.mean(d < 2e-6), np.median(d), d.max())
+    assert abs(w.std - float(g["w1_std"])) < 1e-6, (w.std, float(g["w1_std"]))
+    with pytest.raises(ValueError):
+        learner.update(ro, f(g["returns"]).reshape(n, 1), f(g["adv"]).reshape(n, 1), minibatch=1536, perms=g["perms"][:2])
+
+
 def test_ppo_update_from_a_hip_graph_equals_the_eager_update(aq):
     """PpoLearner.update(graph=True): one epoch captured as a hipGraph (Adam's step count in device memory) and replayed
     K_epochs times, two updates in a row -- the same weights, bit for bit, as the eager launches (deterministic sums)."""
@@ -731,9 +772,10 @@ def test_bench_gpus2_self_launches_two_ranks():
 
 
 def test_bench_gpus2_default_line_carries_config4_and_config5_with_the_all_gather():
-    """The default workload under --gpus 2 (what a SCALE run launches, gloo here): besides config 2 the line carries
-    BASELINE's two node-level configs at their per-GPU sizes -- config 4 (trained actor in the loop) and config 5 (full PPO
-    rollout + GAE) -- each ending in the all-gather of the episode returns with the GLOBAL length, and the gather's time."""
+    """The default workload under --gpus 2 (what a SCALE run launches, gloo here): besides config 3 (the headline) the line
+    carries BASELINE's two node-level configs at their per-GPU sizes -- config 4 (trained actor in the loop) and config 5
+    (full PPO rollout + GAE) -- each ending in the all-gather of the episode returns with the GLOBAL length, and the
+    gather's time; the whole slices are in the detail line, which the launcher parent relays in front of the contract line."""
     import json
     import os
     import subprocess
@@ -744,8 +786,13 @@ def test_bench_gpus2_default_line_carries_config4_and_config5_with_the_all_gathe
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
                         "--min-seconds", "0.05", "--no-sustained"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
-    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * 65536 and d["config"]["handle"] == "lean"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines[-1].startswith('{"metric"') and lines[0].startswith('{"bench_detail"') and len(lines) == 2
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * 262144 and d["config"]["handle"] == "lean"
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and d["config"]["all_gathered_returns"] == 2 * 262144
+    full = json.loads(lines[0])["bench_detail"]["configs"]
+    assert full["config4"]["dominant_kernel"].startswith("k_ppo_fused") and full["config5"]["schedule"] == "inband"
     c4, c5 = d["configs"]["config4"], d["configs"]["config5"]
     assert c4["global_envs"] == 2 * 131072 and c4["all_gathered_returns"] == 2 * 131072 and c4["finite"]
     assert c5["global_envs"] == 2 * 65536 and c5["all_gathered_returns"] == 2 * 65536 and c5["finite"]
@@ -850,6 +897,8 @@ def test_sharded_rollout_keeps_a_handles_fused_switch(aq):
     env.set_ppo_fused(True, block=32); assert env.ppo_fused == (True, 32)
     env.set_ppo_fused_block(None); assert env.ppo_fused == (True, None)
     env.set_ppo_fused(False); env.set_ppo_fused_block(32); assert env.ppo_fused == (False, 32)
+    env.set_ppo_fused_block(64); env.set_ppo_fused(True); assert env.ppo_fused == (True, 64)   # a plain on / off keeps the block
+    env.set_ppo_fused(False); assert env.ppo_fused == (False, 64)
     with pytest.raises(ValueError):
         env.set_ppo_fused_block(48)
 

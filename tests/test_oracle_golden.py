@@ -458,3 +458,84 @@ def test_g21_gae_of_the_reference_update(oracle):
     ret, adv = oracle.gae(g["values"], 1.0 - g["is_terminals"], g["rewards"], ddof=0)
     # the reference carries the collected values through float32 torch tensors (Memory.convert_memory): fp32 resolution
     assert rel_err(ret, g["returns"], 1.0) < 1e-6 and rel_err(adv, g["adv"], 1.0) < 1e-5
+
+
+NAMES = [f"{h}_{l}_{p}" for h in ("actor", "critic") for l in (0, 2, 4) for p in ("weight", "bias")]
+
+
+def _landing_batches(g):
+    """ppo_trainer.py:187-196: every epoch's permutation in batches of BATCH_SIZE, the remainder (if > 1) last."""
+    n, bs, out = len(g["adv"]), int(g["batch_size"]), []
+    for perm in g["perms"]:
+        out += [perm[k * bs:(k + 1) * bs] for k in range(n // bs)]
+        if n % bs > 1:
+            out.append(perm[-(n % bs):])
+    return out
+
+
+def test_g21_g23_update_loop_restated(oracle):
+    """The numpy fp64 restatement of the optimisation loop (oracle.ppo_update) lands on the weights the reference's own
+    PPO.update (ppo.py:143-209, fp64 torch) left: fixed std (g21) and learned std (g23), ten full-batch epochs."""
+    for name, learn in (("g21_ppo_update", False), ("g23_ppo_update_learned_std", True)):
+        g = golden(name)
+        B = g["obs"].shape[0]
+        W0 = [g["w0_" + n] for n in NAMES]
+        a, c, std, _ = oracle.ppo_update(W0[:6], W0[6:], float(g["w0_std"]), g["obs"], g["actions"], g["logprobs"].sum(1),
+                                         g["adv"], g["returns"], [np.arange(B)] * 10, 5e-4, learn_std=learn)
+        got = np.concatenate([x.ravel() for x in a + c])
+        ref = np.concatenate([g["w1_" + n].ravel() for n in NAMES])
+        assert np.max(np.abs(got - ref)) < 2e-7 and np.median(np.abs(got - ref)) < 1e-9
+        assert abs(std - float(g["w1_std"])) < 1e-8
+
+
+def test_g26_landing_trainer_update(oracle):
+    """a22's second variant, visual_landing/ppo_trainer.py: get_advantages with the unbiased std (:133-148), then the
+    reference's own optimizer_step / update loop (:96-131,:187-196 -- fixture g26, run by the file's own methods on an MLP
+    policy): K = 5 epochs x (two minibatches of 1536 + a remainder of 500) = 15 Adam steps, actor.mean() + 0.01 (-H).mean() +
+    0.5 MSE, the std trained.  The fp64 restatement lands on the fp32 reference's weights to 1e-7 (they moved by 3e-4)."""
+    g = golden("g26_landing_trainer_update")
+    n = len(g["adv"])
+    ret, adv = oracle.gae(np.append(g["values"], 0.0), 1.0 - g["is_terminals"], g["rewards"], ddof=1)
+    # (the trainer carries the recurrence through float32 torch scalars over 3 572 samples and ~35 episodes: fp32 resolution)
+    assert rel_err(ret, g["returns"], 1.0) < 2e-5 and rel_err(adv, g["adv"], 1.0) < 5e-5
+    batches = _landing_batches(g)
+    assert len(batches) == 15 and all(sorted(p) == list(range(n)) for p in g["perms"])
+    W0 = [g["w0_" + k] for k in NAMES]
+    a, c, std, log = oracle.ppo_update(W0[:6], W0[6:], float(g["w0_std"]), g["sens"], g["actions"], g["logprobs"], g["adv"],
+                                       g["returns"], batches, float(g["lr"]), eps_clip=float(g["eps_clip"]),
+                                       c_value=float(g["c_value"]), c_entropy=float(g["c_entropy"]), learn_std=True)
+    got = np.concatenate([x.ravel() for x in a + c])
+    ref = np.concatenate([g["w1_" + k].ravel() for k in NAMES])
+    start = np.concatenate([g["w0_" + k].ravel() for k in NAMES])
+    assert np.abs(ref - start).max() > 2.5e-4                      # the reference did train
+    assert np.max(np.abs(got - ref)) < 2e-7, np.max(np.abs(got - ref))
+    assert abs(std - float(g["w1_std"])) < 1e-7 and abs(float(g["w1_std"]) - float(g["w0_std"])) > 1e-4
+    assert abs(np.mean([l["actor"] for l in log]) - float(g["actor_loss_mean"])) < 1e-6
+    assert abs(np.mean([l["critic"] for l in log]) - float(g["critic_loss_mean"])) < 1e-5
+
+
+def test_g27_vel_control_ppo(oracle):
+    """environment/controller/vel_control_ppo.py:65-150 replayed (fixture g27 = the script itself, executed whole): unit steps
+    and ramps of the velocity reference fed to the trained N = 128 policy by offsetting its observation, 500 steps each, the
+    z ramp repeating the x ramp (quirk Q10).  The oracle runs the same closed loop free (its fp64 forward against the
+    reference's fp32 torch forward and float32 action promotion): actions within 1e-6 and states within
+    2e-5 of the reference over all 500 steps; the policy does track (final velocity within 1 % of the step)."""
+    g, wg = golden("g27_vel_control_ppo"), golden("g9_mlp_N128")
+    W = [wg[f"actor_{l}_{p}"] for l in (0, 2, 4) for p in ("weight", "bias")]
+    assert np.array_equal(g["state_6"], g["state_4"]) and str(g["names"][6]).endswith("_z")   # Q10
+    for k in (0, 3, 5, 7):   # step x, step xyz, ramp y, ramp xyz (the others are the same code on another axis)
+        env = oracle.OracleQuad(0.01, 500, training=False, direct_control=1, T=5)
+        st, ac = env.reset(g["x0"])
+        dl = oracle.OracleWindow(5)
+        dl.reset()
+        win = dl.dl_input(st, ac)
+        worst = worst_a = 0.0
+        for i in range(500):
+            a = oracle.mlp_forward(win.astype(np.float64), *W, True)[0]
+            worst_a = max(worst_a, float(np.abs(a - g[f"action_{k}"][i]).max()))
+            q, _, done = env.step(a)
+            worst = max(worst, scaled_err(env.state, g[f"state_{k}"][i]))
+            win = dl.dl_input(np.asarray(q).ravel() + g[f"offset_{k}"][i], a)
+        assert worst < 2e-5 and worst_a < 1e-6, (k, worst, worst_a)
+        assert bool(done) and bool(g[f"done_{k}"][-1]) and not g[f"done_{k}"][:-1].any()
+    assert np.abs(g["state_3"][-1, 1:6:2] - 1.0).max() < 0.01

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-headline}; shift
 OUT=gpurun_out/pmc_valu_$TAG; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 ${PMC_CMD:-bench.py --steps 2000 --warmup 250 --min-seconds 0 --no-extras --no-cpu-baseline --no-subconfigs} "$@" > $OUT/a.log 2>&1 || echo failed
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 ${PMC_CMD:-bench.py --workload ${WL:-config2} --steps 2000 --warmup 250 --min-seconds 0 --no-extras --no-cpu-baseline --no-subconfigs} "$@" > $OUT/a.log 2>&1 || echo failed
 python3 - "$OUT" "${PMC_KERNEL:-k_rollout}" "${PMC_STEPS_PER_LAUNCH:-250}" <<'PY'
 import csv, glob, collections, sys, json
 out, kern, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
