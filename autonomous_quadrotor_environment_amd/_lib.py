@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 8
+QENV_ABI_VERSION = 9
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -112,6 +112,8 @@ SYMBOLS = {
     "qenv_mlp_backward_ppo": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 5 + [C.c_double] * 3 + [_i64] + [_vp] * 13),
     "qenv_mlp_backward_ppo_masked": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 6 + [C.c_double] * 3 + [_i64] + [_vp] * 13),
     "qenv_weight_grad": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_mlp_grad_ppo_workspace_bytes": (C.c_size_t, []),
+    "qenv_mlp_grad_ppo": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 6 + [C.c_double] * 3 + [_i64] + [_vp] * 15),
     "qenv_weight_grad_workspace_bytes": (C.c_size_t, [_i, _i]),
     "qenv_weight_grad_deterministic": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_gae_workspace_bytes": (C.c_size_t, [_i64]),

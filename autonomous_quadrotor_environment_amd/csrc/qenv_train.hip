@@ -985,6 +985,10 @@ template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream
     return rc;
 }
 
+}  // namespace qenv
+#include "qenv_grad4.hpp"
+namespace qenv {
+
 // torch.optim.Adam (ppo.py:105: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay)
 __global__ __launch_bounds__(256) void k_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1,
                                               float b2, float eps, float bc1, float bc2) {
@@ -1122,6 +1126,57 @@ static int launch_bwd(BwdArgs& a, int hidden, void* stream) {
     }
 #undef QENV_BWD_CASE
     return check_launch("k_mlp_bwd");
+}
+
+#ifdef QENV_GRAD4_STAMPS   /* diagnostic builds only (not declared in qenv.h) */
+int qenv_debug_grad4_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(qenv::g4_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
+size_t qenv_mlp_grad_ppo_workspace_bytes(void) { return (size_t)256 * grad4::SLOT * sizeof(float); }
+
+int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float* obs, const float* actions,
+                      const float* old_logprob, const float* adv, const float* returns, const float* weight, double std,
+                      double eps_clip, double c_value, int64_t batch, double* sums, const float* W1, const float* b1,
+                      const float* W2, const float* b2, const float* W3, const float* b3, float* gW1, float* gb1, float* gW2,
+                      float* gb2, float* gW3, float* gb3, void* workspace, void* stream) {
+    if (!obs || !sums || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !gW1 || !gb1 || !gW2 || !gb2 || !gW3 || !gb3)
+        return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: null argument");
+    if (hidden != mlp3::H || k_in != mlp3::KW)
+        return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: the fused gradient kernel covers the reference's controller (hidden 128, 75 inputs); "
+                                  "other shapes: qenv_mlp_backward_ppo + qenv_weight_grad");
+    if (head != 0 && head != 1) return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: head must be 0 (actor) or 1 (critic)");
+    if (head == 0 && (!actions || !old_logprob || !adv)) return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: the actor needs actions, old_logprob, adv");
+    if (head == 1 && !returns) return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: the critic needs returns");
+    if (n_envs <= 0 || n_chunks <= 0 || batch <= 0) return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: bad sizes");
+    if (!(std > 0)) return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: std must be positive");
+    if ((int64_t)hidden * n_envs >= ((int64_t)1 << 29))
+        return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: 128*n_envs per chunk must stay below 2^29 (32-bit byte offsets, range-checked loads)");
+    GradArgs g;
+    BwdArgs& a = g.b;
+    a.N = n_envs; a.n_chunks = n_chunks; a.K = k_in; a.n_out = head == 0 ? 4 : 1; a.final_tanh = head == 0;
+    a.obs = obs; a.seed = nullptr; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+    a.h1 = a.h2 = a.dz2 = a.dz1 = a.dz3 = nullptr;
+    a.loss_mode = head == 0 ? 1 : 2; a.actions = actions; a.old_logprob = old_logprob; a.adv = adv; a.returns = returns;
+    a.inv_var = (float)(1.0 / (std * std)); a.inv_std = (float)(1.0 / std); a.log_norm = (float)(-std::log(std) - 0.9189385332046727);
+    a.eps_clip = (float)eps_clip; a.c_value = (float)c_value; a.inv_B = 1.f / (float)batch;
+    a.sums = sums; a.weight = weight;
+    g.gW1 = gW1; g.gb1 = gb1; g.gW2 = gW2; g.gb2 = gb2; g.gW3 = gW3; g.gb3 = gb3; g.partial = (float*)workspace;
+    const int64_t n_tiles = ((n_envs + 31) / 32) * n_chunks;
+    const int cus = device_cu_count();
+    int64_t blocks = n_tiles < cus ? n_tiles : cus;   // one resident workgroup per CU (its registers hold W2 twice); at most the workspace's 256 slots
+    if (blocks > 256) blocks = 256;
+    hipError_t e = allow_dynamic_lds((const void*)k_mlp_grad_v4, (size_t)grad4::LDS_BYTES);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_grad_v4)");
+    hipLaunchKernelGGL(k_mlp_grad_v4, dim3((unsigned)blocks), dim3(256), (size_t)grad4::LDS_BYTES, (hipStream_t)stream, g);
+    int rc = check_launch("k_mlp_grad_v4");
+    if (rc == QENV_OK && workspace) {
+        hipLaunchKernelGGL(k_sum_grad_slots, dim3((unsigned)((grad4::SLOT + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, (int)blocks, a.n_out, gW1, gb1, gW2, gb2, gW3, gb3);
+        rc = check_launch("k_sum_grad_slots");
+    }
+    return rc;
 }
 
 static int wgrad_impl(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float* A, const float* B, float* C,

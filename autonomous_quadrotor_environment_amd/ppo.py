@@ -9,6 +9,7 @@ Reference (relative to /root/reference):
   visual_landing/rl_reward_fuction.py:3-102      visual_reward
 """
 import ctypes as C
+import os
 import itertools
 import weakref
 
@@ -317,6 +318,9 @@ class PpoLearner:
         self.step = 0
         self.group = group
         self.fused_loss = weights.hidden in (16, 32, 64, 128)  # False: forward, qenv_ppo_loss and backward as separate launches
+        # hidden 128, 75 inputs: the head's backward pass and weight gradients as ONE launch (qenv_mlp_grad_ppo, round 5);
+        # False / QENV_GRAD_ONE_LAUNCH=0: the backward kernel + three weight-gradient launches of rounds 1-4 (A/B runs)
+        self.one_launch = os.environ.get("QENV_GRAD_ONE_LAUNCH", "1") != "0"
         # True: weight / bias gradients summed in a fixed order (per-workgroup slots + an ordered second pass) instead of
         # fp32 atomics -- with gae(deterministic=True) a training run is bit-reproducible; ~3 % slower at 8.4 M samples
         self.deterministic = bool(deterministic)
@@ -382,7 +386,8 @@ class PpoLearner:
         n, K, N = obs.shape
         dev, w = obs.device, self.w
         H = w.hidden
-        b = self._buffers(H, n, N, dev)
+        # (the one-launch gradient path keeps no activations: no [n, H, N] buffers -- 17 GB at config 5's horizon)
+        b = None if (self.fused_loss and self.one_launch and H == 128 and K == 75) else self._buffers(H, n, N, dev)
         stream = _stream(dev)
         f32 = lambda t: t.to(torch.float32).contiguous()
         obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
@@ -446,6 +451,22 @@ class PpoLearner:
         for hid, head in enumerate(("actor", "critic")):
             W = w.head(head)
             n_out = W[4].shape[0]
+            if self.one_launch and H == 128 and K == 75:
+                # the reference's controller: backward AND the six weight / bias gradients of the head in ONE launch, nothing
+                # written to memory in between (qenv_mlp_grad_ppo: the workgroup's four waves share a sample tile and contract it
+                # over the samples on the spot).  deterministic: per-workgroup slots added in a fixed order.
+                g = [self._state[(head, k)][0] for k in range(6)]
+                ws = None
+                if self.deterministic:
+                    if getattr(self, "_grad_ws", None) is None or self._grad_ws.device != obs.device:
+                        self._grad_ws = torch.empty(int(L.lib.qenv_mlp_grad_ppo_workspace_bytes()), dtype=torch.uint8, device=obs.device)
+                    ws = self._grad_ws
+                L.check(L.lib.qenv_mlp_grad_ppo(N, n, K, H, hid, L.ptr(obs), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
+                                                L.ptr(returns), L.ptr(valid), std, float(self.eps_clip), float(self.c_value),
+                                                n * N if valid is None else max(1, int(n_valid_global)), L.ptr(sums),
+                                                *[L.ptr(x) for x in W], *[L.ptr(x) for x in g], L.ptr(ws), stream),
+                        "qenv_mlp_grad_ppo")
+                continue
             L.check(L.lib.qenv_mlp_backward_ppo_masked(N, n, K, H, hid, L.ptr(obs), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
                                                        L.ptr(returns), L.ptr(valid), std, float(self.eps_clip), float(self.c_value),
                                                        n * N if valid is None else max(1, int(n_valid_global)),

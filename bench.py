@@ -745,11 +745,18 @@ def next_rows(dev, policy):
     fl = samples * 2 * (75 * 128 + 128 * 128 + 128 * 4 + 75 * 128 + 128 * 128 + 128) * 3   # forward + 2x backward, both heads
     out["ppo_update_epoch"] = {"samples": samples, "valid_samples": int(float(ro.valid[:S].sum())), "seconds": dt,
                                "samples_per_s": samples / dt,
-                               "kernels": "k_mlp_bwd_v3 (fused loss; split-bf16 matrix cores), k_wgrad (dW2 split-bf16, dW1 / dW3 fp32 MFMA), k_adam",
+                               "kernels": "k_mlp_grad_v4 x 2 (one launch per head: forward recompute, fused loss, backward AND the six weight / "
+                                          "bias gradients; the workgroup's four waves share a 32-sample tile, activations exchanged through LDS "
+                                          "images, transposed by ds_read_b64_tr_b16), k_adam",
                                "algorithmic_TFLOPs": fl / dt / 1e12,
-                               "hbm_GB_per_epoch": 2 * 37.3, "hbm_GBps": 2 * 37.3e9 / dt / 1e9,
-                               "bound": "hbm (H1, H2, dZ2, dZ1 written by the backward kernel and read back by the weight-gradient "
-                                        "kernels: 37 GB per head; DESIGN.md 4d)",
+                               # the samples themselves, read once per head: observations 75 floats + actions 4 + old log-probs 4 + adv +
+                               # valid (actor) / returns + valid (critic); the counters agree (profiles/r05_update_epoch_counters.json:
+                               # FETCH_SIZE x 2 = 2.7 GB, WRITE_SIZE 0.07 GB per launch; rounds 1-4: 37.3 GB per head)
+                               "hbm_GB_per_epoch": samples * 4 * (2 * 75 + 4 + 4 + 1 + 1 + 1 + 1) / 1e9,
+                               "hbm_GBps": samples * 4 * (2 * 75 + 4 + 4 + 1 + 1 + 1 + 1) / dt / 1e9,
+                               "hbm_GB_per_epoch_rounds_1_to_4": 2 * 37.3,
+                               "bound": "vector issue + matrix pipe in turn (one wave per SIMD: 1 080 vector and 166 matrix instructions per "
+                                        "wave and tile, matrix pipe 0.33 busy; profiles/r05_grad4_stamps.json); HBM traffic is the samples, once",
                                "weights": policy_label(policy), "schedule": "inband"}
     return out
 

@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-/* 8: qenv_set_ppo_fused_block, qenv_get_ppo_fused; qenv_set_robust refuses the lean fp64 handle (it has no robust kernels) instead of failing at
+/* 9: qenv_mlp_grad_ppo / qenv_mlp_grad_ppo_workspace_bytes (backward + weight gradients of a head in one launch: no activation
+ *    round trip through HBM); a plain qenv_set_ppo_fused(q, 0 / 1) leaves a forced env block as it is.
+ * 8: qenv_set_ppo_fused_block, qenv_get_ppo_fused; qenv_set_robust refuses the lean fp64 handle (it has no robust kernels) instead of failing at
  *    the first step; qenv_ppo_rollout validates its arguments up front on every path.
  * 7: qenv_policy_rollout; qenv_ppo_rollout (in-band) and qenv_policy_rollout run as one launch where k_ppo_fused applies.
  * 6: qenv_ppo_step_args gains obs_rows_from / obs_slices (the slice layout of stored observations); qenv_dense_tail_chunks_strided.
@@ -43,7 +45,7 @@ extern "C" {
  * 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
  * 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
-#define QENV_ABI_VERSION 8
+#define QENV_ABI_VERSION 9
 
 typedef struct qenv_s *qenv_t;
 
@@ -573,6 +575,22 @@ int qenv_mlp_backward_ppo_masked(int64_t n_envs, int n_chunks, int k_in, int hid
                                  float *h2, float *dz2, float *dz1, float *dz3, void *stream);
 int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const float *A, const float *B,
                      float *C, float *rowsum, void *stream);
+/* ABI 9.  PPO.update's gradient step for ONE head of the reference's controller (hidden 128, k_in 75: model.py:27-42) as ONE
+ * launch: forward recompute, the fused loss of qenv_mlp_backward_ppo_masked (same arguments, same `sums`), the backward
+ * pass AND the six weight / bias gradients (environment/controller/ppo.py:185-203's loss.mean().backward()), accumulated
+ * INTO gW1 [128][75], gb1 [128], gW2 [128][128], gb2 [128], gW3 [n_out][128], gb3 [n_out] (n_out = 4 actor / 1 critic; the
+ * caller zeroes them per step).  No activation is written to memory: the four wavefronts of a workgroup share a 32-sample
+ * tile and contract it over the samples on the spot (qenv_grad4.hpp).  workspace: null = fp32 atomics (summation order
+ * varies in the last bits), or qenv_mlp_grad_ppo_workspace_bytes() bytes (no initialisation needed) = every workgroup
+ * stores its sums and a second launch adds them in a fixed order (bit-reproducible).  Other shapes: QENV_ERR_ARG (use
+ * qenv_mlp_backward_ppo + qenv_weight_grad). */
+size_t qenv_mlp_grad_ppo_workspace_bytes(void);
+int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float *obs,
+                      const float *actions, const float *old_logprob, const float *adv, const float *returns,
+                      const float *weight, double std, double eps_clip, double c_value, int64_t batch, double *sums,
+                      const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                      const float *b3, float *gW1, float *gb1, float *gW2, float *gb2, float *gW3, float *gb3,
+                      void *workspace, void *stream);
 /* qenv_weight_grad with a fixed summation order (bit-reproducible gradients, hence training runs): every workgroup
  * stores its partial C / rowsum in `workspace` (qenv_weight_grad_workspace_bytes(m_rows, n_rows) bytes, no
  * initialisation needed) and a second launch adds the slots in slot order. */
