@@ -37,8 +37,22 @@ __device__ unsigned long long g_rollout_stamps[1024 * 8];
         if ((threadIdx.x & 63) == 0 && wv_ < 1024) g_rollout_stamps[wv_ * 8 + (slot)] = t_;                    \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     } while (0)
+// ... and, inside ONE env step in the middle of the launch, the step's phases (tests/tools/rollout_phase_stamps.py): 0 step start,
+// 1 controller law + mixing done, 2 integrator done, 3 Euler angles done, 4 done / reward done, 5 end of the step's epilogue
+__device__ unsigned long long g_rollout_phase[1024 * 8];
+#define ROLLOUT_PHASE(slot, on)                                                                                \
+    do {                                                                                                       \
+        if (on) {                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
+            const unsigned wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                          \
+            if ((threadIdx.x & 63) == 0 && wv_ < 1024) g_rollout_phase[wv_ * 8 + (slot)] = t_;                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }                                                                                                      \
+    } while (0)
 #else
 #define ROLLOUT_STAMP(slot, real) do { } while (0)
+#define ROLLOUT_PHASE(slot, on) do { } while (0)
 #endif
 
 }  // namespace qenv
@@ -893,7 +907,9 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
         if (!dyn_only) {
             bk.i += 1;
             euler_update<T, M>(q_old, y, dy, ang_ok && (bk.flags & FLAG_ANG_OK), cfg, bk);
+            ROLLOUT_PHASE(3, s == a.n_steps / 2);
             done_reward<T, M>(y, act, effort, cfg, bk);
+            ROLLOUT_PHASE(4, s == a.n_steps / 2);
             ang_ok = true;  // from here on every env's prev_ang belongs to the state in its registers
             if (a.win) {  // dl_in_gen.dl_input of this step (reset warm-up: raw action = the constant action)
                 int slot = a.win_head + s;
@@ -950,11 +966,15 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
             if (s == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ROLLOUT_STAMP(2, false); }
             if (s == 1) ROLLOUT_STAMP(3, false);
             if (s == 2) ROLLOUT_STAMP(4, false);
+            ROLLOUT_PHASE(0, s == a.n_steps / 2);
             begin_step(s);
+            ROLLOUT_PHASE(1, s == a.n_steps / 2);
             // (a robust plant has no FSAL across steps: the wind changes from step to step)
             if constexpr (ROBUST) begin_step_wind(pl, bk.i + 1);
             integrate<T, INTEG>(y, u, pl, cfg.t_step, kq, dy, CTRL == QENV_CTRL_CONST && !ROBUST && s > 0);
+            ROLLOUT_PHASE(2, s == a.n_steps / 2);
             end_step(s);
+            ROLLOUT_PHASE(5, s == a.n_steps / 2);
         }
         ROLLOUT_STAMP(5, false);
     }

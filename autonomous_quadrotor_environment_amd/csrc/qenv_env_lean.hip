@@ -16,4 +16,7 @@ extern "C" int qenv_debug_fused_stamps(unsigned long long* out, int n) {
 extern "C" int qenv_debug_rollout_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qenv::g_rollout_stamps), sizeof(unsigned long long) * (size_t)n);
 }
+extern "C" int qenv_debug_rollout_phase(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qenv::g_rollout_phase), sizeof(unsigned long long) * (size_t)n);
+}
 #endif
