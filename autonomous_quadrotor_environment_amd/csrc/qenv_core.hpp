@@ -177,6 +177,9 @@ template <typename T> struct Act {
     // nominal plant: the moments and the gyroscopic factor divided by the body inertia, once per env step (act_finish) instead
     // of one multiplication per axis in every right-hand-side evaluation
     T Mxj, Myj, Mzj, omrj;
+#ifdef QENV_HOVER_REL   /* experiment (round 5, not kept -- profiles/r05_experiments_not_kept.txt): F = M G (1 + dlt) */
+    T dlt; int rel;
+#endif
 };
 static_assert(phys::JX == phys::JY, "act_finish / rhs use one gyroscopic factor omr / J_xx for the x and y axes");
 // two envs per lane (k_rollout2): the actuation of env 0 / env 1 in the two halves of the packed type
@@ -374,6 +377,9 @@ __device__ __forceinline__ void mix_direct(const T a[4], const P& pl, T w[4], Ac
     u.Mz = ((f[1] - f[0]) + (f[3] - f[2])) * T(phys::K_M / phys::K_F);
     if constexpr (P::robust) u.omr = ((w[1] * pl.ir[1] - w[0] * pl.ir[0]) + (w[3] * pl.ir[3] - w[2] * pl.ir[2]));
     else { u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R); act_finish(u); }
+#ifdef QENV_HOVER_REL
+    u.dlt = ((a[0] + a[1]) + (a[2] + a[3])) * T(0.25); u.rel = P::robust ? 0 : 1;   // T2WR = 2: F = M G (1 + sum a / 4)
+#endif
 }
 
 // f2w, quadrotor_env.py:197-245 / quadrotor_env_opt.py:144-176 (indirect mode), with the
@@ -405,6 +411,9 @@ __device__ __forceinline__ void mix_indirect(const T act[4], bool clipped, bool 
     if constexpr (P::robust) u.omr = ((w[1] * pl.ir[1] - w[0] * pl.ir[0]) + (w[3] * pl.ir[3] - w[2] * pl.ir[2]));
     else { u.omr = ((w[1] - w[0]) + (w[3] - w[2])) * T(phys::I_R); act_finish(u); }
     cl[0] = u.F; cl[1] = u.Mx; cl[2] = u.My; cl[3] = u.Mz;
+#ifdef QENV_HOVER_REL
+    u.dlt = T(0); u.rel = 0;
+#endif
 }
 
 // State layout (quadrotor_env.py:399-400): x vx y vy z vz q0 q1 q2 q3 wx wy wz
@@ -451,6 +460,16 @@ __device__ __forceinline__ void rhs(const T y[13], const Act<T>& u, P& pl, T dy[
     // scaling, so an exact hover (f_z == fl(M G)) has az == 0 exactly in fp32 as well
     const T az = ((r20 * fbx + r21 * fby + r22 * fbz) - mg) * inv_m;
     dy[0] = vx; dy[1] = ax; dy[2] = vy; dy[3] = ay; dy[4] = vz; dy[5] = az;
+#ifdef QENV_HOVER_REL
+    if constexpr (sizeof(T) == 4 && !P::robust) if (u.rel) {
+        // thrust relative to hover: a_z = G (dlt - 2 (b^2 + c^2) (1 + dlt)) + (R drag)_z / M -- the weight never meets the thrust
+        const T fdz = -T(phys::KDZ) * (m::abs(vbz) * vbz);
+        const T g1 = T(phys::G) * (T(1) + u.dlt), s2 = b2 * b + c2 * c;
+        dy[1] = (r00 * fbx + r01 * fby + r02 * fdz) * inv_m + r02 * g1;
+        dy[3] = (r10 * fbx + r11 * fby + r12 * fdz) * inv_m + r12 * g1;
+        dy[5] = (r20 * fbx + r21 * fby + r22 * fdz) * inv_m + (T(phys::G) * u.dlt - s2 * g1);
+    }
+#endif
     // deriv_quat with the normalised quaternion (quaternion_euler_utility.py:58-69), the 1/2 taken into the body rates
     const T hx = T(0.5) * wx, hy = T(0.5) * wy, hz = T(0.5) * wz;
     dy[6] = -(hx * b) - hy * c - hz * d;
