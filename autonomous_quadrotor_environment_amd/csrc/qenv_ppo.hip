@@ -1675,7 +1675,10 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
     const float* b2s = reinterpret_cast<const float*>(lds4 + B2);
     const float* b3s = reinterpret_cast<const float*>(lds4 + B3);
 
-    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    // (the wave index as a SCALAR: the feature loads' buffer resource is built from it -- taken from a vector register, hipcc
+    // wrapped every one of a tile's 416 loads in a 14-instruction waterfall loop: 5.8 k of the 7.6 k vector instructions per tile
+    // that the counters showed; 153 -> 134.5 us per 131 072 samples, round 5)
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tiles_per_chunk = (a.N + 31) / 32;
     const int64_t n_tiles = tiles_per_chunk * a.n_chunks;
     const int64_t rounds = (n_tiles + (int64_t)gridDim.x * WPB - 1) / ((int64_t)gridDim.x * WPB);

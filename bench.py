@@ -720,7 +720,8 @@ def next_rows(dev, policy):
     mfma3 = (K // 16 + (1 if K % 16 else 0) + 4) * 2 * 6     # split-bf16 32x32x16 MFMAs per 32-sample tile: layers 1 and 2, two output tiles
     out["dense_tail_800_64_64_3"] = {"samples": N, "kernel": "k_dense_tail_v3 (split-bf16 matrix cores, fp32-accurate; W1 streamed as fragments)",
                                      "kernel_us": us, "samples_per_s": N / us * 1e6,
-                                     "bound": "vector-L1 fill (features 100 KiB + W1 share 25 KiB per 32-sample tile at ~12 B/clk/CU) / hbm",
+                                     "bound": "the lock step of a SIMD's two waves behind the chunk barrier (profiles/r05_pmc_dense_tail.txt: matrix pipe 0.31 busy, "
+                                              "waits 0.38; HBM traffic = the features once, 3.1 of the 5.7 TB/s this tensor can be read at)",
                                      "algorithmic_TFLOPs": flops / us / 1e6,
                                      "mfma_pipe_busy_at_nominal_clock": mfma3 * 32 * (N / 32) / 1024 / (us * 1e-6 * MAX_CLOCK_GHZ * 1e9),
                                      "hbm_GBps": (K + n_out) * 4 * N / us / 1e3, "hbm_frac": (K + n_out) * 4 * N / us / 1e3 / HBM_PEAK_GBPS,

@@ -8,7 +8,8 @@ import autonomous_quadrotor_environment_amd as aq
 
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: torch.randn(*s, device="cuda", generator=g)
-for K, H, n_out, N in ((800, 64, 3, 131072), (800, 64, 3, 1048576), (800, 128, 3, 131072)):
+SHAPES = ((800, 64, 3, 131072), (800, 64, 3, 1048576), (800, 128, 3, 131072))
+for K, H, n_out, N in SHAPES[:int(sys.argv[1]) if len(sys.argv) > 1 else 3]:   # (argv[1] = 1: config 4's shape only -- profiling runs)
     W = [r(H, K) / K ** 0.5, r(H) * 0.1, r(H, H) / H ** 0.5, r(H) * 0.1, r(n_out, H) / H ** 0.5, r(n_out) * 0.1]
     x = torch.rand(K, N, device="cuda", generator=g) * 2 - 1
     out = torch.empty(n_out, N, device="cuda")
