@@ -87,6 +87,18 @@ __device__ unsigned long long g4_stamps[4 * 16];
 #define G4_STAMP(k)
 #endif
 
+// switches (A/B builds: tools/build_variant.sh NAME "-DG4_...=0/1" qenv_train.hip; tools/ab_grad4.sh, same box, alternating:
+// MERGE_PRE 14.7 -> 15.1 ms per epoch, BALANCE_T3 and BUFLOAD_LOSS 14.7 -> 14.5 each)
+#ifndef G4_MERGE_PRE
+#define G4_MERGE_PRE 0      // 1: no scheduling fence between a phase's preamble and its chain of products
+#endif
+#ifndef G4_BALANCE_T3
+#define G4_BALANCE_T3 1     // 1: the once-per-tile extras of the loss phase spread over the waves instead of all on wave 0
+#endif
+#ifndef G4_BUFLOAD_LOSS
+#define G4_BUFLOAD_LOSS 1   // 1: the loss's per-sample inputs through raw buffer loads (scalar base, one lane offset)
+#endif
+
 struct GradArgs {
     BwdArgs b;                                   // observations, weights, the fused loss's inputs (h1 .. dz3 unused)
     float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;    // the head's gradients, accumulated into (fp32 atomics) ...
@@ -259,6 +271,25 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
         if (more) request_x(tc, tr);   // lands while this tile is computed; stored to the image after its last reader
         // the loss's per-sample inputs, requested now and used three phases later (an HBM miss is ~900 cycles)
         float l_ac[4] = {0.f, 0.f, 0.f, 0.f}, l_lo[4] = {0.f, 0.f, 0.f, 0.f}, l_adv = 0.f, l_ret = 0.f;
+#if G4_BUFLOAD_LOSS
+        auto rsrc = [&](const float* base, uint32_t rows) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rows * N32 * 4u), 0x00020000);
+        };
+        const uint32_t lvo = ec * 4u;
+        float l_wgt = 1.f;
+        if (a.weight) l_wgt = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc(a.weight + (size_t)c * a.N, 1), lvo, 0, 0));
+        if (a.loss_mode == 1) {
+            const __amdgpu_buffer_rsrc_t ra = rsrc(a.actions + (size_t)c * 4 * a.N, 4), rl = rsrc(a.old_logprob + (size_t)c * 4 * a.N, 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                l_ac[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, lvo, (uint32_t)k * N32 * 4u, 0));
+                l_lo[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, lvo, (uint32_t)k * N32 * 4u, 0));
+            }
+            l_adv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc(a.adv + (size_t)c * a.N, 1), lvo, 0, 0));
+        } else {
+            l_ret = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc(a.returns + (size_t)c * a.N, 1), lvo, 0, 0));
+        }
+#else
         const float l_wgt = a.weight ? (a.weight + (size_t)c * a.N)[ec] : 1.f;
         if (a.loss_mode == 1) {
             const float* ac = a.actions + (size_t)c * 4 * a.N;
@@ -269,6 +300,7 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
         } else {
             l_ret = (a.returns + (size_t)c * a.N)[ec];
         }
+#endif
         // ---- layer 1: this wave's 32 rows; the fragments of k-step s + 1 are requested before the products of step s
         f32x16 acc;
 #pragma unroll
@@ -281,7 +313,7 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { A[k] = __builtin_bit_cast(bf16x8, f[64 * k]); B[k] = ldq(xo + k * TERM); }
             };
-            __builtin_amdgcn_sched_barrier(0);
+            if (!G4_MERGE_PRE) __builtin_amdgcn_sched_barrier(0);
             l1_load(0, fa[0], fb[0]);
 #pragma unroll
             for (int sk = 0; sk < KS16; ++sk) {
@@ -332,7 +364,7 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
                 for (int k = 0; k < 3; ++k) B[k] = ldq(ho + k * TERM);
             };
             if (more) store_x(xnext);   // the next tile's observations (their buffer's last reader was the previous tile's dW1)
-            __builtin_amdgcn_sched_barrier(0);
+            if (!G4_MERGE_PRE) __builtin_amdgcn_sched_barrier(0);
             l2_load(0, fb[0]);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -414,7 +446,7 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) dz3[k] = a.final_tanh ? sd[k] * (1.f - outv[k] * outv[k]) : sd[k];
-        if (wave == 0 && half == 0) {   // the dz3 operand image (two terms) and db3
+        if (wave == (G4_BALANCE_T3 ? 1 : 0) && half == 0) {   // the dz3 operand image (two terms) and db3
             bf16x8 sp[2];
             float v8[8] = {dz3[0], dz3[1], dz3[2], dz3[3], 0.f, 0.f, 0.f, 0.f};
             split2x8(v8, sp[0], sp[1]);
@@ -462,7 +494,7 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
                 const int ho = HZ_OFF + (row_rd ^ (32 * ks));
                 B[0] = ldq(ho); B[1] = ldq(ho + TERM);
             };
-            __builtin_amdgcn_sched_barrier(0);
+            if (!G4_MERGE_PRE) __builtin_amdgcn_sched_barrier(0);
             bw_load(0, fb[0]);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -549,7 +581,7 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
         if (col < a.n_out) emit(ga.gW3 + (size_t)col * H + hrow, O_W3 + col * H + hrow, g3[j]);
         else if (col == 4) emit(ga.gb2 + hrow, O_B2 + hrow, g3[j]);
     }
-    if (wave == 0) {
+    if (wave == (G4_BALANCE_T3 ? 1 : 0)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float v = half == 0 ? db3[k] : 0.f;
@@ -557,6 +589,8 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0 && k < a.n_out) emit(ga.gb3 + k, O_B3 + k, v);
         }
+    }
+    if (wave == 0) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_xor(loss_acc, off);
         if (lane == 0) atomicAdd(&a.sums[a.loss_mode], loss_acc);
