@@ -68,8 +68,9 @@ WORKLOADS = {
     "config2": (65536, 1, "const", 1, BYTES_DYNAMICS, "lean",
                 "BASELINE configs[1]: 65536 envs/GPU, zero action, perturbed hover, dynamics only"),
     "config2_hover": (65536, 1, "const", 1, BYTES_DYNAMICS, "lean",
-                      "BASELINE configs[1] literally: 65536 envs/GPU, zero action from EXACT hover (f0 = 0: scipy's h0 = 1e-6 "
-                      "branch, ~5 growing sub-steps = ~32 right-hand sides per step although nothing moves), dynamics only"),
+                      "BASELINE configs[1] literally: 65536 envs/GPU, zero action from EXACT hover (f0 = 0: scipy accepts ~5 growing "
+                      "sub-steps = 32 right-hand sides of a state that does not move; integrate_rk45 recognises the equilibrium and "
+                      "returns the same y without them), dynamics only"),
     "config3": (262144, 0, "lqr", 2, BYTES_FULL, "lean",
                 "BASELINE configs[2]: 262144 envs/GPU, LQR inner loop, random init (seed 3), full step, 500-step episodes"),
     # PPO workloads: controller names select the runner below; bytes from SURVEY.md section 8d
