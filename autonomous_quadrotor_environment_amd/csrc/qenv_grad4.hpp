@@ -95,6 +95,15 @@ __device__ unsigned long long g4_stamps[4 * 16];
 #ifndef G4_BALANCE_T3
 #define G4_BALANCE_T3 1     // 1: the once-per-tile extras of the loss phase spread over the waves instead of all on wave 0
 #endif
+#ifndef G4_DB2_BRANCH
+#define G4_DB2_BRANCH 1     // 1: db2's two products under a scalar branch (t == wave); 0: a zeroed ones fragment for the other tiles (12 more MFMAs: 14.3 against 13.4 ms)
+#endif
+#ifndef G4_NO_SGB
+#define G4_NO_SGB 0         // 1: the chains' read-ahead left to hipcc's own scheduling (no sched_group_barrier sequences)
+#endif
+#ifndef G4_W3_HOLD
+#define G4_W3_HOLD 0        // 1: this wave's 16 rows of W3 read once per tile and held across the loss phase (64 registers)
+#endif
 #ifndef G4_BUFLOAD_LOSS
 #define G4_BUFLOAD_LOSS 1   // 1: the loss's per-sample inputs through raw buffer loads (scalar base, one lane offset)
 #endif
@@ -322,12 +331,14 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
             }
             // the order asked of the scheduler: step 0's six reads, then per step { the next step's reads, six products } -- a
             // step's operands are requested a whole step (192 matrix-pipe cycles) before its first product
+#if !G4_NO_SGB
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
             for (int sk = 0; sk < KS16; ++sk) {
                 if (sk + 1 < KS16) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         G4_STAMP(1);
@@ -371,21 +382,32 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
                 if (ks + 1 < 8) l2_load(ks + 1, fb[(ks + 1) & 1]);
                 six(acc, A2[ks][0], A2[ks][1], A2[ks][2], fb[ks & 1][0], fb[ks & 1][1], fb[ks & 1][2]);
             }
+#if !G4_NO_SGB
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         G4_STAMP(4);
         float h2[16];
         float o[4] = {0.f, 0.f, 0.f, 0.f};
+#if G4_W3_HOLD
+        float4 w3r[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w3r[j] = *reinterpret_cast<const float4*>(ldsb + W3_OFF + 512 * wave + 64 * half + 16 * acc_row(j, 0));
+#endif
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             h2[j] = fast_tanh_prescaled(acc[j]);
+#if G4_W3_HOLD
+            const float4 w = w3r[j];
+#else
             const float4 w = *reinterpret_cast<const float4*>(ldsb + W3_OFF + 512 * wave + 64 * half + 16 * acc_row(j, 0));
+#endif
             o[0] = fmaf(w.x, h2[j], o[0]); o[1] = fmaf(w.y, h2[j], o[1]);
             o[2] = fmaf(w.z, h2[j], o[2]); o[3] = fmaf(w.w, h2[j], o[3]);
         }
@@ -461,7 +483,11 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
         float dz[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
+#if G4_W3_HOLD
+            const float4 w = w3r[j];
+#else
             const float4 w = *reinterpret_cast<const float4*>(ldsb + W3_OFF + 512 * wave + 64 * half + 16 * acc_row(j, 0));
+#endif
             const float g = fmaf(w.w, dz3[3], fmaf(w.z, dz3[2], fmaf(w.y, dz3[1], w.x * dz3[0])));
             dz[j] = g * (1.f - h2[j] * h2[j]);
         }
@@ -501,12 +527,14 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
                 if (ks + 1 < 8) bw_load(ks + 1, fb[(ks + 1) & 1]);
                 three(acc, AT[ks][0], AT[ks][1], fb[ks & 1][0], fb[ks & 1][1]);
             }
+#if !G4_NO_SGB
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         G4_STAMP(10);
@@ -530,9 +558,16 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
                 three(gw2[t], ah, am, h1t[ks][0], h1t[ks][1]);
                 // this wave's own rows (t == wave): their sums into column 4 -- the same two products for every t with the ones
                 // fragment zeroed for the others (no branch: the region stays one basic block for the scheduler)
+#if G4_DB2_BRANCH
+                if (t == wave) {   // (wave-uniform: a scalar branch around the two products)
+                    g3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, ones4, g3, 0, 0, 0);
+                    g3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones4, g3, 0, 0, 0);
+                }
+#else
                 const bf16x8 o4 = t == wave ? ones4 : zeros8;
                 g3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, o4, g3, 0, 0, 0);
                 g3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, o4, g3, 0, 0, 0);
+#endif
             }
         }
         G4_STAMP(11);
