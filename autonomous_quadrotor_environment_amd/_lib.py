@@ -113,7 +113,7 @@ SYMBOLS = {
     "qenv_mlp_backward_ppo_masked": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 6 + [C.c_double] * 3 + [_i64] + [_vp] * 13),
     "qenv_weight_grad": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "qenv_mlp_grad_ppo_workspace_bytes": (C.c_size_t, []),
-    "qenv_mlp_grad_ppo": (_i, [_i64, _i, _i, _i, _i] + [_vp] * 6 + [C.c_double] * 3 + [_i64] + [_vp] * 15),
+    "qenv_mlp_grad_ppo": (_i, [_i64, _i, _i, _i, _i, _vp, _i64] + [_vp] * 5 + [C.c_double] * 3 + [_i64] + [_vp] * 15),
     "qenv_weight_grad_workspace_bytes": (C.c_size_t, [_i, _i]),
     "qenv_weight_grad_deterministic": (_i, [_i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_gae_workspace_bytes": (C.c_size_t, [_i64]),

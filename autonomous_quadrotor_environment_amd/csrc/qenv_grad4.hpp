@@ -112,7 +112,8 @@ struct GradArgs {
     BwdArgs b;                                   // observations, weights, the fused loss's inputs (h1 .. dz3 unused)
     float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;    // the head's gradients, accumulated into (fp32 atomics) ...
     float* partial;                              // ... or, if set, [gridDim.x][grad4::SLOT]: every workgroup stores its sums (deterministic mode)
-};
+    int64_t obs_stride;                          // elements between the observation blocks of consecutive chunks: 75 N (dense) or 15 N (the
+};                                               // slice layout of an in-band rollout: the windows of consecutive steps overlap in 4 slices)
 
 __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
     using namespace mlp3;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void k_mlp_grad_v4(const GradArgs ga) {
     auto request_x = [&](int c_, int r_) {
         const int64_t c = c_;
         const int64_t e = (int64_t)r_ * 32 + col;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.obs + (size_t)c * K1 * a.N), 0,
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.obs + (size_t)c * ga.obs_stride), 0,
                                                                             (int)((uint32_t)K1 * N32 * 4u), 0x00020000);
         const uint32_t voff = e < a.N ? ((uint32_t)e + 8u * (uint32_t)half * N32) * 4u : 0x80000000u;
 #pragma unroll

@@ -1136,7 +1136,7 @@ int qenv_debug_grad4_stamps(unsigned long long* out64) {
 
 size_t qenv_mlp_grad_ppo_workspace_bytes(void) { return (size_t)256 * grad4::SLOT * sizeof(float); }
 
-int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float* obs, const float* actions,
+int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float* obs, int64_t obs_chunk_stride, const float* actions,
                       const float* old_logprob, const float* adv, const float* returns, const float* weight, double std,
                       double eps_clip, double c_value, int64_t batch, double* sums, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* W3, const float* b3, float* gW1, float* gb1, float* gW2,
@@ -1163,6 +1163,9 @@ int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int he
     a.eps_clip = (float)eps_clip; a.c_value = (float)c_value; a.inv_B = 1.f / (float)batch;
     a.sums = sums; a.weight = weight;
     g.gW1 = gW1; g.gb1 = gb1; g.gW2 = gW2; g.gb2 = gb2; g.gW3 = gW3; g.gb3 = gb3; g.partial = (float*)workspace;
+    if (obs_chunk_stride < 0 || (obs_chunk_stride != 0 && obs_chunk_stride < n_envs))
+        return fail(QENV_ERR_ARG, "qenv_mlp_grad_ppo: obs_chunk_stride is 0 (dense: k_in * n_envs) or the element distance of consecutive chunks");
+    g.obs_stride = obs_chunk_stride ? obs_chunk_stride : (int64_t)k_in * n_envs;
     const int64_t n_tiles = ((n_envs + 31) / 32) * n_chunks;
     const int cus = device_cu_count();
     int64_t blocks = n_tiles < cus ? n_tiles : cus;   // one resident workgroup per CU (its registers hold W2 twice); at most the workspace's 256 slots

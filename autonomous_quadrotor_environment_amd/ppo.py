@@ -390,7 +390,13 @@ class PpoLearner:
         b = None if (self.fused_loss and self.one_launch and H == 128 and K == 75) else self._buffers(H, n, N, dev)
         stream = _stream(dev)
         f32 = lambda t: t.to(torch.float32).contiguous()
-        obs, actions, old_logprob, adv, returns = map(f32, (obs, actions, old_logprob, adv, returns))
+        # (the one-launch gradient kernel reads a rollout's observations where they were stored: a [n, 75, N] VIEW of the slice
+        # array -- chunk stride 15 N, rows contiguous -- needs no dense copy)
+        in_place = (self.fused_loss and self.one_launch and H == 128 and K == 75 and obs.dtype == torch.float32
+                    and obs.stride(2) == 1 and obs.stride(1) == N and (n == 1 or obs.stride(0) >= N))
+        actions, old_logprob, adv, returns = map(f32, (actions, old_logprob, adv, returns))
+        if not in_place:
+            obs = f32(obs)
         self.bucket.zero_()
         if valid is not None:
             if not self.fused_loss:
@@ -461,7 +467,7 @@ class PpoLearner:
                     if getattr(self, "_grad_ws", None) is None or self._grad_ws.device != obs.device:
                         self._grad_ws = torch.empty(int(L.lib.qenv_mlp_grad_ppo_workspace_bytes()), dtype=torch.uint8, device=obs.device)
                     ws = self._grad_ws
-                L.check(L.lib.qenv_mlp_grad_ppo(N, n, K, H, hid, L.ptr(obs), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
+                L.check(L.lib.qenv_mlp_grad_ppo(N, n, K, H, hid, L.ptr(obs), int(obs.stride(0)), L.ptr(actions), L.ptr(old_logprob), L.ptr(adv),
                                                 L.ptr(returns), L.ptr(valid), std, float(self.eps_clip), float(self.c_value),
                                                 n * N if valid is None else max(1, int(n_valid_global)), L.ptr(sums),
                                                 *[L.ptr(x) for x in W], *[L.ptr(x) for x in g], L.ptr(ws), stream),
@@ -567,8 +573,9 @@ class PpoLearner:
             n_valid = int(v32.sum().item())
             n_valid_global = self._global_count(n_valid, v32.device)   # once per update: the mask is the same every epoch
             obs = rollout.obs[:n]
-            if not obs.is_contiguous():   # observations stored as slices (PolicyRollout.slice_obs): ONE dense copy for all epochs
-                obs = obs.contiguous()
+            if not obs.is_contiguous() and not (self.fused_loss and self.one_launch and self.w.hidden == 128 and obs.shape[1] == 75):
+                obs = obs.contiguous()    # observations stored as slices (PolicyRollout.slice_obs): ONE dense copy for all epochs
+                                          # (hidden 128: the one-launch gradient kernel reads the slices in place)
             for _ in range(self.K_epochs):
                 out.append(self.gradients(obs, rollout.actions[:n], rollout.logprobs[:n], adv[:n], returns[:n],
                                           valid=v32, n_valid=n_valid, n_valid_global=n_valid_global))

@@ -582,11 +582,13 @@ int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const
  * caller zeroes them per step).  No activation is written to memory: the four wavefronts of a workgroup share a 32-sample
  * tile and contract it over the samples on the spot (qenv_grad4.hpp).  workspace: null = fp32 atomics (summation order
  * varies in the last bits), or qenv_mlp_grad_ppo_workspace_bytes() bytes (no initialisation needed) = every workgroup
- * stores its sums and a second launch adds them in a fixed order (bit-reproducible).  Other shapes: QENV_ERR_ARG (use
+ * stores its sums and a second launch adds them in a fixed order (bit-reproducible).  obs_chunk_stride: elements between the
+ * [k_in][N] observation blocks of consecutive chunks -- 0 = dense (k_in * N), 15 * N = the slice layout a rollout stores
+ * (qenv_ppo_step_args.obs_slices: one 15-float slice per step, consecutive windows overlap), read in place.  Other shapes: QENV_ERR_ARG (use
  * qenv_mlp_backward_ppo + qenv_weight_grad). */
 size_t qenv_mlp_grad_ppo_workspace_bytes(void);
 int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float *obs,
-                      const float *actions, const float *old_logprob, const float *adv, const float *returns,
+                      int64_t obs_chunk_stride, const float *actions, const float *old_logprob, const float *adv, const float *returns,
                       const float *weight, double std, double eps_clip, double c_value, int64_t batch, double *sums,
                       const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                       const float *b3, float *gW1, float *gb1, float *gW2, float *gb2, float *gW3, float *gb3,
