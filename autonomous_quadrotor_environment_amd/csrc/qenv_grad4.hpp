@@ -25,6 +25,7 @@
 // Per tile and wave: 154 MFMAs (layer 1: 30, layer 2: 48, dW3 / db2: 10, dW2: 24, W2^T dZ2: 24, dW1: 18) against the 126 + 3 x
 // split-K launches of before; HBM traffic = the observations, once.
 #pragma once
+#define QENV_GRAD4_HPP 1
 #include "qenv_mlp_common.hpp"
 
 namespace qenv {

@@ -987,6 +987,7 @@ template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream
 
 }  // namespace qenv
 #include "qenv_grad4.hpp"
+#include "qenv_grad5.hpp"
 namespace qenv {
 
 // torch.optim.Adam (ppo.py:105: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay)
@@ -1134,6 +1135,12 @@ int qenv_debug_grad4_stamps(unsigned long long* out64) {
 }
 #endif
 
+#ifdef QENV_GRAD5_STAMPS   /* diagnostic builds only (not declared in qenv.h) */
+int qenv_debug_grad5_stamps(unsigned long long* out128) {
+    return hipMemcpyFromSymbol(out128, HIP_SYMBOL(qenv::g5_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+}
+#endif
+
 size_t qenv_mlp_grad_ppo_workspace_bytes(void) { return (size_t)256 * grad4::SLOT * sizeof(float); }
 
 int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float* obs, int64_t obs_chunk_stride, const float* actions,
@@ -1170,10 +1177,19 @@ int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int he
     const int cus = device_cu_count();
     int64_t blocks = n_tiles < cus ? n_tiles : cus;   // one resident workgroup per CU (its registers hold W2 twice); at most the workspace's 256 slots
     if (blocks > 256) blocks = 256;
-    hipError_t e = allow_dynamic_lds((const void*)k_mlp_grad_v4, (size_t)grad4::LDS_BYTES);
-    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_grad_v4)");
-    hipLaunchKernelGGL(k_mlp_grad_v4, dim3((unsigned)blocks), dim3(256), (size_t)grad4::LDS_BYTES, (hipStream_t)stream, g);
-    int rc = check_launch("k_mlp_grad_v4");
+    static const bool use_v4 = [] { const char* s = getenv("QENV_GRAD_V4"); return s && atoi(s) != 0; }();
+    int rc;
+    if (use_v4) {
+        hipError_t e = allow_dynamic_lds((const void*)k_mlp_grad_v4, (size_t)grad4::LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_grad_v4)");
+        hipLaunchKernelGGL(k_mlp_grad_v4, dim3((unsigned)blocks), dim3(256), (size_t)grad4::LDS_BYTES, (hipStream_t)stream, g);
+        rc = check_launch("k_mlp_grad_v4");
+    } else {
+        hipError_t e = allow_dynamic_lds((const void*)k_mlp_grad_v5, (size_t)grad5::LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_grad_v5)");
+        hipLaunchKernelGGL(k_mlp_grad_v5, dim3((unsigned)blocks), dim3(512), (size_t)grad5::LDS_BYTES, (hipStream_t)stream, g);
+        rc = check_launch("k_mlp_grad_v5");
+    }
     if (rc == QENV_OK && workspace) {
         hipLaunchKernelGGL(k_sum_grad_slots, dim3((unsigned)((grad4::SLOT + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, (int)blocks, a.n_out, gW1, gb1, gW2, gb2, gW3, gb3);
