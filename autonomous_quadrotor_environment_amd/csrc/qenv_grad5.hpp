@@ -1,23 +1,40 @@
-// qenv_grad5.hpp -- k_mlp_grad_v5: k_mlp_grad_v4's launch (forward recompute, fused PPO loss, backward and every weight / bias
-// gradient of one head of the reference's N = 128, T = 5 networks; environment/controller/ppo.py:172-203,
-// visual_landing/ppo_trainer.py:96-131) laid out for TWO waves per SIMD.
+// qenv_grad5.hpp -- k_mlp_grad_v5: forward recompute, fused PPO loss, backward AND the weight / bias gradients of one head of
+// the reference's N = 128, T = 5 networks (environment/controller/ppo.py:172-203, visual_landing/ppo_trainer.py:96-131) in ONE
+// launch, with no activation ever written to HBM.
 //
-// v4 gave each of four waves 32 hidden rows: its register-resident slices of W2 / W2^T and its gradient accumulators fill the
-// whole 512-register file, so a SIMD holds one wave, a lone wave issues a vector instruction every ~5 cycles, and the thirteen
-// phases of a tile run one after the other (matrix pipe 0.34 busy).  Here EIGHT waves share the 32-sample tile, wave w owning
-// hidden rows 16 w .. 16 w + 15 on v_mfma_f32_16x16x32_bf16 tiles (16 rows x 16 samples x 32 k): half the persistent registers
-// per wave (W2 slices 48 + 32, accumulators 32 + 20 + 4), two waves per SIMD, so that one wave's vector work (activations,
-// splits, the loss) fills the other's MFMA and LDS latencies.  A weight-gradient product contracts over the tile's 32 samples in
-// ONE k-step.  The images are [sample][hidden] 16-bit terms in plain 256-byte rows; 16-byte chunk ch of row r sits at
-// ch ^ f(r), f(r) = (r & 15) ^ (r & 1 ? 12 : 0): conflict-free for the 16x16x32 row reads (ds_read_b128), for the transposing
-// reads (ds_read_b64_tr_b16: a half's two blocks 8 rows apart) and for the observations' 16-byte stores; the accumulator
-// fragments' 8-byte stores are two-way (16 rows of one chunk: unavoidable) -- tools/lds_layout_grad5.py checks all of it
-// against the bank rules of MI355X_MICROARCH.md (LDS) by brute force.
+// Rounds 1-4 ran the backward pass one wave per 32-sample tile (k_mlp_bwd_v3) and wrote H1, H2, dZ2, dZ1 (4 x 128 rows x 4 B per
+// sample) for three split-K weight-gradient launches to read back: 37 GB per head and epoch at config 5's 8.4 M samples, >= 12 x
+// the bytes of the samples themselves.  A weight gradient contracts over the SAMPLE index, which an accumulator tile carries on
+// its lanes: the operand has to be transposed, and one wave cannot hold the 128 x 128 accumulator of dW2 beside its tile.
+// Here the EIGHT waves of a workgroup (two per SIMD, 256 registers each) share one 32-sample tile: wave w owns hidden rows
+// 16 w .. 16 w + 15 of every layer on v_mfma_f32_16x16x32_bf16 tiles (16 rows x 16 samples x 32 k) -- its slices of W2 and of
+// W2^T live in its registers as ready MFMA fragments for the whole launch (48 + 32 registers), its slices of the weight
+// gradients in accumulator registers (dW2: 8 tiles, dW1: 5, dW3: 1 -- 56 registers) -- and the waves exchange activations
+// through LDS images laid out [sample][hidden] in 16-bit terms.  One image serves both uses of an activation: read by rows
+// (ds_read_b128) it is the B operand of the next layer (k = hidden index), read through gfx950's transposing
+// ds_read_b64_tr_b16 it is an operand of a weight-gradient product, which contracts over the tile's 32 samples in ONE k-step.
+// (The first version of this launch, four waves of 32 rows on 32x32x16 tiles, filled the 512-register file with one wave per
+// SIMD: a lone wave issues a vector instruction every ~5 cycles and nothing covers its LDS latencies -- 13.4 ms per epoch at
+// config 5's horizon against 12.3 here; git history, round 5.)
 //
-// Arithmetic as v4: the forward half on three-way split bf16 operands (six products per k-step, smallest first, pre-scaled
-// hidden layers), the gradient side on two-way split operands; db1 rides dW1 as the ones column (feature 75), db2 is column 4
-// of the dW3 tile.  The observation image is single-buffered (LDS: W1's fragments for eight waves need 60 KB): the next tile's
-// observations are requested after the loss and stored behind a barrier of their own, beside dW2's products.
+// The images are plain 256-byte rows; 16-byte chunk ch of row r sits at ch ^ f(r), f(r) = (r & 15) ^ (r & 1 ? 12 : 0):
+// conflict-free for the 16x16x32 row reads, for the transposing reads (a half's two blocks 8 rows apart) and for the
+// observations' 16-byte stores; the accumulator fragments' 8-byte stores are two-way (16 rows of one chunk: unavoidable).
+// tools/lds_layout_grad5.py replays every address formula below on a model of the LDS and of the transposing read and checks
+// operands and banks by brute force (MI355X_MICROARCH.md, LDS).
+//
+// Arithmetic.  The FORWARD half is k_mlp_v3's: three-way split bf16 operands, six products per k-step smallest first,
+// pre-scaled hidden layers (fp32-accurate; the policy's log-probabilities are what the rollout computed, up to the
+// association of layer 3's 128-term sum, which eight waves now form as 8 x 16).  Everything on the gradient side -- W2^T dZ2 and
+// the three weight-gradient products -- runs on TWO-way split operands (hi + mid: 16 significant bits, three products per
+// step): a relative 2^-17 per operand on sums over 10^5..10^7 noisy samples (measured against fp64 autograd:
+// tests/test_gpu_ppo_rollout.py, tests/tools/fuzz_learner.py).  db1 rides dW1 as a ones column of the observation image
+// (feature 75); db2 and db3 are plain fp32 sums on the vector lanes.  The observation image is single-buffered (W1's
+// fragments for eight waves take 60 KB of LDS): the next tile's observations are requested after the loss and stored behind
+// a barrier of their own, beside the second half of dW2.
+//
+// Per tile and wave: 152 MFMAs of 16 cycles (layer 1: 36, layer 2: 48, dW3: 3, W2^T dZ2: 24, dW2: 24, dW1: 15; 36 % of the
+// SIMD's time at two waves), ~600 vector instructions, 187 LDS instructions; HBM traffic = the observations, once.
 #pragma once
 #include "qenv_mlp_common.hpp"
 
@@ -40,7 +57,8 @@ constexpr int ZCH_OFF = DZ3_OFF + 2 * PTERM;        // one zero chunk: W1's frag
 constexpr int PART_OFF = ZCH_OFF + 16;              // layer 3's partial sums [wave][tile half][16] float4
 constexpr int W3_OFF = PART_OFF + NW * 2 * 16 * 16; // float4[128]: W3[0..3][h]
 constexpr int B3_OFF = W3_OFF + 2048;               // 4 floats
-constexpr int W1F_OFF = B3_OFF + 16;                // W1 fragments [wave]{[k-step 0..1][term][64 lanes], [k-step 2][term][32 lanes]} uint4
+constexpr int B12_OFF = B3_OFF + 16;                // b1, b2 pre-scaled: [layer][128] floats
+constexpr int W1F_OFF = B12_OFF + 1024;             // W1 fragments [wave]{[k-step 0..1][term][64 lanes], [k-step 2][term][32 lanes]} uint4
 constexpr int W1F_WAVE = 2 * 3 * 1024 + 3 * 512;
 constexpr int LDS_BYTES = W1F_OFF + NW * W1F_WAVE;
 static_assert(W1F_OFF % 16 == 0 && LDS_BYTES <= 160 * 1024, "k_mlp_grad_v5's LDS map");
@@ -110,14 +128,12 @@ __device__ unsigned long long g5_stamps[8 * 16];
 #define G5_STAMP(k)
 #endif
 
-#ifndef QENV_GRAD4_HPP
 struct GradArgs {
     BwdArgs b;                                   // observations, weights, the fused loss's inputs (h1 .. dz3 unused)
     float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;    // the head's gradients, accumulated into (fp32 atomics) ...
     float* partial;                              // ... or, if set, [gridDim.x][grad5::SLOT]: every workgroup stores its sums (deterministic mode)
     int64_t obs_stride;                          // elements between the observation blocks of consecutive chunks: 75 N (dense) or 15 N (the
 };                                               // slice layout of an in-band rollout: the windows of consecutive steps overlap in 4 slices)
-#endif
 
 __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
     using namespace mlp3;
@@ -149,6 +165,8 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
         w.w = a.n_out > 3 ? a.W3[(size_t)3 * H + h] : 0.f;
         *reinterpret_cast<float4*>(ldsb + W3_OFF + 16 * h) = w;
     }
+    for (int h = threadIdx.x; h < 2 * H; h += 512)
+        *reinterpret_cast<float*>(ldsb + B12_OFF + 4 * h) = (h < H ? a.b1[h] : a.b2[h - H]) * TANH_PRESCALE;
     if (threadIdx.x < 4) *reinterpret_cast<float*>(ldsb + B3_OFF + 4 * threadIdx.x) = (int)threadIdx.x < a.n_out ? a.b3[threadIdx.x] : 0.f;
     // the observation image's positions 80 .. 127 are never written by a tile, the dz3 image's positions 4 .. 15 neither
     for (int i = threadIdx.x; i < 3 * TERM / 16; i += 512) lds4[X_OFF / 16 + i] = uint4{0u, 0u, 0u, 0u};
@@ -168,12 +186,6 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
         }
         split3x8(w8, A2[ks][0], A2[ks][1], A2[ks][2]);
         split2x8(v8, AT[ks][0], AT[ks][1]);
-    }
-    float b1r[4], b2r[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        b1r[r] = a.b1[16 * wave + 4 * g + r] * TANH_PRESCALE;
-        b2r[r] = a.b2[16 * wave + 4 * g + r] * TANH_PRESCALE;
     }
     __syncthreads();
 
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
 #pragma unroll
     for (int t = 0; t < 5; ++t) gw1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     g3 = f32x4{0.f, 0.f, 0.f, 0.f};
-    float db3[4] = {0.f, 0.f, 0.f, 0.f};
+    float db3[4] = {0.f, 0.f, 0.f, 0.f}, db2[4] = {0.f, 0.f, 0.f, 0.f};
     double loss_acc = 0.0, std_acc = 0.0;
 
     const int64_t tiles_per_chunk = (a.N + 31) / 32, n_tiles = tiles_per_chunk * a.n_chunks;
@@ -266,7 +278,57 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
         const uint32_t ec = (uint32_t)(valid ? e : a.N - 1);
         const bool more = tile + gridDim.x < n_tiles;
         advance(tc, tr);
-        // the loss's per-sample inputs, requested now and used three phases later (an HBM miss is ~900 cycles)
+        // ---- layer 1: this wave's 16 rows, both tile halves (n: samples 16 n + c16).  Every chain below is written in the order
+        // it should issue -- a k-step's operands are requested while the step before multiplies -- and the sched_group_barrier
+        // sequence after it pins that order (hipcc otherwise reads a whole step, waits, multiplies: the LDS latency of every step
+        // exposed)
+        f32x4 acc[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[n] = *reinterpret_cast<const f32x4*>(ldsb + B12_OFF + 64 * wave + 16 * g);   // rows 16 w + 4 g + r
+        {
+            bf16x8 A[2][3], B[2][2][3];
+            auto ldA = [&](int ks, bf16x8 (&f)[3]) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) f[k] = ks < 2 ? ldq(w1f + (ks * 3 + k) * 1024) : ldq(w1f2 + k * w1f2s);
+            };
+            auto ldB = [&](int ks, int n, bf16x8 (&f)[3]) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) f[k] = ldq(X_OFF + k * TERM + 4096 * n + (rr_base ^ (64 * ks)));
+            };
+            ldA(0, A[0]); ldB(0, 0, B[0][0]); ldB(0, 1, B[0][1]);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int cu = ks & 1, nx = cu ^ 1;
+                if (ks + 1 < 3) { ldA(ks + 1, A[nx]); ldB(ks + 1, 0, B[nx][0]); }
+                six(acc[0], A[cu][0], A[cu][1], A[cu][2], B[cu][0][0], B[cu][0][1], B[cu][0][2]);
+                if (ks + 1 < 3) ldB(ks + 1, 1, B[nx][1]);
+                six(acc[1], A[cu][0], A[cu][1], A[cu][2], B[cu][1][0], B[cu][1][1], B[cu][1][2]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                if (ks + 1 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                if (ks + 1 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        G5_STAMP(1);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float h1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[r] = fast_tanh_prescaled(acc[n][r]);
+            uint2 sp[3];
+            split3x4(h1, sp[0], sp[1], sp[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) st8(H1_OFF + k * TERM + 4096 * n + aw_base, sp[k]);
+        }
+        G5_STAMP(2);
+        lds_barrier();   // B1: H1 complete
+        G5_STAMP(3);
+        // the loss's per-sample inputs, requested now and used two phases later (an HBM miss is ~900 cycles)
         float l_ac[4] = {0.f, 0.f, 0.f, 0.f}, l_lo[4] = {0.f, 0.f, 0.f, 0.f}, l_adv = 0.f, l_ret = 0.f;
         auto rsrc = [&](const float* base, uint32_t rows) {
             return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rows * N32 * 4u), 0x00020000);
@@ -285,48 +347,34 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
         } else {
             l_ret = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc(a.returns + (size_t)c * a.N, 1), lvo, 0, 0));
         }
-        // ---- layer 1: this wave's 16 rows, both tile halves (n: samples 16 n + c16)
-        f32x4 acc[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[n] = f32x4{b1r[0], b1r[1], b1r[2], b1r[3]};
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            bf16x8 A[3], B[2][3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) A[k] = ks < 2 ? ldq(w1f + (ks * 3 + k) * 1024) : ldq(w1f2 + k * w1f2s);
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) B[n][k] = ldq(X_OFF + k * TERM + 4096 * n + (rr_base ^ (64 * ks)));
-#pragma unroll
-            for (int n = 0; n < 2; ++n) six(acc[n], A[0], A[1], A[2], B[n][0], B[n][1], B[n][2]);
-        }
-        G5_STAMP(1);
-        float h1[2][4];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h1[n][r] = fast_tanh_prescaled(acc[n][r]);
-            uint2 sp[3];
-            split3x4(h1[n], sp[0], sp[1], sp[2]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) st8(H1_OFF + k * TERM + 4096 * n + aw_base, sp[k]);
-        }
-        G5_STAMP(2);
-        lds_barrier();   // B1: H1 complete
-        G5_STAMP(3);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- layer 2 (A from registers, B = H1 by rows)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[n] = f32x4{b2r[0], b2r[1], b2r[2], b2r[3]};
+        for (int n = 0; n < 2; ++n) acc[n] = *reinterpret_cast<const f32x4*>(ldsb + B12_OFF + 512 + 64 * wave + 16 * g);
+        {
+            bf16x8 B[2][2][3];
+            auto ldB = [&](int ks, int n, bf16x8 (&f)[3]) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 B[2][3];
+                for (int k = 0; k < 3; ++k) f[k] = ldq(H1_OFF + k * TERM + 4096 * n + (rr_base ^ (64 * ks)));
+            };
+            ldB(0, 0, B[0][0]); ldB(0, 1, B[0][1]);
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cu = ks & 1, nx = cu ^ 1;
+                if (ks + 1 < 4) ldB(ks + 1, 0, B[nx][0]);
+                six(acc[0], A2[ks][0], A2[ks][1], A2[ks][2], B[cu][0][0], B[cu][0][1], B[cu][0][2]);
+                if (ks + 1 < 4) ldB(ks + 1, 1, B[nx][1]);
+                six(acc[1], A2[ks][0], A2[ks][1], A2[ks][2], B[cu][1][0], B[cu][1][1], B[cu][1][2]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) B[n][k] = ldq(H1_OFF + k * TERM + 4096 * n + (rr_base ^ (64 * ks)));
-#pragma unroll
-            for (int n = 0; n < 2; ++n) six(acc[n], A2[ks][0], A2[ks][1], A2[ks][2], B[n][0], B[n][1], B[n][2]);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         G5_STAMP(4);
         // ---- tanh, layer 3's share of this wave (the lane groups' sums meet: xor 16 by ds_swizzle, xor 32 by v_permlane32_swap),
@@ -367,14 +415,10 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
         lds_barrier();   // B2: the partial sums are in
         G5_STAMP(6);
         // the loss's inputs are first touched HERE (hipcc otherwise starts summing the old log-probabilities where they are
-        // requested and waits for HBM at the top of the tile), and before the next tile's observations are requested (the wait
-        // for the older loads must not count the younger ones)
+        // requested and waits for HBM there)
 #pragma unroll
         for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(l_ac[k]), "+v"(l_lo[k]));
         asm volatile("" : "+v"(l_adv), "+v"(l_ret), "+v"(l_wgt));
-        __builtin_amdgcn_sched_barrier(0);
-        if (more && wave < 5) request_x(tc, tr);   // lands during the backward half; stored behind the barrier after dW1
-        __builtin_amdgcn_sched_barrier(0);
         // ---- output, loss, dz3 of this lane's sample (tile half g & 1), the other half's from lane ^ 16; dZ2 of this wave's rows
         float outv[4], sd[4], dz3[2][4];
         {
@@ -450,6 +494,7 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
                     const float gg = fmaf(w.w, dz3[n][3], fmaf(w.z, dz3[n][2], fmaf(w.y, dz3[n][1], w.x * dz3[n][0])));
                     dz[n][r] = gg * (1.f - h2[n][r] * h2[n][r]);
                 }
+                db2[r] += dz[0][r] + dz[1][r];   // this lane's two samples of row 4 g + r; the 16 lanes of a group meet at the end
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -462,6 +507,8 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
         G5_STAMP(7);
         lds_barrier();   // B3: dZ2 and the dz3 operand complete
         G5_STAMP(8);
+        if (more && wave < 5) request_x(tc, tr);   // lands during the two phases to the barrier after dW1; no other load is in flight
+        __builtin_amdgcn_sched_barrier(0);          // meanwhile (a spilled register's reload would wait for these)
         // ---- dW3^T of this wave's rows (columns 0 .. 3 of the g3 tile): A = H2 own, B = dz3, both transposed
         {
             const char* pv = ldsb + PV_OFF + 2 * PTERM * wave;
@@ -471,67 +518,108 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
             three(g3, ah, am, bh, bm);
         }
         G5_STAMP(9);
-        // ---- dH1 = W2^T dZ2 of this wave's rows (A from registers, B = dZ2 by rows)
+        // ---- dH1 = W2^T dZ2 of this wave's rows (A from registers, B = dZ2 by rows); the halves' products alternate
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            bf16x8 B[2][2][2];
+            auto ldB = [&](int ks, bf16x8 (&f)[2][2]) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 B[2][2];
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+                    for (int k = 0; k < 2; ++k) f[n][k] = ldq(DZ2_OFF + k * TERM + 4096 * n + (rr_base ^ (64 * ks)));
+            };
+            ldB(0, B[0]);
 #pragma unroll
-                for (int k = 0; k < 2; ++k) B[n][k] = ldq(DZ2_OFF + k * TERM + 4096 * n + (rr_base ^ (64 * ks)));
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cu = ks & 1;
+                if (ks + 1 < 4) ldB(ks + 1, B[cu ^ 1]);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AT[ks][1], B[cu][0][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AT[ks][1], B[cu][1][0], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AT[ks][0], B[cu][0][1], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AT[ks][0], B[cu][1][1], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AT[ks][0], B[cu][0][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AT[ks][0], B[cu][1][0], acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) three(acc[n], AT[ks][0], AT[ks][1], B[n][0], B[n][1]);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         G5_STAMP(10);
         // ---- dZ1 of this wave's rows replaces H2 in the wave's own image (g3's reads of it were issued earlier: LDS is in order
-        // per wave); dW1 (and db1 in column 75): A = dZ1 own, B = the observations, both transposed
+        // per wave), then dW1 (and db1 in column 75): A = dZ1 own, B = the observations, both transposed.  That chain is all
+        // latency (image reads, vector work, stores, transposing reads, fifteen products): the first half of dW2 -- this wave's
+        // column block, A = dZ2 rows 16 t .., B = H1 own, both transposed, independent of dZ1 -- runs in its gaps; two output
+        // tiles' products alternate and the pair after them is read meanwhile
+        const char* hb = ldsb + H1_OFF;
+        const bf16x8 bh = tr_frag(hb + (tr0 ^ (32 * wave)), hb + (tr1 ^ (32 * wave)));
+        const bf16x8 bm = tr_frag(hb + TERM + (tr0 ^ (32 * wave)), hb + TERM + (tr1 ^ (32 * wave)));
+        bf16x8 Z[2][2][2];   // [stage][tile of the pair][term]
+        auto ldZ = [&](int t, bf16x8 (&f)[2]) {
+            const char* z0 = ldsb + DZ2_OFF + (tr0 ^ (32 * t));
+            const char* z1 = ldsb + DZ2_OFF + (tr1 ^ (32 * t));
+            f[0] = tr_frag(z0, z1); f[1] = tr_frag(z0 + TERM, z1 + TERM);
+        };
+        auto dw2_pair = [&](int t2, bf16x8 (&z)[2][2]) {
+            f32x4& ga_ = gw2[2 * t2];
+            f32x4& gb_ = gw2[2 * t2 + 1];
+            ga_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[0][1], bh, ga_, 0, 0, 0);
+            gb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[1][1], bh, gb_, 0, 0, 0);
+            ga_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[0][0], bm, ga_, 0, 0, 0);
+            gb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[1][0], bm, gb_, 0, 0, 0);
+            ga_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[0][0], bh, ga_, 0, 0, 0);
+            gb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z[1][0], bh, gb_, 0, 0, 0);
+        };
+        ldZ(0, Z[0][0]); ldZ(1, Z[0][1]);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             float dz[4];
+            // H1 of this wave's rows back from the image (hi + mid + lo = the fp32 value): eight registers less across five phases
+            bf16x4 t3[3];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz[r] = acc[n][r] * (1.f - h1[n][r] * h1[n][r]);
+            for (int k = 0; k < 3; ++k) t3[k] = __builtin_bit_cast(bf16x4, *reinterpret_cast<const uint2*>(ldsb + H1_OFF + k * TERM + 4096 * n + aw_base));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hh = ((float)t3[0][r] + (float)t3[1][r]) + (float)t3[2][r];
+                dz[r] = acc[n][r] * (1.f - hh * hh);
+            }
             uint2 sp[2];
             split2x4(dz, sp[0], sp[1]);
 #pragma unroll
             for (int k = 0; k < 2; ++k) st8(pw_base + k * PTERM + 768 * n, sp[k]);
         }
+        ldZ(2, Z[1][0]); ldZ(3, Z[1][1]);
+        dw2_pair(0, Z[0]);
         {
             const char* pv = ldsb + PV_OFF + 2 * PTERM * wave;
             const bf16x8 ah = tr_frag(pv + pt0, pv + pt1), am = tr_frag(pv + PTERM + pt0, pv + PTERM + pt1);
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
+            bf16x8 X[2][2];
+            auto ldX = [&](int t, bf16x8 (&f)[2]) {
                 const char* x0 = ldsb + X_OFF + (tr0 ^ (32 * t));
                 const char* x1 = ldsb + X_OFF + (tr1 ^ (32 * t));
-                three(gw1[t], ah, am, tr_frag(x0, x1), tr_frag(x0 + TERM, x1 + TERM));
+                f[0] = tr_frag(x0, x1); f[1] = tr_frag(x0 + TERM, x1 + TERM);
+            };
+            ldX(0, X[0]);
+            dw2_pair(1, Z[1]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (t + 1 < 5) ldX(t + 1, X[(t + 1) & 1]);
+                three(gw1[t], ah, am, X[t & 1][0], X[t & 1][1]);
             }
         }
         G5_STAMP(11);
         lds_barrier();   // Bx: the observation image has no reader left
         G5_STAMP(12);
-        // ---- the next tile's observations into the image, beside dW2's column block of this wave (A = dZ2 rows 16 t .., B = H1
-        // own, both transposed) and db2 (column 4 of the g3 tile, from this wave's own dZ2 rows)
+        // ---- the next tile's observations into the image, beside the second half of dW2
+        ldZ(4, Z[0][0]); ldZ(5, Z[0][1]);
         if (more && wave < 5) store_x();
-        {
-            const char* hb = ldsb + H1_OFF;
-            const bf16x8 bh = tr_frag(hb + (tr0 ^ (32 * wave)), hb + (tr1 ^ (32 * wave)));
-            const bf16x8 bm = tr_frag(hb + TERM + (tr0 ^ (32 * wave)), hb + TERM + (tr1 ^ (32 * wave)));
-            bf16x8 ones4;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ones4[i] = (__bf16)(c16 == 4 ? 1.f : 0.f);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const char* z0 = ldsb + DZ2_OFF + (tr0 ^ (32 * t));
-                const char* z1 = ldsb + DZ2_OFF + (tr1 ^ (32 * t));
-                const bf16x8 ah = tr_frag(z0, z1), am = tr_frag(z0 + TERM, z1 + TERM);
-                three(gw2[t], ah, am, bh, bm);
-                if (t == wave) {   // (wave-uniform: a scalar branch around the two products)
-                    g3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, ones4, g3, 0, 0, 0);
-                    g3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones4, g3, 0, 0, 0);
-                }
-            }
-        }
+        ldZ(6, Z[1][0]); ldZ(7, Z[1][1]);
+        dw2_pair(2, Z[0]);
+        dw2_pair(3, Z[1]);
         G5_STAMP(13);
         lds_barrier();   // B0: this tile's images have no reader left; the next tile's observations are in place
         G5_STAMP(14);
@@ -562,7 +650,10 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
     for (int r = 0; r < 4; ++r) {
         const int hrow = 16 * wave + 4 * g + r;
         if (c16 < a.n_out) emit(ga.gW3 + (size_t)c16 * H + hrow, O_W3 + c16 * H + hrow, g3[r]);
-        else if (c16 == 4) emit(ga.gb2 + hrow, O_B2 + hrow, g3[r]);
+        float v = db2[r];   // the group's 16 lanes hold the samples 16 n + c16 of row 4 g + r
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (c16 == 0) emit(ga.gb2 + hrow, O_B2 + hrow, v);
     }
     if (wave == 1) {
 #pragma unroll
@@ -585,7 +676,6 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
     }
 }
 
-#ifndef QENV_GRAD4_HPP
 // deterministic mode, second pass: element j of the head's gradients += the workgroups' slots in slot order
 __global__ __launch_bounds__(256) void k_sum_grad_slots(const float* partial, int n_slots, int n_out, float* gW1, float* gb1, float* gW2,
                                                         float* gb2, float* gW3, float* gb3) {
@@ -603,6 +693,5 @@ __global__ __launch_bounds__(256) void k_sum_grad_slots(const float* partial, in
     for (int b = 0; b < n_slots; ++b) acc += partial[(size_t)b * SLOT + j];
     *dst += acc;
 }
-#endif
 
 }  // namespace qenv

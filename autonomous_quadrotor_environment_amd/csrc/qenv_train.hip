@@ -986,7 +986,6 @@ template <int MT, int NTN> static int launch_wgrad(const WgradArgs& a, hipStream
 }
 
 }  // namespace qenv
-#include "qenv_grad4.hpp"
 #include "qenv_grad5.hpp"
 namespace qenv {
 
@@ -1129,19 +1128,13 @@ static int launch_bwd(BwdArgs& a, int hidden, void* stream) {
     return check_launch("k_mlp_bwd");
 }
 
-#ifdef QENV_GRAD4_STAMPS   /* diagnostic builds only (not declared in qenv.h) */
-int qenv_debug_grad4_stamps(unsigned long long* out64) {
-    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(qenv::g4_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
-}
-#endif
-
 #ifdef QENV_GRAD5_STAMPS   /* diagnostic builds only (not declared in qenv.h) */
 int qenv_debug_grad5_stamps(unsigned long long* out128) {
     return hipMemcpyFromSymbol(out128, HIP_SYMBOL(qenv::g5_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
 }
 #endif
 
-size_t qenv_mlp_grad_ppo_workspace_bytes(void) { return (size_t)256 * grad4::SLOT * sizeof(float); }
+size_t qenv_mlp_grad_ppo_workspace_bytes(void) { return (size_t)256 * grad5::SLOT * sizeof(float); }
 
 int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int head, const float* obs, int64_t obs_chunk_stride, const float* actions,
                       const float* old_logprob, const float* adv, const float* returns, const float* weight, double std,
@@ -1177,21 +1170,12 @@ int qenv_mlp_grad_ppo(int64_t n_envs, int n_chunks, int k_in, int hidden, int he
     const int cus = device_cu_count();
     int64_t blocks = n_tiles < cus ? n_tiles : cus;   // one resident workgroup per CU (its registers hold W2 twice); at most the workspace's 256 slots
     if (blocks > 256) blocks = 256;
-    static const bool use_v4 = [] { const char* s = getenv("QENV_GRAD_V4"); return s && atoi(s) != 0; }();
-    int rc;
-    if (use_v4) {
-        hipError_t e = allow_dynamic_lds((const void*)k_mlp_grad_v4, (size_t)grad4::LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_grad_v4)");
-        hipLaunchKernelGGL(k_mlp_grad_v4, dim3((unsigned)blocks), dim3(256), (size_t)grad4::LDS_BYTES, (hipStream_t)stream, g);
-        rc = check_launch("k_mlp_grad_v4");
-    } else {
-        hipError_t e = allow_dynamic_lds((const void*)k_mlp_grad_v5, (size_t)grad5::LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_grad_v5)");
-        hipLaunchKernelGGL(k_mlp_grad_v5, dim3((unsigned)blocks), dim3(512), (size_t)grad5::LDS_BYTES, (hipStream_t)stream, g);
-        rc = check_launch("k_mlp_grad_v5");
-    }
+    hipError_t e = allow_dynamic_lds((const void*)k_mlp_grad_v5, (size_t)grad5::LDS_BYTES);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_mlp_grad_v5)");
+    hipLaunchKernelGGL(k_mlp_grad_v5, dim3((unsigned)blocks), dim3(512), (size_t)grad5::LDS_BYTES, (hipStream_t)stream, g);
+    int rc = check_launch("k_mlp_grad_v5");
     if (rc == QENV_OK && workspace) {
-        hipLaunchKernelGGL(k_sum_grad_slots, dim3((unsigned)((grad4::SLOT + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_sum_grad_slots, dim3((unsigned)((grad5::SLOT + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, (int)blocks, a.n_out, gW1, gb1, gW2, gb2, gW3, gb3);
         rc = check_launch("k_sum_grad_slots");
     }

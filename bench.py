@@ -747,9 +747,10 @@ def next_rows(dev, policy):
     fl = samples * 2 * (75 * 128 + 128 * 128 + 128 * 4 + 75 * 128 + 128 * 128 + 128) * 3   # forward + 2x backward, both heads
     out["ppo_update_epoch"] = {"samples": samples, "valid_samples": int(float(ro.valid[:S].sum())), "seconds": dt,
                                "samples_per_s": samples / dt,
-                               "kernels": "k_mlp_grad_v4 x 2 (one launch per head: forward recompute, fused loss, backward AND the six weight / "
-                                          "bias gradients; the workgroup's four waves share a 32-sample tile, activations exchanged through LDS "
-                                          "images, transposed by ds_read_b64_tr_b16), k_adam",
+                               "kernels": "k_mlp_grad_v5 x 2 (one launch per head: forward recompute, fused loss, backward AND the six weight / "
+                                          "bias gradients; the workgroup's eight waves -- two per SIMD, 16 hidden rows each on 16x16x32 bf16 "
+                                          "tiles -- share a 32-sample tile, activations exchanged through LDS images, transposed by "
+                                          "ds_read_b64_tr_b16), k_adam",
                                "algorithmic_TFLOPs": fl / dt / 1e12,
                                # the samples themselves, read once per head: observations 75 floats + actions 4 + old log-probs 4 + adv +
                                # valid (actor) / returns + valid (critic); the counters agree (profiles/r05_update_epoch_counters.json:
@@ -757,8 +758,9 @@ def next_rows(dev, policy):
                                "hbm_GB_per_epoch": samples * 4 * (2 * 75 + 4 + 4 + 1 + 1 + 1 + 1) / 1e9,
                                "hbm_GBps": samples * 4 * (2 * 75 + 4 + 4 + 1 + 1 + 1 + 1) / dt / 1e9,
                                "hbm_GB_per_epoch_rounds_1_to_4": 2 * 37.3,
-                               "bound": "vector issue + matrix pipe in turn (one wave per SIMD: 1 080 vector and 166 matrix instructions per "
-                                        "wave and tile, matrix pipe 0.33 busy; profiles/r05_grad4_stamps.json); HBM traffic is the samples, once",
+                               "bound": "vector issue + matrix pipe + LDS in turn (two waves per SIMD in step behind five barriers per tile: ~600 "
+                                        "vector, 152 matrix and 187 LDS instructions per wave and tile; matrix pipe 0.36, LDS 0.60 busy; "
+                                        "profiles/r05_grad5_stamps.json, r05_update_epoch_counters.json); HBM traffic is the samples, once",
                                "weights": policy_label(policy), "schedule": "inband"}
     return out
 

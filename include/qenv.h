@@ -579,8 +579,8 @@ int qenv_weight_grad(int64_t n_envs, int n_chunks, int m_rows, int n_rows, const
  * launch: forward recompute, the fused loss of qenv_mlp_backward_ppo_masked (same arguments, same `sums`), the backward
  * pass AND the six weight / bias gradients (environment/controller/ppo.py:185-203's loss.mean().backward()), accumulated
  * INTO gW1 [128][75], gb1 [128], gW2 [128][128], gb2 [128], gW3 [n_out][128], gb3 [n_out] (n_out = 4 actor / 1 critic; the
- * caller zeroes them per step).  No activation is written to memory: the four wavefronts of a workgroup share a 32-sample
- * tile and contract it over the samples on the spot (qenv_grad4.hpp).  workspace: null = fp32 atomics (summation order
+ * caller zeroes them per step).  No activation is written to memory: the eight wavefronts of a workgroup share a 32-sample
+ * tile and contract it over the samples on the spot (qenv_grad5.hpp).  workspace: null = fp32 atomics (summation order
  * varies in the last bits), or qenv_mlp_grad_ppo_workspace_bytes() bytes (no initialisation needed) = every workgroup
  * stores its sums and a second launch adds them in a fixed order (bit-reproducible).  obs_chunk_stride: elements between the
  * [k_in][N] observation blocks of consecutive chunks -- 0 = dense (k_in * N), 15 * N = the slice layout a rollout stores

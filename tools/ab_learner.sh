@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU box: A/B of k_mlp_grad_v4 builds on ONE box, alternating (tools/time_update.py: the epoch at config 5's horizon).
-#   tools/ab_grad4.sh product g4pre g4bal ...   (names of build_variants/libqenv_NAME.so; "product" = the shipped library)
+# GPU box: A/B of learner builds (k_mlp_grad_v5 variants) on ONE box, alternating (tools/time_update.py: the epoch at config 5's horizon).
+#   tools/ab_learner.sh product g4pre g4bal ...   (names of build_variants/libqenv_NAME.so; "product" = the shipped library)
 cd "$GRAFT_REPO_ROOT"
 for rep in 1 2; do
   for n in "$@"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the learner's update epoch at config 5's horizon (tools/time_update.py: 65 536 envs x 128 steps = 8.4 M samples) under
 # rocprofv3: kernel trace + stats, HBM-side bytes (FETCH_SIZE and WRITE_SIZE in separate passes, corrected as
-# MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2 on gfx950) and the SQ counters of k_mlp_grad_v4.
+# MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2 on gfx950) and the SQ counters of k_mlp_grad_v5.
 #   tools/prof_learner_r05.sh TAG [ENV=VALUE ...]      (QENV_GRAD_ONE_LAUNCH=0: rounds 1-4's path, for the comparison)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r05}; shift
