@@ -117,8 +117,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-// lane l <-> lane l ^ 16 (ds_swizzle, bit mode: and 0x1f, or 0, xor 0x10 -- no LDS access)
-__device__ __forceinline__ float xor16(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); }
 }  // namespace grad5
 
 #ifdef QENV_GRAD5_STAMPS
@@ -377,7 +375,7 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
             __builtin_amdgcn_sched_barrier(0);
         }
         G5_STAMP(4);
-        // ---- tanh, layer 3's share of this wave (the lane groups' sums meet: xor 16 by ds_swizzle, xor 32 by v_permlane32_swap),
+        // ---- tanh, layer 3's share of this wave (the lane groups' sums meet: v_permlane16_swap, v_permlane32_swap),
         // H2 own into the wave's image (dW3's A operand, transposed)
         float h2[2][4];
         {
@@ -400,7 +398,8 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
             for (int n = 0; n < 2; ++n) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float v = o[n][k] + xor16(o[n][k]);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[n][k]), __float_as_uint(o[n][k]), false, false);
+                    const float v = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
                     const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
                     o[n][k] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
                 }
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(l_ac[k]), "+v"(l_lo[k]));
         asm volatile("" : "+v"(l_adv), "+v"(l_ret), "+v"(l_wgt));
-        // ---- output, loss, dz3 of this lane's sample (tile half g & 1), the other half's from lane ^ 16; dZ2 of this wave's rows
+        // ---- output, loss, dz3 of this lane's sample (tile half g & 1), the other half's from lane ^ 16 (v_permlane16_swap); dZ2 of this wave's rows
         float outv[4], sd[4], dz3[2][4];
         {
             float4 s4 = *reinterpret_cast<const float4*>(ldsb + B3_OFF);
@@ -464,12 +463,9 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
             if (wave == 0 && valid && lane < 32) loss_acc += (double)err * (double)err;
         }
         {
-            float own[4], oth[4];
+            float own[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                own[k] = a.final_tanh ? sd[k] * (1.f - outv[k] * outv[k]) : sd[k];
-                oth[k] = xor16(own[k]);
-            }
+            for (int k = 0; k < 4; ++k) own[k] = a.final_tanh ? sd[k] * (1.f - outv[k] * outv[k]) : sd[k];
             if (wave == 1 && lane < 32) {   // the dz3 operand image (two terms; row = sample, slot 0) and db3
                 uint2 sp[2];
                 split2x4(own, sp[0], sp[1]);
@@ -479,9 +475,10 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
                 for (int k = 0; k < 4; ++k) db3[k] += own[k];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dz3[0][k] = (g & 1) ? oth[k] : own[k];
-                dz3[1][k] = (g & 1) ? own[k] : oth[k];
+            for (int k = 0; k < 4; ++k) {   // v_permlane16_swap of a value with itself: [0] = the even lane group's (tile half 0), [1] = the odd one's
+                const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(own[k]), __float_as_uint(own[k]), false, false);
+                dz3[0][k] = __uint_as_float(r1[0]);
+                dz3[1][k] = __uint_as_float(r1[1]);
             }
         }
         {

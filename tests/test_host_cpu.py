@@ -329,3 +329,14 @@ def test_probe_bound_is_conservative(tmp_path, oracle):
     assert pb.pb_skippable(P(y), P(z), P(np.full(13, 1e3)), P(plant), tb, 0.0, thr) == 0
     y[6] = 0.3
     assert pb.pb_skippable(P(y), P(np.full(13, 0.1)), P(np.full(13, 1e3)), P(plant), tb, 50.0, thr) == 0
+
+
+def test_grad5_lds_address_maps():
+    """k_mlp_grad_v5's LDS images (csrc/qenv_grad5.hpp): tools/lds_layout_grad5.py replays the kernel's lane address formulas on a
+    model of the LDS and of ds_read_b64_tr_b16 -- every fragment is the MFMA operand the kernel claims, and only the accumulator
+    fragments' 8-byte stores conflict (two-way) under MI355X_MICROARCH.md's bank rules."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lds_layout_grad5.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "wrong elements in total 0" in r.stdout and r.stdout.strip().endswith("OK")
