@@ -9,15 +9,23 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 // x = hi + mid + lo with hi, mid, lo in bf16 (round to nearest each time): 24 significant bits, i.e. the fp32 value
-// exactly unless its exponent range underflows bf16's (it has fp32's)
+// exactly unless its exponent range underflows bf16's (it has fp32's).  Written on PAIRS of values as two-element vectors:
+// the residuals are then v_pk_add_f32 (one instruction per pair) whatever registers the values sit in -- on scalars hipcc
+// takes the packed form only when the pair happens to be register-aligned and otherwise converts every value twice (once
+// alone for its residual, once more beside its neighbour for the packed term: k_dense_tail_v3's chunk loop had 128
+// conversions for 40 values).  The same arithmetic, bit for bit.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 __device__ __forceinline__ void split3x8(const float x[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)x[i];
-        const float r1 = x[i] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2;
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 v = {x[i], x[i + 1]};
+        const bf16x2 h = __builtin_convertvector(v, bf16x2);
+        const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        hi[i] = h[0]; hi[i + 1] = h[1]; mid[i] = m[0]; mid[i + 1] = m[1]; lo[i] = l[0]; lo[i + 1] = l[1];
     }
 }
 
