@@ -115,6 +115,18 @@ struct MthLean {
     static __device__ __forceinline__ double rcp_ctl(double x) { return __builtin_amdgcn_rcp(x); }
     static __device__ __forceinline__ double div_ctl(double a, double b) { return a * __builtin_amdgcn_rcp(b); }
     static __device__ __forceinline__ double sqrt_ctl(double x) { return __builtin_amdgcn_sqrt(x); }
+    // x^(-1/5) to ~1 ulp: the fp32 estimate (2^-23) and two Newton steps on y^-5 = x, y <- y (1.2 - 0.2 x y^5) -- fourteen
+    // instructions where ocml's pow is hundreds (inlined into the attempt loop it cost the rollouts 14-22 %).  x = 0 / inf / NaN
+    // give inf / NaN, which the callers' fmin / fmax clamp exactly as they clamped the estimate.
+    static __device__ __forceinline__ double pow_m02(double x) {
+        double y = pow_ctl(x, -0.2);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double y2 = y * y;
+            y = y * fma(-0.2 * x, y2 * y2 * y, 1.2);
+        }
+        return y;
+    }
     static __device__ __forceinline__ double ulp_up(double t) { return nextafter(t, (double)INFINITY) - t; }
 };
 template <typename T, bool LEAN> struct MathSel { using type = Mth<T>; };
@@ -506,9 +518,25 @@ constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 
 
 // One DP5 step of size h from (y, k1 = f(y)) -> y_new, k7 = f(y_new), and the scaled
 // error norm of scipy's _estimate_error_norm (rk.py:108-109,143-144) if WITH_ERR.
+// Lean arithmetic sizes a FURTHER sub-step of an env step (after a rejected attempt, or an accepted one short of t_bound) with
+// control math good to 2^-23: a 1e-7 different partition of the interval moves the result by up to ~1e-9 relative per env
+// step, where a one-sub-step env step stays within 4e-13 of the reference.  Round 5's fuzz campaign found the regime that shows
+// it: the unclipped position-PD loop once it tumbles (rates of hundreds of rad/s, three to five sub-steps per env step):
+// 1e-6 from the reference after 80 steps where the IEEE handle is at 2e-11.  -DQENV_LEAN_EXACT_CTL=1 forms exactly those
+// attempts' norm with full-precision quotients and their factor with a full-precision root and x^-0.2 (1.2e-8 on the same
+// case; with -DQENV_LEAN_EXACT_H0=1, select_initial_step again in full precision when its result is below t_bound, 2e-11) --
+// measured on one box, product against variant: config 3 8.16 -> 7.62 G env-steps/s (-6.6 %: a wave runs the exact block
+// whenever ANY lane continues), config 2 -1 %, configs 4 / 5 unchanged; with H0 (and ocml's pow) 6.4 G, config 2 -14 %.  Not
+// the default: the deviation is four orders of magnitude inside the 1e-5 tolerance and the IEEE handle is exact
+// (profiles/r05_experiments_not_kept.txt).
+#ifndef QENV_LEAN_EXACT_CTL
+#define QENV_LEAN_EXACT_CTL 0
+#endif
+// exact_ctl (lean arithmetic only): another sub-step will follow this one inside the env step, so the error norm goes into a
+// step size that enters the arithmetic -- form it with full-precision quotients (see rk45_attempt)
 template <typename T, bool WITH_ERR, typename P>
 __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T>& u, P& pl, T h,
-                                      T yn[13], T k7[13], T inc[13]) {
+                                      T yn[13], T k7[13], T inc[13], bool exact_ctl = false) {
     using m = typename P::math;
     T k2[13], k3[13], k4[13], k5[13], k6[13], ys[13];
     // the step size goes into the tableau's coefficients once (15 products per attempt) instead of into every component's
@@ -557,8 +585,9 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
         if constexpr (sizeof(T) != 4) err2 = err2 * (h * h);
         if constexpr (m::lean) {
             // the hardware reciprocal is good to 2^-23: whenever the fast norm cannot decide err < 1 with a wide margin,
-            // form it again with full-precision quotients (rare: the branch is taken by ~1e-5 of the attempts)
-            if (m::abs(err2 - T(13)) < T(13e-5)) {
+            // form it again with full-precision quotients (rare: the branch is taken by ~1e-5 of the attempts) -- and
+            // whenever the norm will size a further sub-step (a rejected attempt, or an accepted one short of t_bound)
+            if (m::abs(err2 - T(13)) < T(13e-5) || (QENV_LEAN_EXACT_CTL && (exact_ctl || !(err2 < T(13))))) {
                 err2 = T(0);
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
@@ -585,21 +614,29 @@ __device__ __forceinline__ T dp5_step(const T y[13], const T k1[13], const Act<T
 // every lane leaves the loop after a bounded number of attempts.
 template <typename P> struct Rk45Cap { static constexpr int value = P::robust ? 16384 : 96; };
 
-// select_initial_step (common.py:66-133) from y and k1 = f(y): the first h_abs of the step.
-template <typename T, typename P>
+// select_initial_step (common.py:66-133) from y and k1 = f(y): the first h_abs of the step, NOT yet clamped to t_bound.
+// EXACT: full-precision reciprocals / roots / pow instead of the control forms (lean arithmetic: see integrate_rk45).
+template <typename M, bool EXACT> struct CtlMath {
+    template <typename T> static __device__ __forceinline__ T rcp(T x) { if constexpr (EXACT) return M::rcp(x); else return M::rcp_ctl(x); }
+    template <typename T> static __device__ __forceinline__ T sqrt(T x) { if constexpr (EXACT) return M::sqrt(x); else return M::sqrt_ctl(x); }
+    template <typename T> static __device__ __forceinline__ T div(T a, T b) { if constexpr (EXACT) return M::div(a, b); else return M::div_ctl(a, b); }
+    template <typename T> static __device__ __forceinline__ T pow(T a, T b) { if constexpr (EXACT) return M::pow(a, b); else return M::pow_ctl(a, b); }
+};
+template <typename T, typename P, bool EXACT = false>
 __device__ __forceinline__ T rk45_initial_step(const T y[13], const T k1[13], const Act<T>& u, P& pl, T tb) {
     using m = typename P::math;
+    using c = CtlMath<m, EXACT>;
     T d0 = T(0), d1 = T(0);
     T isc[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
-        isc[i] = m::rcp_ctl(T(1e-6) + m::abs(y[i]) * T(1e-3));
+        isc[i] = c::rcp(T(1e-6) + m::abs(y[i]) * T(1e-3));
         const T a = y[i] * isc[i], b = k1[i] * isc[i];
         d0 += a * a;
         d1 += b * b;
     }
-    d0 = m::sqrt_ctl(d0 * T(1.0 / 13)); d1 = m::sqrt_ctl(d1 * T(1.0 / 13));
-    T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : m::div_ctl(T(0.01) * d0, d1);
+    d0 = c::sqrt(d0 * T(1.0 / 13)); d1 = c::sqrt(d1 * T(1.0 / 13));
+    T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : c::div(T(0.01) * d0, d1);
     h0 = m::min(h0, tb);
     // h1 = (0.01 / max(d1, d2))^(1/5) only matters below t_bound: when max(d1, d2) <= 0.01 / t_bound^5 is PROVEN from y, f0 and
     // h0 alone (qenv_probe_bound.hpp: a Lipschitz bound of the nominal right-hand side along y .. y + h0 f0), the second
@@ -637,11 +674,11 @@ __device__ __forceinline__ T rk45_initial_step(const T y[13], const T k1[13], co
             const T a = (f1[i] - k1[i]) * isc[i];
             d2 += a * a;
         }
-        d2 = m::div_ctl(m::sqrt_ctl(d2 * T(1.0 / 13)), h0);
+        d2 = c::div(c::sqrt(d2 * T(1.0 / 13)), h0);
         if (d1 <= T(1e-15) && d2 <= T(1e-15)) h1 = m::max(T(1e-6), h0 * T(1e-3));
-        else h1 = m::pow_ctl(m::div_ctl(T(0.01), m::max(d1, d2)), T(0.2));
+        else h1 = c::pow(c::div(T(0.01), m::max(d1, d2)), T(0.2));
     }
-    return m::min(m::min(T(100) * h0, h1), tb);
+    return m::min(T(100) * h0, h1);
 }
 
 // One attempted sub-step of the accept/reject loop (rk.py:111-167) at time t with k1 = f(t, y).  Returns true when the
@@ -658,6 +695,35 @@ __device__ __forceinline__ bool rk45_attempt(T y[13], T k1[13], T dy[13], const 
     const T h = t_new - t;
     h_abs = h;
     T yn[13], k7[13], inc[13];
+    if constexpr (m::lean && QENV_LEAN_EXACT_CTL) {
+        // Lean arithmetic: the control quantities (error norm, growth factor) come from hardware seeds and fp32 log / exp, good
+        // to 2^-23 -- harmless while a step size is only compared or clamped to the rest of the interval, which is every env
+        // step that one sub-step covers.  When ANOTHER sub-step follows (a rejected attempt, or an accepted one short of
+        // t_bound) the factor sizes it, and a 1e-7 different partition of the interval moves the result by ~1e-10 relative:
+        // the fuzz campaign's tumbling position-PD loops (unclipped, rates of hundreds of rad/s, three to five sub-steps per
+        // env step) drifted 1e-6 from the reference where the IEEE handle stays at 1e-11.  So exactly those attempts form the
+        // norm with full-precision quotients and the factor with a full-precision root and x^-0.2; the others skip the factor
+        // altogether (its step size is never used: the next env step starts from select_initial_step).
+        const bool more = t_new < tb;
+        const T err2 = dp5_step<T, true>(y, k1, u, pl, h, yn, k7, inc, more);
+        if (err2 < T(13)) {
+            if (more) {
+                const T err = m::sqrt(err2 * T(1.0 / 13));
+                T factor = (err == T(0)) ? T(10) : m::min(T(10), T(0.9) * m::pow_m02(err));
+                if (rejected) factor = m::min(T(1), factor);
+                h_abs *= factor;
+            }
+            t = t_new;
+            rejected = false;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) { y[i] = yn[i]; k1[i] = k7[i]; dy[i] += inc[i]; }
+        } else {
+            const T err = m::sqrt(err2 * T(1.0 / 13));
+            h_abs *= m::max(T(0.2), T(0.9) * m::pow_m02(err));
+            rejected = true;
+        }
+        return !(t < tb);
+    }
     const T err2 = dp5_step<T, true>(y, k1, u, pl, h, yn, k7, inc);
     const T err = m::sqrt_ctl(err2 * T(1.0 / 13));
     // lean: decided on the (guard-banded) sum itself, sqrt_ctl is a hardware approximation there
@@ -704,6 +770,15 @@ __device__ __forceinline__ void integrate_rk45(T y[13], const Act<T>& u, P& pl, 
         }
     }
     T h_abs = rk45_initial_step(y, k1, u, pl, tb);   // (also for an env at rest: a branch around it costs the others more)
+#ifndef QENV_LEAN_EXACT_H0
+#define QENV_LEAN_EXACT_H0 0
+#endif
+    if constexpr (P::math::lean && QENV_LEAN_EXACT_CTL && QENV_LEAN_EXACT_H0) {
+        // lean arithmetic: a first step size below t_bound enters the arithmetic (rk45_attempt) -- rare (a violent state): again
+        // with full-precision control math; the 1e-6 covers the 2^-23 of the fast form
+        if (h_abs < tb * T(1.000001)) h_abs = rk45_initial_step<T, P, true>(y, k1, u, pl, tb);
+    }
+    h_abs = P::math::min(h_abs, tb);
     T t = at_rest ? tb : T(0);
     bool rejected = false;
     for (int it = 0; it < Rk45Cap<P>::value && t < tb; ++it)

@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256, QENV_MIN_WAVES) void k_rollout(const RolloutAr
                 if (!(CTRL == QENV_CTRL_CONST && s > 0)) rhs(y, u, pl, kq);
 #pragma unroll
                 for (int k = 0; k < 13; ++k) dy[k] = T(0);
-                h_abs = rk45_initial_step(y, kq, u, pl, cfg.t_step);
+                h_abs = Plant<T, ROBUST, LEAN>::math::min(rk45_initial_step(y, kq, u, pl, cfg.t_step), cfg.t_step);
                 t = T(0); rejected = false; it = 0; in_step = true;
             }
             const bool over = rk45_attempt(y, kq, dy, u, pl, cfg.t_step, t, h_abs, rejected);
