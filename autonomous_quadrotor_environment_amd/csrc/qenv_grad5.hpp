@@ -421,20 +421,17 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
         // ---- output, loss, dz3 of this lane's sample (tile half g & 1), the other half's from lane ^ 16 (v_permlane16_swap); dZ2 of this wave's rows
         float outv[4], sd[4], dz3[2][4];
         {
-            float4 s4 = *reinterpret_cast<const float4*>(ldsb + B3_OFF);
+            f32x4 s4 = *reinterpret_cast<const f32x4*>(ldsb + B3_OFF);   // (vector adds: v_pk_add_f32, the waves' sums in wave order)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const float4 pw = *reinterpret_cast<const float4*>(ldsb + PART_OFF + 512 * w + 256 * (g & 1) + 16 * c16);
-                s4.x += pw.x; s4.y += pw.y; s4.z += pw.z; s4.w += pw.w;
-            }
-            outv[0] = s4.x; outv[1] = s4.y; outv[2] = s4.z; outv[3] = s4.w;
+            for (int w = 0; w < NW; ++w) s4 += *reinterpret_cast<const f32x4*>(ldsb + PART_OFF + 512 * w + 256 * (g & 1) + 16 * c16);
+            outv[0] = s4[0]; outv[1] = s4[1]; outv[2] = s4[2]; outv[3] = s4[3];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (a.final_tanh) outv[k] = fast_tanh(outv[k]);   // (|error| <= 1.2e-7: a 1e-6 relative change of the probability ratio)
             sd[k] = 0.f;
         }
-        if (a.loss_mode == 1) {   // the actor's clipped surrogate (k_mlp_bwd's block; the ratio's exp in fp32: 1 ulp)
+        if (a.loss_mode == 1) {   // the actor's clipped surrogate (k_mlp_bwd's block; the ratio's exp in fp32)
             float lp = 0.f, lp_old = 0.f, d[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -442,7 +439,7 @@ __global__ __launch_bounds__(512) void k_mlp_grad_v5(const GradArgs ga) {
                 lp += -0.5f * d[k] * d[k] * a.inv_var + a.log_norm;
                 lp_old += l_lo[k];
             }
-            const float ratio = expf(lp - lp_old);
+            const float ratio = __builtin_amdgcn_exp2f((lp - lp_old) * 1.44269504088896341f);   // (v_exp_f32: 1 ulp; |lp - lp_old| stays far below its range limits)
             const float A = l_adv;
             const float clipped = fminf(fmaxf(ratio, 1.f - a.eps_clip), 1.f + a.eps_clip);
             const float s1 = ratio * A, s2 = clipped * A;
