@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QENV_LIB") or os.path.join(_HERE, "libqenv.so")  # QENV_LIB: developer A/B builds
 
-QENV_ABI_VERSION = 9
+QENV_ABI_VERSION = 10
 F32, F64 = 0, 1
 MAIN, OPT = 0, 1
 RK45, DP5, RK4 = 0, 1, 2
@@ -63,6 +63,7 @@ SYMBOLS = {
     "qenv_destroy": (_i, [_vp]),
     "qenv_set_stream": (_i, [_vp, _vp]),
     "qenv_field": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_int32)]),
+    "qenv_permute_envs": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "qenv_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "qenv_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "qenv_rollout": (_i, [_vp, _i, _i, _dptr, _i, _i]),

@@ -18,6 +18,28 @@ using namespace qenv;
          : FN<float, float, false>(__VA_ARGS__))
 
 // ---- C-ABI ----------------------------------------------------------------------------------------
+// ---- qenv_permute_envs' kernels (see there)
+namespace qenv {
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_rows(T* dst, const T* src, const int32_t* order, int rows, int64_t N) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const int64_t s = order[p];
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) dst[(int64_t)r * N + p] = src[(int64_t)r * N + s];
+}
+__global__ __launch_bounds__(256) void k_check_permutation(const int32_t* order, int64_t N, uint8_t* seen, int32_t* bad) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const int32_t s = order[p];
+    if (s < 0 || s >= N) { atomicAdd(bad, 1); return; }
+    seen[s] = 1;   // (a repeated source leaves another one unseen: counted by the caller's second pass)
+}
+__global__ __launch_bounds__(256) void k_count_unseen(const uint8_t* seen, int64_t N, int32_t* bad) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < N && !seen[p]) atomicAdd(bad, 1);
+}
+}  // namespace qenv
+
 extern "C" {
 
 int qenv_abi_version(void) { return QENV_ABI_VERSION; }
@@ -115,6 +137,53 @@ int qenv_field(qenv_t q, int field_id, void** dev_ptr, int32_t* rows) {
         return fail(QENV_ERR_ARG, "qenv_field: unknown field id");
     }
     return QENV_OK;
+}
+
+// ---- placement: the envs of the batch in another order (qenv.h, ABI 10) ----------------------------------------------------
+// every per-env row of the workspace moves: slot p receives what slot order[p] held -- state, bookkeeping (also what a reset
+// does not touch: prev_ang, ang_vel, the PID and outer-loop states, the banked returns, the episode counters), the robust
+// plant's parameters and gusts, the flags, the observation ring.  The compacted reset lists hold slot numbers: a reset in
+// progress (a masked warm-up waiting on the side stream) is refused.
+int qenv_permute_envs(qenv_t q, const int32_t* order, void* scratch, size_t scratch_bytes) {
+    if (!q || !order || !scratch) return fail(QENV_ERR_ARG, "qenv_permute_envs: null argument");
+    if (scratch_bytes < q->ws_bytes) return fail(QENV_ERR_ARG, "qenv_permute_envs: scratch needs qenv_workspace_bytes() bytes");
+    if (q->ar_pending || q->compact_valid)
+        return fail(QENV_ERR_ARG, "qenv_permute_envs: a masked reset is in progress (its lists hold slot numbers): qenv_ppo_flush / finish the warm-up first");
+    if (q->sens.ws || q->outer.kind != QENV_OUTER_NONE || q->robust)
+        return fail(QENV_ERR_ARG, "qenv_permute_envs: the handle has per-env state outside its workspace (an attached sensor, an outer loop's "
+                                  "table, a robust plant's gust source): detach it first");
+    const int64_t N = q->N;
+    const WsLayout L = ws_layout(q->cfg);
+    const size_t esz = q->cfg.dtype == QENV_F64 ? 8 : 4;
+    char* ws = (char*)q->ws; char* sc = (char*)scratch;
+    hipStream_t st = q->stream;
+    // is it a permutation?  (a wrong list would duplicate some envs and lose others, silently)
+    uint8_t* seen = (uint8_t*)sc; int32_t* bad = (int32_t*)(sc + align256((size_t)N));
+    hipError_t e = hipMemsetAsync(sc, 0, align256((size_t)N) + 256, st);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(qenv_permute_envs)");
+    const dim3 g1((unsigned)((N + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_check_permutation, g1, b, 0, st, order, N, seen, bad);
+    hipLaunchKernelGGL(k_count_unseen, g1, b, 0, st, (const uint8_t*)seen, N, bad);
+    int32_t nbad = 0;
+    e = hipMemcpyAsync(&nbad, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail_hip(e, "qenv_permute_envs: permutation check");
+    if (nbad) return fail(QENV_ERR_ARG, "qenv_permute_envs: order is not a permutation of 0 .. n_envs - 1");
+    auto gather = [&](size_t off, int rows, size_t elem) {
+        const dim3 g((unsigned)((N + 255) / 256), (unsigned)(rows < 16 ? rows : 16));
+        if (elem == 8) hipLaunchKernelGGL((k_gather_rows<double>), g, b, 0, st, (double*)(sc + off), (const double*)(ws + off), order, rows, N);
+        else if (elem == 4) hipLaunchKernelGGL((k_gather_rows<float>), g, b, 0, st, (float*)(sc + off), (const float*)(ws + off), order, rows, N);
+        else hipLaunchKernelGGL((k_gather_rows<uint8_t>), g, b, 0, st, (uint8_t*)(sc + off), (const uint8_t*)(ws + off), order, rows, N);
+        return hipMemcpyAsync(ws + off, sc + off, (size_t)rows * N * elem, hipMemcpyDeviceToDevice, st);
+    };
+    if ((e = gather(0, ROWS_T, esz)) != hipSuccess) return fail_hip(e, "qenv_permute_envs: rows");
+    // the int rows except the two reset lists (slot numbers, not in use: checked above)
+    if ((e = gather(L.int_off + (size_t)IROW_I * N * 4, 3, 4)) != hipSuccess) return fail_hip(e, "qenv_permute_envs: int rows");
+    if ((e = gather(L.int_off + (size_t)IROW_GUST_K * N * 4, 1, 4)) != hipSuccess) return fail_hip(e, "qenv_permute_envs: int rows");
+    if ((e = gather(L.flag_off, 1, 1)) != hipSuccess) return fail_hip(e, "qenv_permute_envs: flags");
+    if ((e = gather(L.flag_off + L.flag_stride, 1, 1)) != hipSuccess) return fail_hip(e, "qenv_permute_envs: flags");
+    if ((e = gather(L.win_off, 15 * q->cfg.T, 4)) != hipSuccess) return fail_hip(e, "qenv_permute_envs: window");
+    return check_launch("k_gather_rows");
 }
 
 int qenv_outer_velpid(qenv_t q, const void* table, int32_t n_rows) {

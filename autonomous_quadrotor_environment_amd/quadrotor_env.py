@@ -183,6 +183,8 @@ class BatchedQuad:
             L.check(L.lib.qenv_create(C.byref(self._cfg), L.ptr(self._ws), nbytes, C.c_void_p(self._bound_stream), C.byref(self._h)),
                     "qenv_create")
         self._fields = {}
+        self._order = None          # placement (regroup): logical env index of every SLOT of the batch, None = natural order
+        self._inv = None            # ... and the slot of every logical env
         if direct_control:
             self.zero_control = np.ones(4) * (2 / T2WR - 1)
         else:
@@ -251,7 +253,63 @@ class BatchedQuad:
             mask = torch.as_tensor(np.asarray(mask))
         if mask.numel() != self.n_envs:
             raise ValueError(f"mask: expected {self.n_envs} elements, got {tuple(mask.shape)}")
-        return mask.reshape(-1).to(device=self.device).to(torch.uint8).contiguous()
+        m = mask.reshape(-1).to(device=self.device).to(torch.uint8)
+        if self._order is not None:   # the caller's masks are in logical order
+            m = m.index_select(0, self._order)
+        return m.contiguous()
+
+    # ---- placement: which lane steps which env ---------------------------------------------------
+    # A wavefront runs as many RK45 attempts per env step as its slowest lane needs.  With the reference's random initial
+    # states ~5 % of the envs are never stabilised by the LQR: they tumble at tens of rad/s and need two or three sub-steps per
+    # env step for the rest of the episode -- and in the batch's natural order nearly every wave of 64 holds one (config 3: 1.73
+    # attempts per wave-step where the lanes need 1.02: the census of tests/tools/regroup_experiment.py).  regroup() sorts the
+    # envs by a key (default: the body-rate norm of their current states) so that the hard ones share waves: 1.25 attempts per
+    # wave-step, +14 % env-steps/s on config 3, every env's trajectory bit for bit what it was (an env never sees its
+    # neighbours).  The library moves every per-env row of the handle (qenv_permute_envs: also what a reset leaves alone --
+    # prev_ang, ang_vel, PID state, banked returns); from then on every per-env view of this object (state, reward, flags,
+    # episode_return ...) is in SLOT order -- logical(t) returns it in the caller's order, and reset() / masks are taken in
+    # the caller's order.  step() with per-env actions refuses a regrouped batch (the rollouts with an on-device controller are
+    # what this is for); clear_placement() moves everything back.
+    def regroup(self, key=None):
+        """Sort the envs by `key` ([N], one value per slot of the current placement; default |omega| of the current
+        states), now.  Returns the new order (logical env index per slot)."""
+        if key is None:
+            key = torch.linalg.vector_norm(self.state[10:13], dim=0)
+        key = torch.as_tensor(key, device=self.device).reshape(-1)
+        if key.numel() != self.n_envs:
+            raise ValueError(f"regroup: key needs {self.n_envs} elements, got {key.numel()}")
+        return self._permute(torch.argsort(key, stable=True))
+
+    def clear_placement(self):
+        """Back to the natural order (every per-env row moves back)."""
+        if self._inv is not None:
+            self._permute(self._inv)
+
+    def _permute(self, perm):
+        """Slot p receives what slot perm[p] holds."""
+        if getattr(self, "_sensor", None) is not None:
+            raise L.QenvError("regroup(): not with an attached sensor (its per-env state lives outside the handle)")
+        scratch = torch.empty(self._ws.numel(), dtype=torch.uint8, device=self.device)
+        p32 = perm.to(torch.int32).contiguous()
+        self._bind()
+        L.check(L.lib.qenv_permute_envs(self._h, L.ptr(p32), L.ptr(scratch), scratch.numel()), "qenv_permute_envs")
+        order = perm if self._order is None else self._order.index_select(0, perm)
+        if torch.equal(order, torch.arange(self.n_envs, device=self.device)):
+            self._order = self._inv = None
+        else:
+            self._order = order.contiguous()
+            self._inv = torch.empty_like(order)
+            self._inv[order] = torch.arange(self.n_envs, device=self.device)
+        return order
+
+    @property
+    def slot_order(self):
+        """[N] logical env index of every slot (None: natural order)."""
+        return self._order
+
+    def logical(self, t):
+        """A per-env tensor of this object ([..., N], slot order) in the caller's env order (a copy when a placement is on)."""
+        return t if self._inv is None else t.index_select(-1, self._inv)
 
     # ---- attributes (device views into the workspace, [rows, N]) -----------------------------
     state = property(lambda s: s._field(L.FIELD_STATE))
@@ -299,6 +357,8 @@ class BatchedQuad:
             self._rng = rng
             det_state = random_init_states(rng, self.n_envs, self.variant).T.copy()
         init = self._as_rows(det_state, 13, "det_state")
+        if self._order is not None:   # det_state is in the caller's order
+            init = init.index_select(1, self._order)
         m = self._mask(mask)
         states = torch.empty(self.T, 14, self.n_envs, device=self.device, dtype=self.dtype) if return_history else None
         actions = torch.empty(self.T, 4, self.n_envs, device=self.device, dtype=self.dtype) if return_history else None
@@ -311,6 +371,8 @@ class BatchedQuad:
 
     def reset_sampled(self, seed, episode=0, env_offset=0, mask=None, push_window=False):
         """Masked auto-reset with device-drawn initial states (sample_init_states + reset(mask) in one launch)."""
+        if self._order is not None:
+            raise L.QenvError("reset_sampled(): device-drawn initial states are keyed by the slot index -- not with regroup()")
         m = self._mask(mask)
         self._bind()
         L.check(L.lib.qenv_reset_sampled(self._h, int(seed), int(episode), int(env_offset), L.ptr(m),
@@ -322,6 +384,9 @@ class BatchedQuad:
         out_mask: optional [N] tensor receiving 1 - done; push_window: also append this step's
         [action, vel, q, q_dot] slice to the observation ring (dl_in_gen.dl_input).
         Returns (quat_state [14, N], reward [N], done [N] bool)."""
+        if self._order is not None and action is not None and np.ndim(action) > 1:
+            raise L.QenvError("step(): this batch is regrouped (regroup()): per-env actions would be taken in slot order -- "
+                              "index them with env.slot_order yourself, or clear_placement() and reset")
         act = self._as_rows(action, 4, "action")
         self._bind()
         if push_window:

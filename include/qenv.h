@@ -45,7 +45,7 @@ extern "C" {
  * 4: qenv_mlp_backward_ppo's sums has five entries ([4]: d actor / d std); qenv_ppo_step / qenv_ppo_flush; compute mode LEAN.
  * 3: QENV_FIELD_EP_RETURN no longer counts the rewards of the reset's own warm-up steps; added qenv_mlp_backward_ppo,
  *    qenv_weight_grad_deterministic, qenv_gae_deterministic and their workspace-size queries. */
-#define QENV_ABI_VERSION 9
+#define QENV_ABI_VERSION 10
 
 typedef struct qenv_s *qenv_t;
 
@@ -166,6 +166,17 @@ int qenv_set_stream(qenv_t q, void *stream); /* hipStream_t */
 
 /* Device pointer of a workspace row block + its row count (quad attributes). */
 int qenv_field(qenv_t q, int field_id, void **dev_ptr, int32_t *rows);
+
+/* ABI 10.  Placement: the envs of the batch in another order -- slot p receives everything slot order[p] held (state,
+ * bookkeeping incl. what quad.reset leaves alone -- prev_ang, ang_vel: quadrotor_env.py:408-454 --, PID state, returns,
+ * counters, flags, observation ring).  A wavefront runs as many solve_ivp sub-steps per env step as its slowest lane needs
+ * (quadrotor_env.py:483: a new solve_ivp per step); envs that a controller does not stabilise take two or three for the rest
+ * of their episode, and sorted together (e.g. by |omega|) they stop holding one lane of every wavefront: BASELINE configs[2]
+ * +14 % env-steps/s, every env's trajectory bit for bit the same.  order: device, int32[n_envs], a permutation (checked);
+ * scratch: device, qenv_workspace_bytes() bytes.  The caller keeps the slot -> env map for its own views (the Python
+ * wrapper: BatchedQuad.regroup / logical).  Refused while a masked reset's lists are in use and on handles with per-env
+ * state outside the workspace (attached sensor, outer-loop table, robust plant).  Synchronises `stream` once. */
+int qenv_permute_envs(qenv_t q, const int32_t *order, void *scratch, size_t scratch_bytes);
 
 /* ---- the hot path ------------------------------------------------------------------ */
 

@@ -1,0 +1,41 @@
+"""GPU box: what does the ORDER of the envs in the batch cost config 3?  A wave runs as many RK45 attempts per env step as its
+slowest lane needs; the envs the LQR does not stabilise (about 5 % of the random initial states: they tumble at tens of rad/s
+and take two or three sub-steps per env step for the rest of the episode) sit in almost every wave of 64 when the batch is in
+its natural order.  Times 500-step episodes (two 250-step launches + the reset, as bench.py does) in the natural order and with
+the envs sorted by |omega| at the end of a first episode; checks that every env's final state is bit-identical."""
+import os, sys, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import autonomous_quadrotor_environment_amd as aq
+from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+x0 = torch.from_numpy(np.ascontiguousarray(fast_random_init_states(3, N, 0, N).T)).cuda()
+
+
+def episodes(x, reps):
+    env = aq.BatchedQuad(N, 0.01, 10 ** 9, training=False, direct_control=0, T=1, integrator="rk45", dtype=torch.float64, compute="lean")
+    def ep():
+        env.reset(x)
+        for _ in range(500 // K):
+            env.rollout("lqr", K)
+    ep(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return env, dt
+
+
+env, dt_nat = episodes(x0, 6)
+st_nat = env.state.clone()
+key = torch.linalg.vector_norm(st_nat[10:13], dim=0)
+order = torch.argsort(key)
+env2, dt_srt = episodes(x0[:, order].contiguous(), 6)
+same = bool(torch.equal(env2.state, st_nat[:, order]))
+# a coarser key: sixteen buckets of log |omega| (a radix pass instead of a sort)
+print(json.dumps(dict(envs=N, steps_per_launch=K, natural_Gsteps_s=round(N * 500 / dt_nat / 1e9, 3), sorted_Gsteps_s=round(N * 500 / dt_srt / 1e9, 3),
+                      gain=round(dt_nat / dt_srt, 3), states_bit_identical=same,
+                      share_omega_gt_1=float((key > 1).float().mean()), share_omega_gt_10=float((key > 10).float().mean()))))
