@@ -271,14 +271,16 @@ class BatchedQuad:
     # the caller's order.  step() with per-env actions refuses a regrouped batch (the rollouts with an on-device controller are
     # what this is for); clear_placement() moves everything back.
     def regroup(self, key=None):
-        """Sort the envs by `key` ([N], one value per slot of the current placement; default |omega| of the current
-        states), now.  Returns the new order (logical env index per slot)."""
+        """Sort the envs by `key`, largest first ([N], one value per slot of the current placement; default |omega| of the
+        current states), now.  Returns the new order (logical env index per slot)."""
         if key is None:
             key = torch.linalg.vector_norm(self.state[10:13], dim=0)
         key = torch.as_tensor(key, device=self.device).reshape(-1)
         if key.numel() != self.n_envs:
             raise ValueError(f"regroup: key needs {self.n_envs} elements, got {key.numel()}")
-        return self._permute(torch.argsort(key, stable=True))
+        # the hard envs FIRST: a launch dispatches its workgroups in slot order, so the slow waves start first and the easy
+        # ones fill the tail of the launch (ascending: the slowest waves are the last to start -- 2.4 % less on config 3)
+        return self._permute(torch.argsort(key, descending=True, stable=True))
 
     def clear_placement(self):
         """Back to the natural order (every per-env row moves back)."""

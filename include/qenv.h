@@ -172,7 +172,7 @@ int qenv_field(qenv_t q, int field_id, void **dev_ptr, int32_t *rows);
  * counters, flags, observation ring).  A wavefront runs as many solve_ivp sub-steps per env step as its slowest lane needs
  * (quadrotor_env.py:483: a new solve_ivp per step); envs that a controller does not stabilise take two or three for the rest
  * of their episode, and sorted together (e.g. by |omega|) they stop holding one lane of every wavefront: BASELINE configs[2]
- * +14 % env-steps/s, every env's trajectory bit for bit the same.  order: device, int32[n_envs], a permutation (checked);
+ * +14 % env-steps/s (hard envs first: the slow wavefronts are dispatched first), every env's trajectory bit for bit the same.  order: device, int32[n_envs], a permutation (checked);
  * scratch: device, qenv_workspace_bytes() bytes.  The caller keeps the slot -> env map for its own views (the Python
  * wrapper: BatchedQuad.regroup / logical).  Refused while a masked reset's lists are in use and on handles with per-env
  * state outside the workspace (attached sensor, outer-loop table, robust plant).  Synchronises `stream` once. */
