@@ -973,3 +973,35 @@ def test_regroup_places_envs_without_changing_any_of_them(aq, N, ctrl):
     episode(ref); episode(env)
     assert torch.equal(env.state, ref.state)
     env.step(torch.zeros(4, N, device="cuda", dtype=torch.float64))
+
+
+@pytest.mark.parametrize("N,dt", [(1, torch.float64), (63, torch.float32), (1500, torch.float32), (1500, torch.float64)])
+def test_permute_envs_moves_every_row_of_any_handle(aq, N, dt):
+    """qenv_permute_envs on the other handle shapes: fp32 / IEEE fp64 rows, a T = 5 observation ring that is being pushed, training
+    bounds, one env.  After the move the batch steps on (zero-control steps need no per-env input) exactly as the batch in the
+    natural order does, ring included."""
+    from autonomous_quadrotor_environment_amd.quadrotor_env import fast_random_init_states
+    kw = dict(training=True, direct_control=1, T=5, dtype=dt)
+    x0 = torch.from_numpy(np.ascontiguousarray(fast_random_init_states(5, N).T)).cuda()
+    ref = aq.BatchedQuad(N, 0.01, 200, **kw); env = aq.BatchedQuad(N, 0.01, 200, **kw)
+    for e in (ref, env):
+        e.reset(x0, push_window=True)
+        for _ in range(7):
+            e.step(None, push_window=True)
+    g = torch.Generator(device="cuda").manual_seed(N)
+    order = env.regroup(torch.rand(N, device="cuda", generator=g))
+    names = ("state", "ang", "prev_ang", "ang_vel", "V_q", "w", "step_effort", "clipped_action", "accel", "prev_shaping", "reward",
+             "abs_sum", "episode_return", "i", "flags", "window", "last_return", "episodes")
+    for name in names:
+        assert torch.equal(env.logical(getattr(env, name)), getattr(ref, name)), name
+    if N > 1:
+        assert env.slot_order is not None and torch.equal(env.window, ref.window[:, order])
+    for e in (ref, env):
+        for _ in range(6):
+            e.step(None, push_window=True)
+        e.rollout("const", 9)
+    for name in names:
+        assert torch.equal(env.logical(getattr(env, name)), getattr(ref, name)), name
+    env.clear_placement()
+    for name in names:
+        assert torch.equal(getattr(env, name), getattr(ref, name)), name
