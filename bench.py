@@ -7,8 +7,10 @@ A "step" is one pass of the hot path over this rank's batch: one `quad.step()` f
 Default workload = BASELINE.json configs[2], the largest single-GPU configuration: 262 144 parallel
 envs per GPU, the LQR inner loop (lqr_quad.py:123-168) on random initial states (seed 3), the full
 step (integrator, Euler angles, done, reward), the reference's integrator (scipy-exact adaptive RK45),
-500-step episodes.  (Rounds 1-4 quoted configs[1], the smaller one; it is now the first entry of
-`configs`, perturbed and literally-at-hover.)  Envs shard across ranks with no data-path collective
+500-step episodes, the envs placed so that the ones the LQR never stabilises share wavefronts (BatchedQuad.regroup after
+one untimed placement episode: per-env results bit-identical; `configs.config3_natural_order` = the batch as drawn;
+--placement natural).  (Rounds 1-4 quoted configs[1], the smaller one; it is now an entry of `configs`, perturbed and
+literally-at-hover.)  Envs shard across ranks with no data-path collective
 (weak scaling: per-GPU batch fixed); the episode returns are all-gathered once after the timed region
 for the configs that have rewards.
 
@@ -28,7 +30,8 @@ for all of them -- fp32 arithmetic (fp32 and mixed handles) is at 1e-4 / 5e-5 af
 config 2 already (thrust minus weight cancels to 1e-6 m/s^2 in fp32).
 
 The K-step region (barrier + sync on both sides, exactly K steps) is repeated until >= 0.3 s
-have been timed; `ms_per_step` / `value` are the MEDIAN region.  The contract line carries
+have been timed; `ms_per_step` / `value` are the MEDIAN region -- for the episodic workloads (config 3 / 4) the MEAN over
+regions that cover whole episodes: a region costs what its phase of the episode costs.  The contract line carries
 the contract fields plus `roofline`, `cpu_baseline`, `sustained` and (default run)
 `configs`: short per-GPU slices of the other BASELINE configs.  A rank's clock for a region stops when its own GPU
 has finished (torch.cuda.synchronize); the MAX all-reduce over the ranks closes the bracket afterwards.
