@@ -964,6 +964,11 @@ def test_regroup_places_envs_without_changing_any_of_them(aq, N, ctrl):
     with pytest.raises(L.QenvError):                       # not a permutation
         env._permute(torch.zeros(N, dtype=torch.int64, device="cuda"))
     # a second regrouping composes with the first; clearing moves everything back
+    env.regroup("spin")                                                      # a named key: |wz| + 0.3 |wxy|, largest first
+    k2 = ref.state[12].abs() + 0.3 * torch.linalg.vector_norm(ref.state[10:12], dim=0)
+    assert bool((k2[env.slot_order][1:] <= k2[env.slot_order][:-1]).all()) and torch.equal(env.logical(env.state), ref.state)
+    env._permute(env._inv.index_select(0, order))                            # back to `order`
+    assert torch.equal(env.slot_order, order)
     o2 = env.regroup(torch.arange(N, device="cuda", dtype=torch.float64))   # largest key first: the slots in reverse
     assert torch.equal(o2, order.flip(0)) and torch.equal(env.logical(env.state), ref.state)
     env.clear_placement()
