@@ -84,6 +84,7 @@ SYMBOLS = {
     "qenv_sensor_bias_reset": (_i, [_vp, _vp, _vp, _i, _dptr]),
     "qenv_attach_sensor": (_i, [_vp, _vp, _vp, C.c_uint64, _i64, _i, _dptr, _vp, C.c_uint64]),
     "qenv_dense_tail": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qenv_dense_tail_rows": (_i, [_i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_dense_tail_chunks": (_i, [_i64, C.c_int32, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_dense_tail_chunks_strided": (_i, [_i64, C.c_int32, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qenv_sample_action": (_i, [_vp, _vp, C.c_double, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _vp]),

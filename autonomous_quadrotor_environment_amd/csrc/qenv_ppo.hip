@@ -1503,9 +1503,9 @@ template <bool SAMPLE> static int launch_mlp_256(const MlpArgs& a, int T, hipStr
 // padded by one word so the transposing staging writes are conflict-free); the four waves of a workgroup
 // march over the chunks together, each accumulating its own 32-env tile.
 struct DenseArgs {
-    const float* x;  // [n_chunks][K][N]
+    const float* x;  // [n_chunks][K][N] (feature-major), or [n_chunks][N][K] (rows: sample-major, torch's [batch, features])
     int64_t N;
-    int32_t K, n_out, final_tanh, n_chunks;
+    int32_t K, n_out, final_tanh, n_chunks, rows;
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     float* out;
 };
@@ -1699,9 +1699,28 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
         // carries the sample and the half's 8 rows; rows >= K fall out of the range check)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + chunk * (int64_t)a.K * a.N), 0,
                                                                             (int)((uint32_t)a.K * N32 * 4u), 0x00020000);
-        const uint32_t voff = valid ? ((uint32_t)e + 8u * (uint32_t)half * N32) * 4u : 0x80000000u;
+        // rows (the reference's own layout: rl_nn_model.py flattens its conv features to [batch, 800]): a lane's fragment of a
+        // k-step -- eight consecutive k of ONE sample -- is 32 contiguous bytes: two 16-byte loads instead of eight 4-byte ones
+        // 512 KiB apart, and no transposed copy of the features for the caller to make.  (Bare, the chip streams this pattern
+        // at 5.1-5.5 TB/s and the feature-major one at 1.3, tools/ubench/read_patterns.hip -- but this kernel runs 132-138 us
+        // on either: how it reads is not what bounds it.)
+        const uint32_t voff = !valid ? 0x80000000u
+                              : a.rows ? ((uint32_t)e * (uint32_t)a.K + 8u * (uint32_t)half) * 4u
+                                       : ((uint32_t)e + 8u * (uint32_t)half * N32) * 4u;
         float xw[KSC][8];
         auto request_x = [&](int kc) {
+            if (a.rows) {
+#pragma unroll
+                for (int s = 0; s < KSC; ++s) {
+                    const bool in = kc + 16 * s + 8 * half < a.K;   // (K % 8 == 0: a fragment is inside or outside as a whole;
+                    const uint32_t vo = in ? voff : 0x80000000u;    //  outside would be the NEXT sample's features, not zeros)
+                    const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (uint32_t)(kc + 16 * s) * 4u, 0);
+                    const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (uint32_t)(kc + 16 * s + 4) * 4u, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { xw[s][i] = __uint_as_float(lo[i]); xw[s][4 + i] = __uint_as_float(hi[i]); }
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < KSC; ++s)
 #pragma unroll
@@ -1821,6 +1840,9 @@ template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream)
             return check_launch("k_dense_tail_v3");
         }
     }
+    if (a.rows)
+        return fail(QENV_ERR_ARG, "qenv_dense_tail_rows: sample-major features are read by k_dense_tail_v3 only (hidden 64, K % 8 == 0, "
+                                  ">= 65 536 samples); other shapes: feature-major x [K][N]");
     const size_t lds = sizeof(float) * (64 * (HP + 1) + HP * HP + 32 * HP + 2 * HP + 32);
     hipError_t e = allow_dynamic_lds((const void*)k_dense_tail<H>, lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(k_dense_tail)");
@@ -2371,7 +2393,7 @@ int qenv_dense_tail_chunks_strided(int64_t n, int32_t n_chunks, int64_t chunk_st
         }
     }
     DenseArgs a;
-    a.x = x; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh; a.n_chunks = n_chunks;
+    a.x = x; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh; a.n_chunks = n_chunks; a.rows = 0;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     switch (hidden) {
         case 16: return launch_dense<16>(a, (hipStream_t)stream);
@@ -2380,6 +2402,20 @@ int qenv_dense_tail_chunks_strided(int64_t n, int32_t n_chunks, int64_t chunk_st
         case 128: return launch_dense<128>(a, (hipStream_t)stream);
         default: return fail(QENV_ERR_ARG, "qenv_dense_tail: hidden must be 16, 32, 64 or 128");
     }
+}
+
+int qenv_dense_tail_rows(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float* x_rows, const float* W1,
+                         const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* out,
+                         void* stream) {
+    if (!x_rows || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return fail(QENV_ERR_ARG, "qenv_dense_tail_rows: null argument");
+    if (n <= 0 || k_in <= 0 || n_out < 1 || n_out > 4) return fail(QENV_ERR_ARG, "qenv_dense_tail_rows: bad sizes");
+    if ((int64_t)k_in * n >= ((int64_t)1 << 29)) return fail(QENV_ERR_ARG, "qenv_dense_tail_rows: K*n must stay below 2^29 (32-bit byte offsets)");
+    if (((uintptr_t)x_rows & 15) != 0) return fail(QENV_ERR_ARG, "qenv_dense_tail_rows: x_rows must be 16-byte aligned");
+    if (hidden != 64) return fail(QENV_ERR_ARG, "qenv_dense_tail_rows: hidden must be 64 (rl_nn_model.py's tail); other shapes: qenv_dense_tail");
+    DenseArgs a;
+    a.x = x_rows; a.N = n; a.K = k_in; a.n_out = n_out; a.final_tanh = final_tanh; a.n_chunks = 1; a.rows = 1;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
+    return launch_dense<64>(a, (hipStream_t)stream);
 }
 
 int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float* x, const float* W1,

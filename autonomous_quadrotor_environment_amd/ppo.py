@@ -251,14 +251,23 @@ def adv_normalize(adv, stats, ddof=0, valid=None):
     return adv
 
 
-def dense_tail(x, weights, final_tanh=True, out=None):
+def dense_tail(x, weights, final_tanh=True, out=None, rows=False):
     """Dense tail of visual_landing/rl_nn_model.py (:58-66): Linear(K,H) tanh Linear(H,H) tanh Linear(H,n_out)
-    [tanh] on feature-major float32 x [K, N]; weights = [W1, b1, W2, b2, W3, b3] float32 device tensors in
-    torch layout.  Returns [n_out, N]."""
+    [tanh] on feature-major float32 x [K, N] -- or, rows=True, on x [N, K], the layout the reference's own model feeds this
+    tail (its conv features flattened to [batch, 800]): no transposed copy to make (hidden 64, K % 8 == 0, >= 65 536
+    samples; the same speed), bit-identical to the feature-major call on x.t().  weights = [W1, b1, W2, b2, W3, b3]
+    float32 device tensors in torch layout.  Returns [n_out, N]."""
     W1, b1, W2, b2, W3, b3 = [w.to(device=x.device, dtype=torch.float32).contiguous() for w in weights]
-    K, N = x.shape
+    K, N = (x.shape[1], x.shape[0]) if rows else x.shape
     assert W1.shape[1] == K and x.dtype == torch.float32
     x = x.contiguous()
+    if rows:
+        out = torch.empty(W3.shape[0], N, device=x.device, dtype=torch.float32) if out is None else out
+        if tuple(out.shape) != (W3.shape[0], N) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+            raise ValueError(f"dense_tail: out must be a contiguous float32 [{W3.shape[0]}, {N}] tensor on {x.device}")
+        L.check(L.lib.qenv_dense_tail_rows(N, K, W1.shape[0], W3.shape[0], int(bool(final_tanh)), L.ptr(x), L.ptr(W1), L.ptr(b1),
+                                           L.ptr(W2), L.ptr(b2), L.ptr(W3), L.ptr(b3), L.ptr(out), _stream(x.device)), "qenv_dense_tail_rows")
+        return out
     out = torch.empty(W3.shape[0], N, device=x.device, dtype=torch.float32) if out is None else out
     if tuple(out.shape) != (W3.shape[0], N) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
         raise ValueError(f"dense_tail: out must be a contiguous float32 [{W3.shape[0]}, {N}] tensor on {x.device}")

@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-/* 9: qenv_mlp_grad_ppo / qenv_mlp_grad_ppo_workspace_bytes (backward + weight gradients of a head in one launch: no activation
+/* 10: qenv_permute_envs (placement: the envs of a batch in another order); qenv_dense_tail_rows (the dense tail on sample-major features).
+ * 9: qenv_mlp_grad_ppo / qenv_mlp_grad_ppo_workspace_bytes (backward + weight gradients of a head in one launch: no activation
  *    round trip through HBM); a plain qenv_set_ppo_fused(q, 0 / 1) leaves a forced env block as it is.
  * 8: qenv_set_ppo_fused_block, qenv_get_ppo_fused; qenv_set_robust refuses the lean fp64 handle (it has no robust kernels) instead of failing at
  *    the first step; qenv_ppo_rollout validates its arguments up front on every path.
@@ -332,6 +333,15 @@ int qenv_attach_sensor(qenv_t q, void *sens, const void *z27, uint64_t seed, int
 int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float *x,
                     const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                     const float *b3, float *out, void *stream);
+/* ABI 10.  The same on the features in the reference's OWN layout: x_rows float32 [N][K], sample-major -- what
+ * rl_nn_model.py:58 feeds its first Linear (the conv stack's output flattened to [batch, 800]); out stays [n_out][N].  No
+ * transposed copy of the features for the caller to make (419 MB at 131 072 samples); a lane's operand fragment is 32
+ * contiguous bytes of its sample's row.  The same time as the feature-major call (the kernel is not bound by how it reads:
+ * 132-138 us either way, tools/ubench/read_patterns.hip) and bit-identical to it on the transposed features.  hidden 64,
+ * K % 8 == 0, >= 65 536 samples, x_rows 16-byte aligned (else QENV_ERR_ARG: transpose and use qenv_dense_tail). */
+int qenv_dense_tail_rows(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float *x_rows,
+                         const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                         const float *b3, float *out, void *stream);
 /* The same network over n_chunks independent chunks in ONE launch: x [n_chunks][K][N] -> out [n_chunks][n_out][N]
  * (the layout of a stored time-major rollout: the forward pass of PPO.update, ppo.py:176-183, over all its steps). */
 int qenv_dense_tail_chunks(int64_t n, int32_t n_chunks, int k_in, int hidden, int n_out, int final_tanh,

@@ -203,6 +203,12 @@ def test_ppo_loss_and_seed_gradients_golden(aq, dt):
     assert float((out["grad_mean"] == 0).float().mean()) > 0.02  # some samples sit on the saturated clamp
 
 
+def w_small():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, device="cuda", generator=g) * 0.05
+    return [r(64, 800), r(64), r(64, 64), r(64), r(3, 64), r(3)]
+
+
 def test_dense_tail_rl_nn_model_shape(aq, oracle):
     """rl_nn_model.py dense tail 800 -> 64 -> 64 -> 3 (tanh x3) and its critic twin (-> 1, no final tanh) on
     synthetic U(-1,1) features, against the fp64 oracle MLP; ragged N."""
@@ -223,6 +229,12 @@ def test_dense_tail_rl_nn_model_shape(aq, oracle):
                                  W3.astype(np.float32).astype(np.float64), b3.astype(np.float32).astype(np.float64), ft)
         assert got.shape == (N, n_out)
         assert np.max(np.abs(got - ref)) < 5e-6, (K, H, n_out, np.max(np.abs(got - ref)))
+        if H == 64 and K % 8 == 0 and N >= 65536:
+            # the features in the reference's own layout ([batch, K], rl_nn_model.py:58): the same bits, no transposed copy
+            rows = _np(aq.dense_tail(torch.from_numpy(np.ascontiguousarray(x.T)).cuda(), w, final_tanh=ft, rows=True)).T
+            assert np.array_equal(rows, got), (K, N)
+    with pytest.raises(aq._lib.QenvError):   # the row layout is read by k_dense_tail_v3 only: small batches say so
+        aq.dense_tail(torch.zeros(1000, 800, device="cuda"), w_small(), final_tanh=True, rows=True)
 
 
 def test_dense_tail_landing_model_fixture(aq):

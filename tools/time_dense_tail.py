@@ -23,5 +23,16 @@ for K, H, n_out, N in SHAPES[:int(sys.argv[1]) if len(sys.argv) > 1 else 3]:   #
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1000 / 20
     flops = 2.0 * N * (K * H + H * H + H * n_out)
-    print(json.dumps(dict(K=K, hidden=H, n_out=n_out, samples=N, us=round(us, 1), samples_per_s=round(N / us * 1e6),
-                          hbm_TBps=round((K + n_out) * 4 * N / us / 1e6, 2), algorithmic_TFLOPs=round(flops / us / 1e6, 1))), flush=True)
+    rec = dict(K=K, hidden=H, n_out=n_out, samples=N, us=round(us, 1), samples_per_s=round(N / us * 1e6),
+               hbm_TBps=round((K + n_out) * 4 * N / us / 1e6, 2), algorithmic_TFLOPs=round(flops / us / 1e6, 1))
+    if H == 64 and K * N < (1 << 29):   # the same features sample-major ([N, K]: the reference's own layout)
+        xr = x.t().contiguous(); out2 = torch.empty_like(out)
+        for _ in range(3):
+            aq.dense_tail(xr, W, final_tanh=True, out=out2, rows=True)
+        torch.cuda.synchronize(); a.record()
+        for _ in range(20):
+            aq.dense_tail(xr, W, final_tanh=True, out=out2, rows=True)
+        b.record(); torch.cuda.synchronize()
+        us2 = a.elapsed_time(b) * 1000 / 20
+        rec.update(rows_us=round(us2, 1), rows_hbm_TBps=round((K + n_out) * 4 * N / us2 / 1e6, 2), rows_bit_identical=bool(torch.equal(out, out2)))
+    print(json.dumps(rec), flush=True)
