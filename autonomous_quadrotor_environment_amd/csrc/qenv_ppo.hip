@@ -1645,7 +1645,17 @@ constexpr int W3T = W2F + NT * NT * 2 * 3 * 64;                   // [64] float4
 constexpr int B1 = W3T + H, B2 = B1 + H / 4, B3 = B2 + H / 4, LDS_UINT4 = B3 + 1;
 }  // namespace dt3
 
-__global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
+// in-kernel stamps (diagnostic builds: tools/build_variant.sh dt3stamps "-DQENV_DT3_STAMPS" qenv_ppo.hip; tests/tools/dense_tail_stamps.py):
+// chunk 6 of workgroup 7's first round, s_memtime per wave at: chunk top, operands split, barrier passed, loads issued, products done
+#ifdef QENV_DT3_STAMPS
+__device__ unsigned long long dt3_stamps[8 * 8];
+#define DT3_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (stamp_on && lane == 0) dt3_stamps[wave * 8 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DT3_STAMP(k)
+#endif
+
+template <bool ROWS>   // ROWS: the features sample-major (DenseArgs::rows) -- a template parameter: a run-time branch per k-step
+__global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   // would cut the product loop into basic blocks
     using namespace dt3;
     constexpr int BLOCK = 512, WPB = 8;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
@@ -1705,11 +1715,29 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
         // at 5.1-5.5 TB/s and the feature-major one at 1.3, tools/ubench/read_patterns.hip -- but this kernel runs 132-138 us
         // on either: how it reads is not what bounds it.)
         const uint32_t voff = !valid ? 0x80000000u
-                              : a.rows ? ((uint32_t)e * (uint32_t)a.K + 8u * (uint32_t)half) * 4u
+                              : ROWS ? ((uint32_t)e * (uint32_t)a.K + 8u * (uint32_t)half) * 4u
                                        : ((uint32_t)e + 8u * (uint32_t)half * N32) * 4u;
         float xw[KSC][8];
-        auto request_x = [&](int kc) {
+        auto request_x_step = [&](int kc, int s) {   // the eight features of k-step s of the chunk at kc
+#ifdef QENV_DT3_RUNTIME_ROWS   /* A/B: the layout as a run-time branch per k-step (basic-block boundaries around the loads) */
             if (a.rows) {
+#else
+            if constexpr (ROWS) {
+#endif
+                const bool in = kc + 16 * s + 8 * half < a.K;
+                const uint32_t vo = in ? voff : 0x80000000u;
+                const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (uint32_t)(kc + 16 * s) * 4u, 0);
+                const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (uint32_t)(kc + 16 * s + 4) * 4u, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xw[s][i] = __uint_as_float(lo[i]); xw[s][4 + i] = __uint_as_float(hi[i]); }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)(kc + 16 * s + i) * N32 * 4u, 0));
+        };
+        auto request_x = [&](int kc) {
+            if constexpr (ROWS) {
 #pragma unroll
                 for (int s = 0; s < KSC; ++s) {
                     const bool in = kc + 16 * s + 8 * half < a.K;   // (K % 8 == 0: a fragment is inside or outside as a whole;
@@ -1743,6 +1771,8 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
         request_x(0);
         for (int ic = 0; ic < n_kc; ++ic) {
             const int kc = ic * KC;
+            [[maybe_unused]] const bool stamp_on = blockIdx.x == 7 && r == 0 && (ic == 6 || ic == 7);
+            if (ic == 6) DT3_STAMP(0);
             {   // this thread's fragment of chunk ic -> its three bf16 terms in buffer ic & 1
                 const float w8[8] = {wlo.x * TANH_PRESCALE, wlo.y * TANH_PRESCALE, wlo.z * TANH_PRESCALE, wlo.w * TANH_PRESCALE,
                                      whi.x * TANH_PRESCALE, whi.y * TANH_PRESCALE, whi.z * TANH_PRESCALE, whi.w * TANH_PRESCALE};
@@ -1754,9 +1784,65 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
             bf16x8 xsp[KSC][3];
 #pragma unroll
             for (int s = 0; s < KSC; ++s) split3x8(xw[s], xsp[s][0], xsp[s][1], xsp[s][2]);
+            if (ic == 6) DT3_STAMP(1);
             __syncthreads();   // chunk ic is staged (and every wave has left chunk ic - 1, whose buffer chunk ic + 1 will overwrite)
-            if (ic + 1 < n_kc) { request_w1(kc + KC); request_x(kc + KC); }
+            if (ic == 6) DT3_STAMP(2);
+#ifndef QENV_DT3_SPREAD
+#define QENV_DT3_SPREAD 1   // 1: the next chunk's feature loads are issued k-step by k-step between this chunk's products instead of
+#endif                      //    in one burst behind the barrier (the stamps: the burst takes the last waves 5 k cycles to get accepted
+                            //    -- the CU's memory path passes ~12.6 B per clock -- and nothing is requested while they multiply)
+            if (ic + 1 < n_kc) { request_w1(kc + KC); if (!QENV_DT3_SPREAD) request_x(kc + KC); }
+            if (ic == 6) DT3_STAMP(3);
             const uint4* frag = lds4 + (ic & 1) * W1B + lane;
+#ifndef QENV_DT3_PIPE
+#define QENV_DT3_PIPE 1   // 1: a k-step's six weight fragments are read while the k-step before multiplies, the two output
+#endif                    //    tiles' products alternate (A/B: -DQENV_DT3_PIPE=0)
+#if QENV_DT3_PIPE
+            {
+                bf16x8 A[2][NT][3];
+                auto ldA = [&](int s_, bf16x8 (&f_)[NT][3]) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) f_[t][k] = __builtin_bit_cast(bf16x8, frag[((t * KSC + s_) * 3 + k) * 64]);
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                ldA(0, A[0]);
+#pragma unroll
+                for (int s = 0; s < KSC; ++s) {
+                    const int cu = s & 1;
+                    if (s + 1 < KSC) ldA(s + 1, A[cu ^ 1]);
+                    if (QENV_DT3_SPREAD && ic + 1 < n_kc) request_x_step(kc + KC, s);
+                    // (the same six products per tile in the same order: bit-identical sums)
+                    acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][0][1], xsp[s][1], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][1][1], xsp[s][1], acc1[1], 0, 0, 0);
+                    acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][0][2], xsp[s][0], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][1][2], xsp[s][0], acc1[1], 0, 0, 0);
+                    acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][0][0], xsp[s][2], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][1][0], xsp[s][2], acc1[1], 0, 0, 0);
+                    acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][0][1], xsp[s][0], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][1][1], xsp[s][0], acc1[1], 0, 0, 0);
+                    acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][0][0], xsp[s][1], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][1][0], xsp[s][1], acc1[1], 0, 0, 0);
+                    acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][0][0], xsp[s][0], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][1][0], xsp[s][0], acc1[1], 0, 0, 0);
+                }
+                // the order asked of the scheduler: a k-step's fragment reads and its share of the next chunk's feature loads in
+                // front of the k-step's products (left alone hipcc gathers all the loads at the top of the loop: the burst again;
+                // in four pieces between the products: 124 us against 116)
+                constexpr int NLD = ROWS ? 2 : 8;
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                for (int s = 0; s < KSC; ++s) {
+                    if (s + 1 < KSC) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                    if (QENV_DT3_SPREAD && ic + 1 < n_kc) __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ic == 6) DT3_STAMP(4);
+            if (ic == 7) DT3_STAMP(5);   // (the same point one chunk later: a whole chunk period)
+#else
 #pragma unroll
             for (int s = 0; s < KSC; ++s)
 #pragma unroll
@@ -1771,6 +1857,7 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {
                     acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[s][1], acc1[t], 0, 0, 0);
                     acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[s][0], acc1[t], 0, 0, 0);
                 }
+#endif
         }
         __syncthreads();   // every wave has left the last chunk: the next round restages buffer 0
         // ---- layer 2 on the matrix cores, layer 3 on the vector lanes (see k_mlp_v3)
@@ -1832,11 +1919,13 @@ template <int H> static int launch_dense(const DenseArgs& a, hipStream_t stream)
         const int64_t n_tiles3 = ((a.N + 31) / 32) * a.n_chunks;
         if (bf16 && a.K % 8 == 0 && n_tiles3 >= 2048) {
             const size_t lds3 = sizeof(uint4) * (size_t)dt3::LDS_UINT4;
-            hipError_t e3 = allow_dynamic_lds((const void*)k_dense_tail_v3, lds3);
+            const void* fn3 = a.rows ? (const void*)k_dense_tail_v3<true> : (const void*)k_dense_tail_v3<false>;
+            hipError_t e3 = allow_dynamic_lds(fn3, lds3);
             if (e3 != hipSuccess) return fail_hip(e3, "hipFuncSetAttribute(k_dense_tail_v3)");
             int64_t blocks3 = (n_tiles3 + 7) / 8;
             if (blocks3 > 256) blocks3 = 256;
-            hipLaunchKernelGGL(k_dense_tail_v3, dim3((unsigned)blocks3), dim3(512), lds3, stream, a);
+            if (a.rows) hipLaunchKernelGGL(k_dense_tail_v3<true>, dim3((unsigned)blocks3), dim3(512), lds3, stream, a);
+            else hipLaunchKernelGGL(k_dense_tail_v3<false>, dim3((unsigned)blocks3), dim3(512), lds3, stream, a);
             return check_launch("k_dense_tail_v3");
         }
     }
@@ -2417,6 +2506,12 @@ int qenv_dense_tail_rows(int64_t n, int k_in, int hidden, int n_out, int final_t
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3; a.out = out;
     return launch_dense<64>(a, (hipStream_t)stream);
 }
+
+#ifdef QENV_DT3_STAMPS   /* diagnostic builds only (not declared in qenv.h) */
+int qenv_debug_dt3_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(qenv::dt3_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int qenv_dense_tail(int64_t n, int k_in, int hidden, int n_out, int final_tanh, const float* x, const float* W1,
                     const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* out,
