@@ -762,7 +762,7 @@ def next_rows(dev, policy):
     mfma3 = (K // 16 + (1 if K % 16 else 0) + 4) * 2 * 6     # split-bf16 32x32x16 MFMAs per 32-sample tile: layers 1 and 2, two output tiles
     out["dense_tail_800_64_64_3"] = {"samples": N, "kernel": "k_dense_tail_v3 (split-bf16 matrix cores, fp32-accurate; W1 streamed as fragments)",
                                      "kernel_us": us, "samples_per_s": N / us * 1e6,
-                                     "bound": "the CU's fill rate: ~10 B per clock for 88 % of a chunk's period, at the clock an MFMA-dense loop holds "
+                                     "bound": "the CU's fill rate (~10 B per clock) while it multiplies, nothing requested in the split / barrier phases "
                                               "(profiles/r05_dense_tail_stamps.json: the next chunk's loads go out k-step by k-step between the products; "
                                               "in one burst behind the chunk barrier they took the last waves 5 k cycles to get accepted: 135 us); "
                                               "HBM traffic = the features once",
