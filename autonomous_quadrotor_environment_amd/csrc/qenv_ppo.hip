@@ -1717,8 +1717,12 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   //
         const uint32_t voff = !valid ? 0x80000000u
                               : ROWS ? ((uint32_t)e * (uint32_t)a.K + 8u * (uint32_t)half) * 4u
                                        : ((uint32_t)e + 8u * (uint32_t)half * N32) * 4u;
-        float xw[KSC][8];
-        auto request_x_step = [&](int kc, int s) {   // the eight features of k-step s of the chunk at kc
+#ifndef QENV_DT3_RING
+#define QENV_DT3_RING 1   // feature chunks in flight: chunk ic + RING is requested between the products of chunk ic.  2: 120-126 us against
+                          // 130-134 on one box, 122-128 against 122-124 on another (within the boxes' noise); 3 spills (193 us): 1 stays
+#endif
+        float xring[QENV_DT3_RING][KSC][8];
+        auto request_x_step = [&](int kc, int s, float (&xw)[KSC][8]) {   // the eight features of k-step s of the chunk at kc
 #ifdef QENV_DT3_RUNTIME_ROWS   /* A/B: the layout as a run-time branch per k-step (basic-block boundaries around the loads) */
             if (a.rows) {
 #else
@@ -1736,7 +1740,7 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   //
             for (int i = 0; i < 8; ++i)
                 xw[s][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)(kc + 16 * s + i) * N32 * 4u, 0));
         };
-        auto request_x = [&](int kc) {
+        auto request_x = [&](int kc, float (&xw)[KSC][8]) {
             if constexpr (ROWS) {
 #pragma unroll
                 for (int s = 0; s < KSC; ++s) {
@@ -1768,8 +1772,10 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   //
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc1[t][j] = b1s[32 * t + acc_row(j, half)];
         request_w1(0);
-        request_x(0);
-        for (int ic = 0; ic < n_kc; ++ic) {
+#pragma unroll
+        for (int b = 0; b < QENV_DT3_RING; ++b)
+            if (b < n_kc) request_x(b * KC, xring[b]);
+        auto do_chunk = [&](int ic, float (&xw)[KSC][8]) {
             const int kc = ic * KC;
             [[maybe_unused]] const bool stamp_on = blockIdx.x == 7 && r == 0 && (ic == 6 || ic == 7);
             if (ic == 6) DT3_STAMP(0);
@@ -1791,7 +1797,8 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   //
 #define QENV_DT3_SPREAD 1   // 1: the next chunk's feature loads are issued k-step by k-step between this chunk's products instead of
 #endif                      //    in one burst behind the barrier (the stamps: the burst takes the last waves 5 k cycles to get accepted
                             //    -- the CU's memory path passes ~12.6 B per clock -- and nothing is requested while they multiply)
-            if (ic + 1 < n_kc) { request_w1(kc + KC); if (!QENV_DT3_SPREAD) request_x(kc + KC); }
+            if (ic + 1 < n_kc) request_w1(kc + KC);
+            if (!QENV_DT3_SPREAD && ic + QENV_DT3_RING < n_kc) request_x(kc + QENV_DT3_RING * KC, xw);
             if (ic == 6) DT3_STAMP(3);
             const uint4* frag = lds4 + (ic & 1) * W1B + lane;
 #ifndef QENV_DT3_PIPE
@@ -1812,7 +1819,7 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   //
                 for (int s = 0; s < KSC; ++s) {
                     const int cu = s & 1;
                     if (s + 1 < KSC) ldA(s + 1, A[cu ^ 1]);
-                    if (QENV_DT3_SPREAD && ic + 1 < n_kc) request_x_step(kc + KC, s);
+                    if (QENV_DT3_SPREAD && ic + QENV_DT3_RING < n_kc) request_x_step(kc + QENV_DT3_RING * KC, s, xw);
                     // (the same six products per tile in the same order: bit-identical sums)
                     acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][0][1], xsp[s][1], acc1[0], 0, 0, 0);
                     acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cu][1][1], xsp[s][1], acc1[1], 0, 0, 0);
@@ -1835,7 +1842,7 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   //
 #pragma unroll
                 for (int s = 0; s < KSC; ++s) {
                     if (s + 1 < KSC) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-                    if (QENV_DT3_SPREAD && ic + 1 < n_kc) __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);
+                    if (QENV_DT3_SPREAD && ic + QENV_DT3_RING < n_kc) __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1858,6 +1865,11 @@ __global__ __launch_bounds__(512) void k_dense_tail_v3(const DenseArgs a) {   //
                     acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xsp[s][0], acc1[t], 0, 0, 0);
                 }
 #endif
+        };
+        for (int ic = 0; ic < n_kc; ic += QENV_DT3_RING) {   // (the ring slot is a compile-time index: the registers of a slot)
+#pragma unroll
+            for (int b = 0; b < QENV_DT3_RING; ++b)
+                if (ic + b < n_kc) do_chunk(ic + b, xring[b]);
         }
         __syncthreads();   // every wave has left the last chunk: the next round restages buffer 0
         // ---- layer 2 on the matrix cores, layer 3 on the vector lanes (see k_mlp_v3)
